@@ -1,0 +1,132 @@
+/*
+ * scorp_gs.h — C ABI of libscorp_gs.so, the MI355X (gfx950) Gaussian-splat rasterization backend.
+ *
+ * This is the drop-in boundary for the one hot path of PolySummit/SCORP: everything below
+ * `GaussianRasterizer(raster_settings)(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+ * cov3D_precomp)` in gs3dgs/gaussian_renderer/__init__.py:51-66,101-111 (and its 2DGS twin,
+ * gs2dgs/gaussian_renderer/__init__.py:51-67,111-120) plus `simple_knn._C.distCUDA2`
+ * (gs3dgs/scene/gaussian_model.py:22,177).  The reference binds those through three third-party CUDA torch
+ * extensions (`diff_gaussian_rasterization`, `diff_surfel_rasterization`, `simple_knn`; .gitmodules:7-17)
+ * whose source is not in the reference tree, so there is no upstream C signature to match: the entry points
+ * below are what a ctypes / pybind / cgo binding for this path binds instead.  Plain C: raw device pointers,
+ * ints and floats; no torch or pybind types.
+ *
+ * Conventions (all fixed by the reference's call site):
+ *   - every array is fp32, contiguous, resident on the current HIP device, owned by the caller;
+ *   - matrices are the 16 floats of the *transposed* 4x4 the reference stores (row-vector convention,
+ *     gs3dgs/scene/cameras.py:82-97), i.e. element [r][c] of the maths matrix is m[c*4 + r];
+ *   - quaternions are (w,x,y,z) and already normalised by the caller (gaussian_model.py:131-132);
+ *   - cov3D_precomp is xx,xy,xz,yy,yz,zz (gs3dgs/utils/general_utils.py:79-88);
+ *   - shs is [N, sh_coeffs, 3]; only the first (sh_degree+1)^2 coefficients are read;
+ *   - exactly one of {shs, colors_precomp} and one of {scales+rotations, cov3D_precomp} is non-NULL;
+ *   - outputs: color[3,H,W] (background composited), depth[1,H,W] = sum z*alpha*T (NOT normalised: the caller
+ *     divides by alpha, gaussian_renderer/__init__.py:113), alpha[1,H,W] = sum alpha*T, radii[N] int32.
+ *
+ * Threading: re-entrant; all work is enqueued on the stream passed in; the only host synchronisation is in
+ * scorp_gs3d_num_pairs().  Errors: 0 = ok, negative = failure with a message in scorp_last_error()
+ * (thread-local).  With `debug` set every kernel is followed by a stream sync + error check
+ * (the reference's `pipe.debug`, gaussian_renderer/__init__.py:63).
+ */
+#ifndef SCORP_GS_H
+#define SCORP_GS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *scorp_stream_t; /* a hipStream_t (NULL = the default stream) */
+
+#define SCORP_OK 0
+#define SCORP_ERR_INVALID (-1)   /* bad argument (NULL, size, shape) */
+#define SCORP_ERR_HIP (-2)       /* a HIP call or kernel failed */
+#define SCORP_ERR_OVERFLOW (-3)  /* the pair buffer was smaller than the number of (tile,splat) pairs */
+
+/* The 12 fields of GaussianRasterizationSettings (gaussian_renderer/__init__.py:51-64) + the 8 call arguments. */
+typedef struct ScorpGs3dInputs {
+  int32_t num_gaussians;    /* N */
+  int32_t sh_degree;        /* active degree, 0..3 */
+  int32_t sh_coeffs;        /* coefficients allocated per Gaussian in `shs` (= (max_sh_degree+1)^2) */
+  int32_t image_width;
+  int32_t image_height;
+  float tanfovx;
+  float tanfovy;
+  float scale_modifier;
+  int32_t prefiltered;      /* accepted for signature parity; the reference always passes False */
+  int32_t debug;
+  const float *bg;          /* [3]  device */
+  const float *viewmatrix;  /* [16] device */
+  const float *projmatrix;  /* [16] device */
+  const float *campos;      /* [3]  device */
+  const float *means3D;     /* [N,3] */
+  const float *shs;         /* [N,sh_coeffs,3] or NULL */
+  const float *colors_precomp; /* [N,3] or NULL */
+  const float *opacities;   /* [N] (the reference passes [N,1]) */
+  const float *scales;      /* [N,3] or NULL */
+  const float *rotations;   /* [N,4] or NULL */
+  const float *cov3D_precomp; /* [N,6] or NULL */
+} ScorpGs3dInputs;
+
+/* Gradients w.r.t. the 8 call arguments; any pointer may be NULL (not wanted). Each is fully overwritten. */
+typedef struct ScorpGs3dGrads {
+  float *means3D;        /* [N,3] */
+  float *means2D;        /* [N,3]: (dL/dndc_x, dL/dndc_y, 0) — consumed by add_densification_stats, gaussian_model.py:603-605 */
+  float *shs;            /* [N,sh_coeffs,3] */
+  float *colors_precomp; /* [N,3] */
+  float *opacities;      /* [N] */
+  float *scales;         /* [N,3] */
+  float *rotations;      /* [N,4] */
+  float *cov3D_precomp;  /* [N,6] */
+} ScorpGs3dGrads;
+
+int scorp_version(void);
+const char *scorp_last_error(void);
+
+/* ---- workspace sizing (pure host arithmetic) ---- */
+/* Forward state: per-Gaussian projected records, per-tile ranges, per-pixel final-T / last-contributor. */
+size_t scorp_gs3d_state_bytes(int32_t num_gaussians, int32_t image_width, int32_t image_height);
+/* Pair buffer for `capacity` (tile,splat) pairs: unsorted 64-bit keys + the depth-sorted 32-bit splat list. */
+size_t scorp_gs3d_pairs_bytes(uint64_t capacity);
+/* Scratch of one backward call (per-Gaussian screen-space gradient accumulators). */
+size_t scorp_gs3d_backward_scratch_bytes(int32_t num_gaussians);
+
+/* ---- forward, in three steps so the caller owns every allocation ---- */
+/* 1. project + cull every Gaussian, count splats per tile, prefix-sum the counts. Enqueue only.
+ *    Writes radii[N]. `state` must be scorp_gs3d_state_bytes() large and 256-byte aligned. */
+int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_radii, void *state, size_t state_bytes,
+                          scorp_stream_t stream);
+/* 2. number of (tile,splat) pairs of the preprocess just enqueued. Synchronises the stream (one 8-byte D2H).
+ *    A caller that sizes the pair buffer from a previous view may skip this and check
+ *    scorp_gs3d_check_overflow() later instead. */
+int scorp_gs3d_num_pairs(const void *state, scorp_stream_t stream, uint64_t *num_pairs);
+/* 3. bucket pairs by tile, depth-sort each tile, blend front to back. Enqueue only. If the pair buffer is too
+ *    small nothing is written out of bounds, outputs are undefined and scorp_gs3d_check_overflow() reports it. */
+int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
+                      float *out_depth, float *out_alpha, scorp_stream_t stream);
+/* Synchronises; returns SCORP_ERR_OVERFLOW if the last render on this state needed more than `capacity` pairs
+ * (and the needed count in *num_pairs), SCORP_OK otherwise. */
+int scorp_gs3d_check_overflow(const void *state, scorp_stream_t stream, uint64_t *num_pairs);
+
+/* ---- backward ---- */
+/* `state` and `pairs` are the buffers of the matching forward and are only READ, so several backward passes
+ * may run on one forward (utils/mask.py:52,65,89 does). dL_dcolor[3,H,W]; dL_ddepth / dL_dalpha [H,W] or NULL. */
+int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
+                        const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                        const ScorpGs3dGrads *grads, void *scratch, size_t scratch_bytes, scorp_stream_t stream);
+
+/* ---- introspection for stage-level parity tests (device->host copies; synchronises) ---- */
+/* xy[N,2], depth[N], conic_opacity[N,4], rgb[N,3], rect[N,4] (tile units, max exclusive); any may be NULL. */
+int scorp_gs3d_debug_geom(const void *state, int32_t num_gaussians, int32_t image_width, int32_t image_height,
+                          float *xy, float *depth, float *conic_opacity, float *rgb, int32_t *rect,
+                          scorp_stream_t stream);
+/* tile_start[tiles+1] (uint32) and the sorted splat list point_list[num_pairs] (uint32). */
+int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint64_t capacity, int32_t num_gaussians,
+                           int32_t image_width, int32_t image_height, uint32_t *tile_start, uint32_t *point_list,
+                           scorp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCORP_GS_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of libscorp_gs.so (C ABI in include/scorp_gs.h).
+
+There is no CPU or PyTorch fallback: if the HIP library is missing or fails to load, importing the
+rasterizer raises.  Build it with `python -m scorp_amd.build` (or __graft_entry__.build()).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscorp_gs.so")
+
+c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
+
+
+class ScorpGs3dInputs(ctypes.Structure):
+    _fields_ = [
+        ("num_gaussians", ctypes.c_int32), ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
+        ("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32),
+        ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("scale_modifier", ctypes.c_float),
+        ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+        ("bg", c_float_p), ("viewmatrix", c_float_p), ("projmatrix", c_float_p), ("campos", c_float_p),
+        ("means3D", c_float_p), ("shs", c_float_p), ("colors_precomp", c_float_p), ("opacities", c_float_p),
+        ("scales", c_float_p), ("rotations", c_float_p), ("cov3D_precomp", c_float_p),
+    ]
+
+
+class ScorpGs3dGrads(ctypes.Structure):
+    _fields_ = [(n, c_float_p) for n in ("means3D", "means2D", "shs", "colors_precomp", "opacities", "scales",
+                                         "rotations", "cov3D_precomp")]
+
+
+EXPORTS = [
+    "scorp_version", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
+    "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
+    "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m scorp_amd.build` "
+            "(needs /opt/rocm/bin/hipcc). scorp_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u64, i32, sz = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
+    L.scorp_version.restype = ctypes.c_int
+    L.scorp_last_error.restype = ctypes.c_char_p
+    L.scorp_gs3d_state_bytes.restype = sz
+    L.scorp_gs3d_state_bytes.argtypes = [i32, i32, i32]
+    L.scorp_gs3d_pairs_bytes.restype = sz
+    L.scorp_gs3d_pairs_bytes.argtypes = [u64]
+    L.scorp_gs3d_backward_scratch_bytes.restype = sz
+    L.scorp_gs3d_backward_scratch_bytes.argtypes = [i32]
+    L.scorp_gs3d_preprocess.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, sz, vp]
+    L.scorp_gs3d_num_pairs.argtypes = [vp, vp, ctypes.POINTER(u64)]
+    L.scorp_gs3d_render.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp, vp]
+    L.scorp_gs3d_check_overflow.argtypes = [vp, vp, ctypes.POINTER(u64)]
+    L.scorp_gs3d_backward.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp,
+                                      ctypes.POINTER(ScorpGs3dGrads), vp, sz, vp]
+    L.scorp_gs3d_debug_geom.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.scorp_gs3d_debug_tiles.argtypes = [vp, vp, u64, i32, i32, i32, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().scorp_last_error()
+        raise RuntimeError(f"{what} failed ({code}): {msg.decode(errors='replace') if msg else ''}")

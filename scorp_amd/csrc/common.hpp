@@ -1,0 +1,113 @@
+// common.hpp — shared device records, workspace layout and host-side error plumbing of libscorp_gs.
+// gfx950 only (wave64, 160 KiB LDS); no dual-backend paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "scorp_gs.h"
+
+namespace scorp {
+
+// ---- constants of the published 3DGS algorithm (named as in oracle/gs3d_oracle.c) ----
+constexpr int kTile = 16;
+constexpr float kNearZ = 0.2f;
+constexpr float kDilation = 0.3f;
+constexpr float kFovGuard = 1.3f;
+constexpr float kRadiusSigma = 3.0f;
+constexpr float kLambdaFloor = 0.1f;
+constexpr float kAlphaMax = 0.99f;
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kTMin = 0.0001f;
+constexpr float kWEps = 0.0000001f;
+constexpr float kDet2Eps = 0.0000001f;
+
+// ---- device records ----
+// One projected splat as the blend kernels gather it: three 16-byte loads from one 48-byte record.
+struct alignas(16) SplatRec {
+  float x, y, A, B;         // pixel-space centre, conic A,B
+  float C, o, r, g;         // conic C, opacity, colour r,g
+  float b, depth, rcut, _;  // colour b, view-space z, alpha>=1/255 cutoff radius (px)
+};
+static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
+
+// What the binning kernels stream per Gaussian (16 bytes, coalesced).
+struct alignas(16) BinRec {
+  uint16_t x0, y0, x1, y1;  // tile rectangle, max exclusive
+  uint32_t depth_bits;      // fp32 bits of view-space z (> 0, so unsigned order == float order)
+  int32_t radius;           // bits 0..27: pixel radius (0 = culled); bits 28..30: SH colour clamp mask (r,g,b)
+};
+static_assert(sizeof(BinRec) == 16, "BinRec must be 16 bytes");
+constexpr int kClampShift = 28;
+constexpr int32_t kRadiusMask = 0x0FFFFFFF;
+
+struct StateHeader {
+  uint32_t num_pairs;  // D of the last preprocess
+  uint32_t overflow;   // 1 if the last render needed more than `capacity`
+  uint32_t capacity;   // capacity the last render ran with
+  uint32_t _pad[13];
+};
+static_assert(sizeof(StateHeader) == 64, "StateHeader must be 64 bytes");
+
+// Per-Gaussian screen-space gradient accumulator filled by the blend backward (float atomics), 48 bytes.
+constexpr int kAccStride = 12;  // dx, dy, dA, dB, dC, dopacity, dr, dg, db, ddepth, pad, pad
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Forward state layout (one caller-owned blob, 256-byte aligned sub-buffers).
+struct StateLayout {
+  size_t header, rec, bin, tile_count, tile_start, final_T, n_contrib, total;
+  int tiles_x, tiles_y, tiles;
+  StateLayout(int N, int W, int H) {
+    tiles_x = (W + kTile - 1) / kTile;
+    tiles_y = (H + kTile - 1) / kTile;
+    tiles = tiles_x * tiles_y;
+    size_t n = N > 0 ? (size_t)N : 1, hw = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
+    size_t off = 0;
+    header = off; off = align_up(off + sizeof(StateHeader), 256);
+    rec = off; off = align_up(off + n * sizeof(SplatRec), 256);
+    bin = off; off = align_up(off + n * sizeof(BinRec), 256);
+    tile_count = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
+    tile_start = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
+    final_T = off; off = align_up(off + hw * 4, 256);
+    n_contrib = off; off = align_up(off + hw * 4, 256);
+    total = off;
+  }
+};
+
+// Pair buffer: keys[capacity] u64 (depth_bits<<32 | splat) bucketed by tile, then point_list[capacity] u32.
+struct PairLayout {
+  size_t keys, list, total;
+  explicit PairLayout(uint64_t capacity) {
+    size_t c = capacity > 0 ? (size_t)capacity : 1;
+    keys = 0;
+    list = align_up(c * 8, 256);
+    total = align_up(list + c * 4, 256);
+  }
+};
+
+// ---- host error plumbing ----
+void set_error(const char *fmt, ...);
+
+#define SCORP_HIP_CHECK(expr)                                                                    \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) {                                                                      \
+      scorp::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return SCORP_ERR_HIP;                                                                      \
+    }                                                                                            \
+  } while (0)
+
+// After a kernel launch: always catch launch errors; in debug mode also sync and catch execution errors.
+#define SCORP_KERNEL_CHECK(name, debug, stream)                                                   \
+  do {                                                                                            \
+    hipError_t _e = hipGetLastError();                                                            \
+    if (_e == hipSuccess && (debug)) _e = hipStreamSynchronize(stream);                           \
+    if (_e != hipSuccess) {                                                                       \
+      scorp::set_error("kernel %s failed: %s", name, hipGetErrorString(_e));                      \
+      return SCORP_ERR_HIP;                                                                       \
+    }                                                                                             \
+  } while (0)
+
+}  // namespace scorp

@@ -1,0 +1,575 @@
+// gs3d_forward.hip — 3DGS forward for gfx950: project -> per-tile count -> scan -> bucket -> per-tile LDS depth
+// sort -> front-to-back blend.
+//
+// Replaces the forward half of `diff_gaussian_rasterization` as called at
+// gs3dgs/gaussian_renderer/__init__.py:101-111.  The arithmetic follows oracle/gs3d_oracle.c (the CPU
+// restatement of the published algorithm); the pipeline does not follow the CUDA original's
+// duplicate-with-64-bit-keys + global radix sort: (tile,splat) pairs are counted per tile while projecting,
+// bucketed by tile with one atomic per pair, and each tile's list (a few hundred entries) is depth-sorted in
+// LDS by the workgroup that owns the tile.  Ties in depth are broken by splat index, which makes the order —
+// and therefore the image — independent of atomic arrival order.
+#include "common.hpp"
+
+namespace scorp {
+namespace {
+
+struct Camera {
+  float view[16];
+  float proj[16];
+  float campos[3];
+};
+
+__device__ __forceinline__ Camera load_camera(const float *__restrict__ view, const float *__restrict__ proj,
+                                              const float *__restrict__ campos) {
+  Camera c;
+#pragma unroll
+  for (int i = 0; i < 16; i++) { c.view[i] = view[i]; c.proj[i] = proj[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; i++) c.campos[i] = campos[i];
+  return c;
+}
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+// SH -> RGB for one Gaussian (gs3dgs/utils/sh_utils.py:57-112 restated for the [K,3] layout the rasterizer gets).
+__device__ __forceinline__ void sh_to_rgb(int deg, const float *__restrict__ sh, float x, float y, float z,
+                                          float *rgb) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float r = SH_C0 * sh[c];
+    if (deg > 0) {
+      r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+      if (deg > 1) {
+        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        r = r + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] + SH_C2[2] * (2 * zz - xx - yy) * sh[18 + c] +
+            SH_C2[3] * xz * sh[21 + c] + SH_C2[4] * (xx - yy) * sh[24 + c];
+        if (deg > 2) {
+          r = r + SH_C3[0] * y * (3 * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
+              SH_C3[2] * y * (4 * zz - xx - yy) * sh[33 + c] + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[36 + c] +
+              SH_C3[4] * x * (4 * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
+              SH_C3[6] * x * (xx - 3 * yy) * sh[45 + c];
+        }
+      }
+    }
+    rgb[c] = r + 0.5f;
+  }
+}
+
+// Load the first 3*(deg+1)^2 floats of one Gaussian's SH block; 16-byte loads when the block is 16-byte aligned.
+__device__ __forceinline__ void load_sh(const float *__restrict__ base, int K, int deg, float *sh) {
+  const int nfl = 3 * (deg + 1) * (deg + 1);
+  if ((K & 3) == 0) {
+    const float4 *b4 = reinterpret_cast<const float4 *>(base);
+#pragma unroll
+    for (int q = 0; q < 12; q++)
+      if (q * 4 < nfl) {
+        float4 v = b4[q];
+        sh[q * 4 + 0] = v.x; sh[q * 4 + 1] = v.y; sh[q * 4 + 2] = v.z; sh[q * 4 + 3] = v.w;
+      }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 48; q++)
+      if (q < nfl) sh[q] = base[q];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: per-Gaussian projection. One thread per Gaussian.  Floating-point contraction is OFF in this kernel so
+// the discrete decisions (cull, radius, tile rectangle) round exactly like the CPU oracle; it is HBM-bound
+// (236 B in, 68 B out per Gaussian), so the extra multiplies are free.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+preprocess_kernel(int N, int K, int deg, int W, int H, float tanfovx, float tanfovy, float scale_mod,
+                  const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
+                  const float *__restrict__ campos_p, const float *__restrict__ means3D,
+                  const float *__restrict__ shs, const float *__restrict__ colors_precomp,
+                  const float *__restrict__ opacities, const float *__restrict__ scales,
+                  const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
+                  SplatRec *__restrict__ rec, BinRec *__restrict__ bin, int32_t *__restrict__ radii,
+                  uint32_t *__restrict__ tile_count, int tiles_x, int tiles_y) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const Camera cam = load_camera(viewmatrix, projmatrix, campos_p);
+  const float *vm = cam.view, *pm = cam.proj;
+  BinRec br;
+  br.x0 = br.y0 = br.x1 = br.y1 = 0; br.depth_bits = 0; br.radius = 0;
+  int radius_out = 0;
+  const float px_ = means3D[3 * (size_t)i], py_ = means3D[3 * (size_t)i + 1], pz_ = means3D[3 * (size_t)i + 2];
+  const float tx = vm[0] * px_ + vm[4] * py_ + vm[8] * pz_ + vm[12];
+  const float ty = vm[1] * px_ + vm[5] * py_ + vm[9] * pz_ + vm[13];
+  const float tz = __builtin_fmaf(vm[10], pz_, __builtin_fmaf(vm[6], py_, __builtin_fmaf(vm[2], px_, vm[14])));
+  if (tz > kNearZ) {
+    const float hx = pm[0] * px_ + pm[4] * py_ + pm[8] * pz_ + pm[12];
+    const float hy = pm[1] * px_ + pm[5] * py_ + pm[9] * pz_ + pm[13];
+    const float hw = pm[3] * px_ + pm[7] * py_ + pm[11] * pz_ + pm[15];
+    const float pw = 1.0f / (hw + kWEps);
+    const float ndcx = hx * pw, ndcy = hy * pw;
+    float c6[6];
+    if (cov3D_precomp) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) c6[q] = cov3D_precomp[6 * (size_t)i + q];
+    } else {
+      const float4 q4 = reinterpret_cast<const float4 *>(rotations)[i];
+      const float r = q4.x, x = q4.y, y = q4.z, z = q4.w;
+      const float s0 = scale_mod * scales[3 * (size_t)i], s1 = scale_mod * scales[3 * (size_t)i + 1],
+                  s2 = scale_mod * scales[3 * (size_t)i + 2];
+      float L[9];
+      L[0] = (1 - 2 * (y * y + z * z)) * s0; L[1] = (2 * (x * y - r * z)) * s1;     L[2] = (2 * (x * z + r * y)) * s2;
+      L[3] = (2 * (x * y + r * z)) * s0;     L[4] = (1 - 2 * (x * x + z * z)) * s1; L[5] = (2 * (y * z - r * x)) * s2;
+      L[6] = (2 * (x * z - r * y)) * s0;     L[7] = (2 * (y * z + r * x)) * s1;     L[8] = (1 - 2 * (x * x + y * y)) * s2;
+      c6[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+      c6[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+      c6[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
+      c6[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+      c6[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
+      c6[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+    }
+    // EWA: M = J * Wrot (2x3), cov2D = M Sigma M^T + dilation
+    const float limx = kFovGuard * tanfovx, limy = kFovGuard * tanfovy;
+    const float txc = fminf(limx, fmaxf(-limx, tx / tz)) * tz;
+    const float tyc = fminf(limy, fmaxf(-limy, ty / tz)) * tz;
+    const float fx = (float)W / (2 * tanfovx), fy = (float)H / (2 * tanfovy);
+    const float J00 = fx / tz, J02 = -(fx * txc) / (tz * tz), J11 = fy / tz, J12 = -(fy * tyc) / (tz * tz);
+    float M0[3], M1[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      M0[c] = J00 * vm[c * 4 + 0] + J02 * vm[c * 4 + 2];
+      M1[c] = J11 * vm[c * 4 + 1] + J12 * vm[c * 4 + 2];
+    }
+    float s0v[3], s1v[3];
+    s0v[0] = c6[0] * M0[0] + c6[1] * M0[1] + c6[2] * M0[2];
+    s0v[1] = c6[1] * M0[0] + c6[3] * M0[1] + c6[4] * M0[2];
+    s0v[2] = c6[2] * M0[0] + c6[4] * M0[1] + c6[5] * M0[2];
+    s1v[0] = c6[0] * M1[0] + c6[1] * M1[1] + c6[2] * M1[2];
+    s1v[1] = c6[1] * M1[0] + c6[3] * M1[1] + c6[4] * M1[2];
+    s1v[2] = c6[2] * M1[0] + c6[4] * M1[1] + c6[5] * M1[2];
+    const float a = M0[0] * s0v[0] + M0[1] * s0v[1] + M0[2] * s0v[2] + kDilation;
+    const float b = M0[0] * s1v[0] + M0[1] * s1v[1] + M0[2] * s1v[2];
+    const float c = M1[0] * s1v[0] + M1[1] * s1v[1] + M1[2] * s1v[2] + kDilation;
+    const float det = a * c - b * b;
+    if (det != 0.0f) {
+      const float det_inv = 1.0f / det;
+      const float mid = 0.5f * (a + c);
+      const float disc = sqrtf(fmaxf(kLambdaFloor, mid * mid - det));
+      const float lam = fmaxf(mid + disc, mid - disc);
+      const int radius = (int)ceilf(kRadiusSigma * sqrtf(lam));
+      const float sx = ((ndcx + 1) * W - 1) * 0.5f, sy = ((ndcy + 1) * H - 1) * 0.5f;
+      const int x0 = min(tiles_x, max(0, (int)((sx - radius) / kTile)));
+      const int y0 = min(tiles_y, max(0, (int)((sy - radius) / kTile)));
+      const int x1 = min(tiles_x, max(0, (int)((sx + radius + kTile - 1) / kTile)));
+      const int y1 = min(tiles_y, max(0, (int)((sy + radius + kTile - 1) / kTile)));
+      if ((x1 - x0) * (y1 - y0) > 0) {
+        float rgb[3];
+        int clamp_bits = 0;
+        if (colors_precomp) {
+#pragma unroll
+          for (int q = 0; q < 3; q++) rgb[q] = colors_precomp[3 * (size_t)i + q];
+        } else {
+          float sh[48];
+          load_sh(shs + (size_t)i * K * 3, K, deg, sh);
+          const float dx = px_ - cam.campos[0], dy = py_ - cam.campos[1], dz = pz_ - cam.campos[2];
+          const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+          sh_to_rgb(deg, sh, dx * inv, dy * inv, dz * inv, rgb);
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            if (rgb[q] < 0.0f) clamp_bits |= 1 << q;  // remembered for the backward (zero gradient where clamped)
+            rgb[q] = fmaxf(rgb[q], 0.0f);
+          }
+        }
+        const float op = opacities[i];
+        // Beyond rcut the splat's alpha is < 1/255 everywhere (|d|^2 / (2 lambda_max) > ln(255 o)), so a pixel
+        // block farther than rcut can skip it without changing a single output bit. 1% + 0.1 px of slack.
+        const float lg = logf(fmaxf(255.0f * op, 1.0f));
+        const float rcut = 1.01f * sqrtf(2.0f * lam * lg) + 0.1f;
+        SplatRec s;
+        s.x = sx; s.y = sy; s.A = c * det_inv; s.B = -b * det_inv;
+        s.C = a * det_inv; s.o = op; s.r = rgb[0]; s.g = rgb[1];
+        s.b = rgb[2]; s.depth = tz; s.rcut = rcut; s._ = 0.0f;
+        float4 *dst = reinterpret_cast<float4 *>(rec + i);
+        dst[0] = make_float4(s.x, s.y, s.A, s.B);
+        dst[1] = make_float4(s.C, s.o, s.r, s.g);
+        dst[2] = make_float4(s.b, s.depth, s.rcut, 0.0f);
+        br.x0 = (uint16_t)x0; br.y0 = (uint16_t)y0; br.x1 = (uint16_t)x1; br.y1 = (uint16_t)y1;
+        br.depth_bits = __float_as_uint(tz);
+        br.radius = radius | (clamp_bits << kClampShift);
+        radius_out = radius;
+        for (int y = y0; y < y1; y++)
+          for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * tiles_x + x], 1u);
+      }
+    }
+  }
+  reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
+  radii[i] = radius_out;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: exclusive prefix sum of the per-tile counts (one workgroup; T is 7.5k at 1600x1200, <100k at 5400x4050).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+scan_tiles_kernel(const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_start, int tiles,
+                  StateHeader *__restrict__ header) {
+  __shared__ uint32_t s_part[1024];
+  const int t = threadIdx.x;
+  const int per = (tiles + 1023) / 1024;
+  const int lo = min(tiles, t * per), hi = min(tiles, lo + per);
+  uint32_t sum = 0;
+  for (int k = lo; k < hi; k++) sum += tile_count[k];
+  s_part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan over the 1024 partials
+    uint32_t v = t >= off ? s_part[t - off] : 0u;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = s_part[t] - sum;
+  for (int k = lo; k < hi; k++) {
+    tile_start[k] = run;
+    run += tile_count[k];
+  }
+  if (t == 1023) {
+    tile_start[tiles] = s_part[1023];
+    header->num_pairs = s_part[1023];
+    header->overflow = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: bucket (tile,splat) pairs by tile. The per-tile counter doubles as the cursor (counted back down to zero,
+// so it is clean for the next view). Slot order inside a tile is arbitrary; the sort below fixes it.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, uint32_t *__restrict__ tile_count,
+                     const uint32_t *__restrict__ tile_start, int tiles_x, uint64_t *__restrict__ keys,
+                     uint32_t capacity, StateHeader *__restrict__ header) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {
+    header->capacity = capacity;
+    if (header->num_pairs > capacity) header->overflow = 1;
+  }
+  if (i >= N) return;
+  const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
+  const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
+  if ((br.radius & kRadiusMask) == 0) return;
+  const uint64_t key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
+  for (int y = br.y0; y < br.y1; y++)
+    for (int x = br.x0; x < br.x1; x++) {
+      const int t = y * tiles_x + x;
+      const uint32_t slot = tile_start[t] + atomicSub(&tile_count[t], 1u) - 1u;
+      if (slot < capacity) keys[slot] = key;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K4: per-tile depth sort. One workgroup per tile; bitonic network (all-ascending "flip" form, so virtual +inf
+// padding never moves) in LDS for lists up to kSortLds entries, in global memory (same network) beyond that.
+// Output: point_list = splat indices front to back.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSortLds = 4096;  // 32 KiB of 64-bit keys
+
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort(Ptr a, uint32_t n, uint32_t P) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t k = 2; k <= P; k <<= 1) {
+    const uint32_t half = k >> 1;
+    for (uint32_t i = tid; i < (P >> 1); i += 256) {  // flip step: lo <-> mirrored partner inside each k-block
+      const uint32_t lo = (i / half) * k + (i % half);
+      const uint32_t hi = (i / half) * k + (k - 1 - (i % half));
+      if (hi < n) {
+        const uint64_t u = a[lo], v = a[hi];
+        if (u > v) { a[lo] = v; a[hi] = u; }
+      }
+    }
+    __syncthreads();
+    for (uint32_t j = half >> 1; j >= 1; j >>= 1) {
+      for (uint32_t i = tid; i < (P >> 1); i += 256) {
+        const uint32_t lo = 2 * j * (i / j) + (i % j);
+        const uint32_t hi = lo + j;
+        if (hi < n) {
+          const uint64_t u = a[lo], v = a[hi];
+          if (u > v) { a[lo] = v; a[hi] = u; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+sort_tiles_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict__ keys,
+                  uint32_t *__restrict__ point_list, uint32_t capacity, int lds_limit) {
+  __shared__ uint64_t s_keys[kSortLds];
+  const int tile = blockIdx.x;
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t n = end - beg;
+  if (n == 0) return;
+  uint32_t P = 1;
+  while (P < n) P <<= 1;
+  if (n <= (uint32_t)lds_limit) {
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s_keys[i] = keys[beg + i];
+    __syncthreads();
+    if (n > 1) bitonic_sort(s_keys, n, P);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[beg + i] = (uint32_t)s_keys[i];
+  } else {
+    // Oversize tile: same network straight on global memory. Global accesses of one workgroup are made visible
+    // to its own waves by the barrier (same CU, same L1/L2).
+    __syncthreads();
+    bitonic_sort(keys + beg, n, P);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[beg + i] = (uint32_t)keys[beg + i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K5: front-to-back blend. One workgroup (4 wave64) per 16x16 tile; each wave owns an 8x8 pixel block.
+// Splat records are gathered 256 at a time into LDS; each wave first ballots which of them can reach its 8x8
+// block at all (distance to the block > rcut  =>  alpha < 1/255 on every pixel of the block), then walks only
+// those, reading each record from LDS at a wave-uniform address (broadcast, conflict-free).
+// ---------------------------------------------------------------------------------------------------------
+template <bool kCull>
+__global__ void __launch_bounds__(256)
+blend_forward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                     const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x,
+                     const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
+                     float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
+  __shared__ float4 s_a[256], s_b[256], s_c[256];
+  const int tile = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bx = (tile % tiles_x) * kTile + (wave & 1) * 8, by = (tile / tiles_x) * kTile + (wave >> 1) * 8;
+  const int px = bx + (lane & 7), py = by + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f, Wt = 0.0f;
+  uint32_t last = 0;
+  bool done = !inside;
+  for (uint32_t base = beg; base < end; base += 256) {
+    if (__syncthreads_and(done)) break;  // also the barrier that protects the LDS batch being overwritten
+    const uint32_t k = base + threadIdx.x;
+    if (k < end) {
+      const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[k]);
+      s_a[threadIdx.x] = src[0];
+      s_b[threadIdx.x] = src[1];
+      s_c[threadIdx.x] = src[2];
+    }
+    __syncthreads();
+    const int cnt = (int)min(256u, end - base);
+    for (int q = 0; q < cnt; q += 64) {
+      const int j = q + lane;
+      bool hit = false;
+      if (j < cnt) {
+        if (kCull) {
+          const float4 a = s_a[j];
+          const float rc = s_c[j].z;
+          const float ddx = fmaxf(fmaxf(bx0 - a.x, a.x - bx1), 0.0f), ddy = fmaxf(fmaxf(by0 - a.y, a.y - by1), 0.0f);
+          hit = ddx * ddx + ddy * ddy <= rc * rc;
+        } else {
+          hit = true;
+        }
+      }
+      uint64_t mask = __ballot(hit);
+      while (mask) {
+        const int jj = q + __builtin_ctzll(mask);
+        mask &= mask - 1;
+        if (done) continue;
+        const float4 a = s_a[jj], b = s_b[jj], c = s_c[jj];
+        const float dx = a.x - pxf, dy = a.y - pyf;
+        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+        if (power > 0.0f) continue;
+        const float alpha = fminf(kAlphaMax, b.y * __expf(power));
+        if (alpha < kAlphaMin) continue;
+        const float test_T = T * (1.0f - alpha);
+        if (test_T < kTMin) { done = true; continue; }
+        const float w = alpha * T;
+        C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
+        Dp += c.y * w;
+        Wt += w;
+        T = test_T;
+        last = (base - beg) + (uint32_t)jj + 1u;
+      }
+    }
+  }
+  if (inside) {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    out_color[pix] = C0 + T * bg[0];
+    out_color[HW + pix] = C1 + T * bg[1];
+    out_color[2 * HW + pix] = C2 + T * bg[2];
+    out_depth[pix] = Dp;
+    out_alpha[pix] = Wt;
+  }
+}
+
+int validate(const ScorpGs3dInputs *in) {
+  if (!in) { set_error("inputs is NULL"); return SCORP_ERR_INVALID; }
+  if (in->num_gaussians < 0 || in->image_width <= 0 || in->image_height <= 0) {
+    set_error("bad sizes: N=%d W=%d H=%d", in->num_gaussians, in->image_width, in->image_height);
+    return SCORP_ERR_INVALID;
+  }
+  if (in->image_width > 16 * 65535 || in->image_height > 16 * 65535) {
+    set_error("image larger than 65535 tiles per axis"); return SCORP_ERR_INVALID;
+  }
+  if (in->num_gaussians > 0) {
+    if (!in->means3D || !in->opacities) { set_error("means3D / opacities is NULL"); return SCORP_ERR_INVALID; }
+    if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) {
+      set_error("provide exactly one of shs / colors_precomp"); return SCORP_ERR_INVALID;
+    }
+    const bool sr = in->scales != nullptr && in->rotations != nullptr;
+    if (sr == (in->cov3D_precomp != nullptr) || ((in->scales != nullptr) != (in->rotations != nullptr))) {
+      set_error("provide exactly one of scales+rotations / cov3D_precomp"); return SCORP_ERR_INVALID;
+    }
+    if (in->shs) {
+      if (in->sh_degree < 0 || in->sh_degree > 3) { set_error("sh_degree %d not in 0..3", in->sh_degree); return SCORP_ERR_INVALID; }
+      if (in->sh_coeffs < (in->sh_degree + 1) * (in->sh_degree + 1)) {
+        set_error("sh_coeffs %d < (sh_degree+1)^2", in->sh_coeffs); return SCORP_ERR_INVALID;
+      }
+    }
+  }
+  if (!in->bg || !in->viewmatrix || !in->projmatrix || !in->campos) {
+    set_error("bg / viewmatrix / projmatrix / campos is NULL"); return SCORP_ERR_INVALID;
+  }
+  return SCORP_OK;
+}
+
+}  // namespace
+}  // namespace scorp
+
+using namespace scorp;
+
+extern "C" size_t scorp_gs3d_state_bytes(int32_t N, int32_t W, int32_t H) { return StateLayout(N, W, H).total; }
+extern "C" size_t scorp_gs3d_pairs_bytes(uint64_t capacity) { return PairLayout(capacity).total; }
+
+extern "C" int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_radii, void *state, size_t state_bytes,
+                                     scorp_stream_t stream_) {
+  if (int e = validate(in)) return e;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
+  const StateLayout L(N, W, H);
+  if (!state || state_bytes < L.total || ((uintptr_t)state & 255)) {
+    set_error("state buffer NULL, misaligned or too small (%zu < %zu)", state_bytes, L.total);
+    return SCORP_ERR_INVALID;
+  }
+  if (N > 0 && !out_radii) { set_error("out_radii is NULL"); return SCORP_ERR_INVALID; }
+  char *base = (char *)state;
+  uint32_t *tile_count = (uint32_t *)(base + L.tile_count);
+  SCORP_HIP_CHECK(hipMemsetAsync(tile_count, 0, ((size_t)L.tiles + 1) * 4, stream));
+  if (N > 0) {
+    preprocess_kernel<<<(N + 255) / 256, 256, 0, stream>>>(
+        N, in->sh_coeffs, in->sh_degree, W, H, in->tanfovx, in->tanfovy, in->scale_modifier, in->viewmatrix,
+        in->projmatrix, in->campos, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
+        in->rotations, in->cov3D_precomp, (SplatRec *)(base + L.rec), (BinRec *)(base + L.bin), out_radii,
+        tile_count, L.tiles_x, L.tiles_y);
+    SCORP_KERNEL_CHECK("preprocess", in->debug, stream);
+  }
+  scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, (uint32_t *)(base + L.tile_start), L.tiles,
+                                            (StateHeader *)(base + L.header));
+  SCORP_KERNEL_CHECK("scan_tiles", in->debug, stream);
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs3d_num_pairs(const void *state, scorp_stream_t stream_, uint64_t *num_pairs) {
+  if (!state || !num_pairs) { set_error("state / num_pairs is NULL"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  StateHeader h;
+  SCORP_HIP_CHECK(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, stream));
+  SCORP_HIP_CHECK(hipStreamSynchronize(stream));
+  *num_pairs = h.num_pairs;
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs3d_check_overflow(const void *state, scorp_stream_t stream_, uint64_t *num_pairs) {
+  if (!state) { set_error("state is NULL"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  StateHeader h;
+  SCORP_HIP_CHECK(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, stream));
+  SCORP_HIP_CHECK(hipStreamSynchronize(stream));
+  if (num_pairs) *num_pairs = h.num_pairs;
+  if (h.overflow) {
+    set_error("pair buffer overflow: %u pairs needed, capacity %u", h.num_pairs, h.capacity);
+    return SCORP_ERR_OVERFLOW;
+  }
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
+                                 float *out_color, float *out_depth, float *out_alpha, scorp_stream_t stream_) {
+  if (int e = validate(in)) return e;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
+  const StateLayout L(N, W, H);
+  const PairLayout P(capacity);
+  if (!state || ((uintptr_t)state & 255) || !pairs || ((uintptr_t)pairs & 255)) {
+    set_error("state / pairs buffer NULL or not 256-byte aligned"); return SCORP_ERR_INVALID;
+  }
+  if (capacity > 0xFFFFFFFFull) { set_error("capacity above 2^32-1 pairs"); return SCORP_ERR_INVALID; }
+  if (!out_color || !out_depth || !out_alpha) { set_error("output image pointer is NULL"); return SCORP_ERR_INVALID; }
+  char *base = (char *)state, *pb = (char *)pairs;
+  uint32_t *tile_count = (uint32_t *)(base + L.tile_count), *tile_start = (uint32_t *)(base + L.tile_start);
+  uint64_t *keys = (uint64_t *)(pb + P.keys);
+  uint32_t *point_list = (uint32_t *)(pb + P.list);
+  StateHeader *header = (StateHeader *)(base + L.header);
+  scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), tile_count,
+                                                                    tile_start, L.tiles_x, keys, (uint32_t)capacity,
+                                                                    header);
+  SCORP_KERNEL_CHECK("scatter_pairs", in->debug, stream);
+  sort_tiles_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, (uint32_t)capacity, kSortLds);
+  SCORP_KERNEL_CHECK("sort_tiles", in->debug, stream);
+  blend_forward_kernel<true><<<L.tiles, 256, 0, stream>>>(
+      tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, in->bg,
+      out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib));
+  SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs3d_debug_geom(const void *state, int32_t N, int32_t W, int32_t H, float *xy, float *depth,
+                                     float *conic_opacity, float *rgb, int32_t *rect, scorp_stream_t stream_) {
+  if (!state) { set_error("state is NULL"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const StateLayout L(N, W, H);
+  if (N <= 0) return SCORP_OK;
+  SplatRec *hrec = (SplatRec *)malloc((size_t)N * sizeof(SplatRec));
+  BinRec *hbin = (BinRec *)malloc((size_t)N * sizeof(BinRec));
+  if (!hrec || !hbin) { free(hrec); free(hbin); set_error("host allocation failed"); return SCORP_ERR_INVALID; }
+  hipError_t e = hipMemcpyAsync(hrec, (const char *)state + L.rec, (size_t)N * sizeof(SplatRec), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(hbin, (const char *)state + L.bin, (size_t)N * sizeof(BinRec), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) { free(hrec); free(hbin); set_error("debug_geom copy failed: %s", hipGetErrorString(e)); return SCORP_ERR_HIP; }
+  for (int i = 0; i < N; i++) {
+    const bool vis = (hbin[i].radius & kRadiusMask) != 0;
+    const SplatRec z = {};
+    const SplatRec &s = vis ? hrec[i] : z;
+    if (xy) { xy[2 * i] = s.x; xy[2 * i + 1] = s.y; }
+    if (depth) depth[i] = s.depth;
+    if (conic_opacity) { conic_opacity[4 * i] = s.A; conic_opacity[4 * i + 1] = s.B; conic_opacity[4 * i + 2] = s.C; conic_opacity[4 * i + 3] = s.o; }
+    if (rgb) { rgb[3 * i] = s.r; rgb[3 * i + 1] = s.g; rgb[3 * i + 2] = s.b; }
+    if (rect) { rect[4 * i] = vis ? hbin[i].x0 : 0; rect[4 * i + 1] = vis ? hbin[i].y0 : 0; rect[4 * i + 2] = vis ? hbin[i].x1 : 0; rect[4 * i + 3] = vis ? hbin[i].y1 : 0; }
+  }
+  free(hrec); free(hbin);
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint64_t capacity, int32_t N, int32_t W,
+                                      int32_t H, uint32_t *tile_start, uint32_t *point_list, scorp_stream_t stream_) {
+  if (!state || !pairs) { set_error("state / pairs is NULL"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const StateLayout L(N, W, H);
+  const PairLayout P(capacity);
+  StateHeader h;
+  SCORP_HIP_CHECK(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, stream));
+  SCORP_HIP_CHECK(hipStreamSynchronize(stream));
+  if (tile_start)
+    SCORP_HIP_CHECK(hipMemcpyAsync(tile_start, (const char *)state + L.tile_start, ((size_t)L.tiles + 1) * 4, hipMemcpyDeviceToHost, stream));
+  const size_t n = h.num_pairs < capacity ? h.num_pairs : (size_t)capacity;
+  if (point_list && n)
+    SCORP_HIP_CHECK(hipMemcpyAsync(point_list, (const char *)pairs + P.list, n * 4, hipMemcpyDeviceToHost, stream));
+  SCORP_HIP_CHECK(hipStreamSynchronize(stream));
+  return SCORP_OK;
+}

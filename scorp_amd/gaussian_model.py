@@ -1,0 +1,286 @@
+"""`GaussianModel` — the parameter container the 3DGS scripts drive, API-compatible with
+gs3dgs/scene/gaussian_model.py:28-605 for everything the hot path and its three harnesses touch:
+
+  properties      get_xyz / get_features / get_opacity / get_scaling / get_rotation / get_covariance   (:126-161)
+  schedule        oneupSHdegree (:163-165), training_setup (:192-210), update_learning_rate (:212-218)
+  checkpoints     capture / restore (:92-124)
+  freezing        set_freeze (:65-90)  — post_refine_gs.py:53-56 freezes everything but the colours
+  densification   add_densification_stats (:603-605), densify_and_prune (+clone/split), prune_points,
+                  reset_opacity (:253-256, :412-601)
+
+Layout is the reference's (six leaf `nn.Parameter`s: _xyz[N,3], _features_dc[N,1,3], _features_rest[N,K-1,3],
+_scaling[N,3] log, _rotation[N,4], _opacity[N,1] logit) so checkpoints and PLY files interchange.  All optimizer
+surgery goes through one helper (`_rebuild`) instead of three near-identical loops.  Tensors live on
+`self.device` (the reference hard-codes "cuda", which is the same device on ROCm).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .sh import RGB2SH, SH2RGB
+
+GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+_ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+         "scaling": "_scaling", "rotation": "_rotation"}
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def build_rotation(r):
+    """Normalise then expand (w,x,y,z) to a 3x3 (general_utils.py:93-114), on r's device."""
+    q = r / torch.sqrt((r * r).sum(dim=1, keepdim=True))
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.view(-1, 3, 3)
+
+
+def build_scaling_rotation(s, r):
+    return build_rotation(r) * s[:, None, :]          # R @ diag(s)
+
+
+def strip_symmetric(S):
+    """3x3 -> (xx,xy,xz,yy,yz,zz) (general_utils.py:79-91)."""
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1)
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear decay with optional warm-up (general_utils.py:44-77)."""
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+        else:
+            delay_rate = 1.0
+        t = np.clip(step / max_steps, 0, 1)
+        return delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+    return helper
+
+
+class OptimizationParams:
+    """Defaults of gs3dgs/arguments/__init__.py:74-107 (the values, not the argparse plumbing)."""
+    iterations = 30_000
+    position_lr_init = 0.00016
+    position_lr_final = 0.0000016
+    position_lr_delay_mult = 0.01
+    position_lr_max_steps = 30_000
+    feature_lr = 0.0025
+    opacity_lr = 0.05
+    scaling_lr = 0.005
+    rotation_lr = 0.001
+    percent_dense = 0.01
+    lambda_dssim = 0.2
+    densification_interval = 100
+    opacity_reset_interval = 3000
+    densify_from_iter = 500
+    densify_until_iter = 25_000
+    densify_grad_threshold = 0.0002
+    random_background = True
+
+
+class GaussianModel:
+    def __init__(self, sh_degree: int, device="cuda"):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.device = torch.device(device)
+        for a in _ATTR.values():
+            setattr(self, a, torch.empty(0))
+        self.max_radii2D = torch.empty(0)
+        self.xyz_gradient_accum = torch.empty(0)
+        self.denom = torch.empty(0)
+        self.optimizer = None
+        self.percent_dense = 0
+        self.spatial_lr_scale = 0
+        self.scaling_activation, self.scaling_inverse_activation = torch.exp, torch.log
+        self.opacity_activation, self.inverse_opacity_activation = torch.sigmoid, inverse_sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    # ---- construction ----
+    @classmethod
+    def from_raw(cls, raw, sh_degree, device="cuda"):
+        """From a dict of pre-activation numpy arrays (scorp_amd.synthetic.make_gaussians)."""
+        m = cls(sh_degree, device)
+        P = lambda a: nn.Parameter(torch.tensor(a, dtype=torch.float32, device=m.device).contiguous().requires_grad_(True))
+        m._xyz, m._features_dc, m._features_rest = P(raw["xyz"]), P(raw["features_dc"]), P(raw["features_rest"])
+        m._scaling, m._rotation, m._opacity = P(raw["scaling"]), P(raw["rotation"]), P(raw["opacity"])
+        m.max_radii2D = torch.zeros(m._xyz.shape[0], device=m.device)
+        return m
+
+    def create_from_pcd(self, pcd, spatial_lr_scale: float):
+        """gaussian_model.py:167-190: colours -> SH dc, scale = log sqrt(mean 3-NN d^2), identity rotations, opacity 0.1."""
+        from simple_knn._C import distCUDA2
+        self.spatial_lr_scale = spatial_lr_scale
+        pts = torch.tensor(np.asarray(pcd.points)).float().to(self.device)
+        col = RGB2SH(torch.tensor(np.asarray(pcd.colors)).float().to(self.device))
+        K = (self.max_sh_degree + 1) ** 2
+        feats = torch.zeros((col.shape[0], 3, K), device=self.device)
+        feats[:, :3, 0] = col
+        dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+        rots = torch.zeros((pts.shape[0], 4), device=self.device)
+        rots[:, 0] = 1
+        opac = inverse_sigmoid(0.1 * torch.ones((pts.shape[0], 1), device=self.device))
+        self._xyz = nn.Parameter(pts.requires_grad_(True))
+        self._features_dc = nn.Parameter(feats[:, :, 0:1].transpose(1, 2).contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(feats[:, :, 1:].transpose(1, 2).contiguous().requires_grad_(True))
+        self._scaling = nn.Parameter(scales.requires_grad_(True))
+        self._rotation = nn.Parameter(rots.requires_grad_(True))
+        self._opacity = nn.Parameter(opac.requires_grad_(True))
+        self.max_radii2D = torch.zeros(pts.shape[0], device=self.device)
+
+    # ---- activations (the per-view host work of SURVEY §8 row a4) ----
+    @property
+    def get_scaling(self):
+        return self.scaling_activation(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._opacity)
+
+    @property
+    def get_color(self):
+        return SH2RGB(self._features_dc.squeeze(1))
+
+    def get_covariance(self, scaling_modifier=1):
+        L = build_scaling_rotation(scaling_modifier * self.get_scaling, self._rotation)
+        return strip_symmetric(L @ L.transpose(1, 2))
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ---- optimizer ----
+    def training_setup(self, training_args):
+        n = self.get_xyz.shape[0]
+        self.percent_dense = training_args.percent_dense
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
+        self.denom = torch.zeros((n, 1), device=self.device)
+        self.spatial_lr_scale = 1.0
+        lrs = {"xyz": training_args.position_lr_init * self.spatial_lr_scale, "f_dc": training_args.feature_lr,
+               "f_rest": training_args.feature_lr / 20.0, "opacity": training_args.opacity_lr,
+               "scaling": training_args.scaling_lr, "rotation": training_args.rotation_lr}
+        groups = [{"params": [getattr(self, _ATTR[g])], "lr": lrs[g], "name": g} for g in GROUPS]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.xyz_scheduler_args = get_expon_lr_func(
+            lr_init=training_args.position_lr_init * self.spatial_lr_scale,
+            lr_final=training_args.position_lr_final * self.spatial_lr_scale,
+            lr_delay_mult=training_args.position_lr_delay_mult, max_steps=training_args.position_lr_max_steps)
+
+    def update_learning_rate(self, iteration):
+        for group in self.optimizer.param_groups:
+            if group["name"] == "xyz":
+                group["lr"] = self.xyz_scheduler_args(iteration)
+                return group["lr"]
+
+    def set_freeze(self, param_name: str, freeze: bool = True):
+        if not hasattr(self, param_name):
+            raise ValueError(f"Parameter '{param_name}' does not exist in GaussianModel.")
+        getattr(self, param_name).requires_grad = not freeze
+
+    def capture(self):
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+                self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(),
+                self.spatial_lr_scale)
+
+    def restore(self, model_args, training_args):
+        (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+         self._opacity, self.max_radii2D, xyz_gradient_accum, denom, opt_dict, self.spatial_lr_scale) = model_args
+        self.training_setup(training_args)
+        self.xyz_gradient_accum, self.denom = xyz_gradient_accum, denom
+        self.optimizer.load_state_dict(opt_dict)
+
+    # ---- optimizer surgery: one helper for replace / prune / append ----
+    def _rebuild(self, fn_param, fn_state, only=None):
+        """Replace each group's parameter by fn_param(name, old) and its Adam moments by fn_state(name, moment)."""
+        for group in self.optimizer.param_groups:
+            name = group["name"]
+            if only is not None and name != only:
+                continue
+            old = group["params"][0]
+            state = self.optimizer.state.pop(old, None)
+            new = nn.Parameter(fn_param(name, old.detach()).requires_grad_(old.requires_grad))
+            if state is not None:
+                state["exp_avg"] = fn_state(name, state["exp_avg"])
+                state["exp_avg_sq"] = fn_state(name, state["exp_avg_sq"])
+                self.optimizer.state[new] = state
+            group["params"][0] = new
+            setattr(self, _ATTR[name], new)
+
+    def replace_tensor_to_optimizer(self, tensor, name):
+        self._rebuild(lambda n, p: tensor, lambda n, m: torch.zeros_like(tensor), only=name)
+        return {name: getattr(self, _ATTR[name])}
+
+    def prune_points(self, mask):
+        keep = ~mask
+        self._rebuild(lambda n, p: p[keep], lambda n, m: m[keep])
+        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
+        self.denom = self.denom[keep]
+        self.max_radii2D = self.max_radii2D[keep]
+
+    def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation):
+        ext = {"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest, "opacity": new_opacities,
+               "scaling": new_scaling, "rotation": new_rotation}
+        self._rebuild(lambda n, p: torch.cat((p, ext[n]), dim=0),
+                      lambda n, m: torch.cat((m, torch.zeros_like(ext[n])), dim=0))
+        n = self.get_xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=self.device)
+        self.denom = torch.zeros((n, 1), device=self.device)
+        self.max_radii2D = torch.zeros(n, device=self.device)
+
+    def reset_opacity(self):
+        op = self.get_opacity
+        self.replace_tensor_to_optimizer(inverse_sigmoid(torch.min(op, torch.ones_like(op) * 0.01)), "opacity")
+
+    # ---- densification (every 100 iterations until 25k, arguments:102-106) ----
+    def _take(self, sel, reps=1):
+        r = lambda t: t[sel].repeat(reps, *([1] * (t.dim() - 1)))
+        return r(self._xyz), r(self._features_dc), r(self._features_rest), r(self._opacity), r(self._scaling), r(self._rotation)
+
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
+              (torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent)
+        self.densification_postfix(*self._take(sel))
+
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+        n0 = self.get_xyz.shape[0]
+        padded = torch.zeros(n0, device=self.device)
+        padded[: grads.shape[0]] = grads.squeeze()
+        sel = (padded >= grad_threshold) & (torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
+        xyz, f_dc, f_rest, opac, _, rot = self._take(sel, N)
+        stds = self.get_scaling[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
+        new_xyz = torch.bmm(build_rotation(rot), samples.unsqueeze(-1)).squeeze(-1) + xyz
+        new_scaling = self.scaling_inverse_activation(stds / (0.8 * N))
+        self.densification_postfix(new_xyz, f_dc, f_rest, opac, new_scaling, rot)
+        self.prune_points(torch.cat((sel, torch.zeros(N * int(sel.sum()), device=self.device, dtype=torch.bool))))
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        self.densify_and_clone(grads, max_grad, extent)
+        self.densify_and_split(grads, max_grad, extent)
+        prune = (self.get_opacity < min_opacity).squeeze()
+        if max_screen_size:
+            prune = prune | (self.max_radii2D > max_screen_size) | (self.get_scaling.max(dim=1).values > 0.1 * extent)
+        self.prune_points(prune)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        """Accumulates |dL/d(ndc xy)| of the visible splats — this is what pins the scale of the means2D gradient."""
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1

@@ -1,0 +1,212 @@
+"""`diff_gaussian_rasterization`-compatible front-end over libscorp_gs.so.
+
+Same names, argument meaning and error behaviour as the module the reference imports at
+gs3dgs/gaussian_renderer/__init__.py:15 and calls at :51-66,101-111:
+`GaussianRasterizationSettings` (12 fields) and `GaussianRasterizer(raster_settings)(means3D, means2D, shs,
+colors_precomp, opacities, scales, rotations, cov3D_precomp) -> (color[3,H,W], radii[N] int32, depth[1,H,W],
+alpha[1,H,W])`, differentiable w.r.t. all eight arguments.  PyTorch supplies device memory, the current
+stream and autograd bookkeeping; every kernel is in the HIP library, reached through ctypes.
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class PairPolicy:
+    """How the (tile,splat) pair buffer is sized.
+
+    "exact"   (default) one 8-byte D2H read per forward tells the exact pair count — what the CUDA original
+              does too; always correct.
+    "reserve" no host sync: the buffer is sized from the largest count seen so far times `slack`; each forward
+              is queued for `drain()`, which synchronises once, raises if any view overflowed and grows the
+              reservation.  For throughput loops that check once per N views.
+    """
+    mode = "exact"
+    slack = 1.25
+    reserve = 0          # pairs
+    _pending = []        # state tensors whose overflow flag has not been read yet
+
+    @classmethod
+    def drain(cls):
+        """Synchronise and verify every forward issued in "reserve" mode since the last drain."""
+        L = _C.lib()
+        pend, cls._pending = cls._pending, []
+        worst = 0
+        err = None
+        for state in pend:
+            n = ctypes.c_uint64(0)
+            code = L.scorp_gs3d_check_overflow(state.data_ptr(), _stream(), ctypes.byref(n))
+            worst = max(worst, n.value)
+            if code != 0 and err is None:
+                err = L.scorp_last_error().decode()
+        cls.reserve = max(cls.reserve, int(worst * cls.slack) + 1024)
+        if err:
+            raise RuntimeError(f"pair reservation too small ({err}); reservation grown to {cls.reserve}, re-run the view(s)")
+        return worst
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _prep(t, name, shape_tail=None):
+    """float32, contiguous, on the GPU; None stays None (maps to NULL in the C ABI)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor (scorp_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _inputs_struct(s, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D, keep):
+    """Fill the C struct; `keep` collects tensors that must outlive the call."""
+    bg, vm, pm, cp = (_prep(s.bg, "bg"), _prep(s.viewmatrix, "viewmatrix"), _prep(s.projmatrix, "projmatrix"),
+                      _prep(s.campos, "campos"))
+    keep.extend([bg, vm, pm, cp])
+    a = _C.ScorpGs3dInputs()
+    a.num_gaussians = means3D.shape[0]
+    a.sh_degree = int(s.sh_degree)
+    a.sh_coeffs = 0 if sh is None else sh.shape[1]
+    a.image_width, a.image_height = int(s.image_width), int(s.image_height)
+    a.tanfovx, a.tanfovy, a.scale_modifier = float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier)
+    a.prefiltered, a.debug = int(bool(s.prefiltered)), int(bool(s.debug))
+    a.bg, a.viewmatrix, a.projmatrix, a.campos = bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr()
+    a.means3D = means3D.data_ptr()
+    a.shs = None if sh is None else sh.data_ptr()
+    a.colors_precomp = None if colors_precomp is None else colors_precomp.data_ptr()
+    a.opacities = opacities.data_ptr()
+    a.scales = None if scales is None else scales.data_ptr()
+    a.rotations = None if rotations is None else rotations.data_ptr()
+    a.cov3D_precomp = None if cov3D is None else cov3D.data_ptr()
+    return a
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+        L = _C.lib()
+        dev = means3D.device
+        means3D, sh, colors_precomp = _prep(means3D, "means3D"), _prep(sh, "shs"), _prep(colors_precomp, "colors_precomp")
+        opacities, scales, rotations = _prep(opacities, "opacities"), _prep(scales, "scales"), _prep(rotations, "rotations")
+        cov3Ds_precomp = _prep(cov3Ds_precomp, "cov3D_precomp")
+        N, H, W = means3D.shape[0], int(settings.image_height), int(settings.image_width)
+        keep = []
+        args = _inputs_struct(settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep)
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((N,), dtype=torch.int32, device=dev)
+        state_bytes = L.scorp_gs3d_state_bytes(N, W, H)
+        state = torch.empty(state_bytes, dtype=torch.uint8, device=dev)
+        stream = _stream()
+        _C.check(L.scorp_gs3d_preprocess(ctypes.byref(args), _ptr(radii), _ptr(state), state_bytes, stream), "scorp_gs3d_preprocess")
+        if PairPolicy.mode == "exact":
+            n = ctypes.c_uint64(0)
+            _C.check(L.scorp_gs3d_num_pairs(_ptr(state), stream, ctypes.byref(n)), "scorp_gs3d_num_pairs")
+            capacity = max(int(n.value), 1)
+        else:
+            if PairPolicy.reserve <= 0:
+                PairPolicy.reserve = max(4 * N, 1 << 20)
+            capacity = PairPolicy.reserve
+            PairPolicy._pending.append(state)
+        pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
+        _C.check(L.scorp_gs3d_render(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(depth),
+                                     _ptr(alpha), stream), "scorp_gs3d_render")
+        ctx.settings = settings
+        ctx.capacity = capacity
+        ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
+        none = torch.empty(0, device=dev)
+        ctx.save_for_backward(means3D, none if sh is None else sh, none if colors_precomp is None else colors_precomp,
+                              opacities, none if scales is None else scales, none if rotations is None else rotations,
+                              none if cov3Ds_precomp is None else cov3Ds_precomp, state, pairs, *keep)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        L = _C.lib()
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3D, state, pairs, bg, vm, pm, cp = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_cov = ctx.has
+        sh = sh if has_sh else None
+        colors_precomp = colors_precomp if has_col else None
+        scales, rotations = (scales, rotations) if has_sr else (None, None)
+        cov3D = cov3D if has_cov else None
+        s = ctx.settings._replace(bg=bg, viewmatrix=vm, projmatrix=pm, campos=cp)
+        keep = []
+        args = _inputs_struct(s, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D, keep)
+        N, dev = means3D.shape[0], means3D.device
+        need = ctx.needs_input_grad  # means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, settings
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        g_means3D = new(N, 3) if need[0] else None
+        g_means2D = new(N, 3) if need[1] else None
+        g_sh = torch.empty_like(sh) if (need[2] and has_sh) else None
+        g_col = new(N, 3) if (need[3] and has_col) else None
+        g_op = torch.empty_like(opacities) if need[4] else None
+        g_sc = new(N, 3) if (need[5] and has_sr) else None
+        g_rot = new(N, 4) if (need[6] and has_sr) else None
+        g_cov = new(N, 6) if (need[7] and has_cov) else None
+        grads = _C.ScorpGs3dGrads()
+        grads.means3D, grads.means2D, grads.shs, grads.colors_precomp = _ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col)
+        grads.opacities, grads.scales, grads.rotations, grads.cov3D_precomp = _ptr(g_op), _ptr(g_sc), _ptr(g_rot), _ptr(g_cov)
+        gc = _prep(grad_color, "grad_color")
+        gd = _prep(grad_depth, "grad_depth") if grad_depth is not None else None
+        ga = _prep(grad_alpha, "grad_alpha") if grad_alpha is not None else None
+        scratch_bytes = L.scorp_gs3d_backward_scratch_bytes(N)
+        scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+        _C.check(L.scorp_gs3d_backward(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(gd),
+                                       _ptr(ga), ctypes.byref(grads), _ptr(scratch), scratch_bytes, _stream()),
+                 "scorp_gs3d_backward")
+        return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Frustum test of the upstream API (not called by the reference): view-space z > 0.2."""
+        with torch.no_grad():
+            vm = self.raster_settings.viewmatrix
+            z = positions @ vm[:3, 2] + vm[3, 2]
+            return z > 0.2
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)

@@ -1,0 +1,63 @@
+"""`render()` of the 3DGS path — host-side mirror of gs3dgs/gaussian_renderer/__init__.py:24-132.
+
+Same signature, same branches (`pipe.compute_cov3D_python`, `pipe.convert_SHs_python`, `override_color`), same
+six-key result dict, same depth normalisation (`render_depth = depth / alpha`, NaN -> 0).  The only deliberate
+difference: tensors are created on `pc.get_xyz.device` instead of the literal "cuda".
+"""
+import math
+
+import torch
+
+from .rasterizer3d import GaussianRasterizationSettings, GaussianRasterizer
+from .sh import eval_sh
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    w, h = viewpoint_camera.resolution
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(h), image_width=int(w), tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is None:
+        if getattr(pipe, "convert_SHs_python", False):
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
+            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+
+    rendered_image, radii, rendered_depth, rendered_alpha = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    rendered_depth = torch.nan_to_num(rendered_depth / rendered_alpha, 0, 0)
+    return {
+        "render": rendered_image,
+        "viewspace_points": screenspace_points,
+        "visibility_filter": radii > 0,
+        "radii": radii,
+        "render_depth": rendered_depth,
+        "render_alpha": rendered_alpha,
+    }

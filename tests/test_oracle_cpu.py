@@ -1,0 +1,156 @@
+"""CPU tests: the oracle against the golden vectors captured from the reference's importable helpers
+(tests/golden/make_golden.py), and the oracle's analytic backward against torch.autograd of the dense
+formulation. No GPU, no reference tree needed."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_dense
+from oracle.gs_oracle import OracleRender
+from scorp_amd import camera as cam_mod
+from scorp_amd import sh as sh_mod
+from tests.util import image_weights, make_case
+
+
+def test_sh_basis_matches_reference_eval_sh(golden):
+    sh, dirs = golden["g1_sh"], golden["g1_dirs"]                      # sh[N,3,K] as the reference's python branch
+    sh_k3 = torch.tensor(sh).transpose(1, 2).contiguous()              # [N,K,3] as the rasterizer receives it
+    for deg in range(4):
+        ref = golden[f"g1_rgb_deg{deg}"]
+        got = torch_dense.sh_to_rgb(deg, sh_k3.double(), torch.tensor(dirs).double()).numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+        got2 = sh_mod.eval_sh(deg, torch.tensor(sh), torch.tensor(dirs)).numpy()
+        np.testing.assert_allclose(got2, ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(sh_mod.RGB2SH(torch.tensor(sh[:, :, 0])).numpy(), golden["g1_rgb2sh"], atol=1e-6)
+    np.testing.assert_allclose(sh_mod.SH2RGB(torch.tensor(sh[:, :, 0])).numpy(), golden["g1_sh2rgb"], atol=1e-6)
+
+
+def test_c_oracle_colour_matches_reference_eval_sh(golden):
+    """Drive the C oracle's SH->RGB (+0.5, clamp) with the golden coefficients: camera at the origin looking down
+    +z, one Gaussian along each golden direction that lies in front of it."""
+    sh, dirs = golden["g1_sh"], golden["g1_dirs"]
+    front = dirs[:, 2] > 0.5
+    means = (dirs[front] * 3.0).astype(np.float32)
+    n = means.shape[0]
+    assert n >= 8
+    shs = np.ascontiguousarray(np.transpose(sh[front], (0, 2, 1)))    # [n,16,3]
+    view = np.eye(4, dtype=np.float32)
+    proj = (torch.tensor(view) @ cam_mod.getProjectionMatrix(0.01, 100.0, 1.6, 1.6).T).numpy()
+    for deg in range(4):
+        o = OracleRender(np.float32, means, np.full(n, 0.5, np.float32), view, proj, np.zeros(3, np.float32),
+                         np.zeros(3, np.float32), 64, 64, math.tan(0.8), math.tan(0.8), shs=shs, sh_degree=deg,
+                         scales=np.full((n, 3), 0.01, np.float32), rotations=np.tile([1, 0, 0, 0], (n, 1)).astype(np.float32))
+        vis = o.radii > 0
+        assert vis.sum() >= 8
+        np.testing.assert_allclose(o.geom()["rgb"][vis], golden[f"g1_clamped_deg{deg}"][front][vis], atol=2e-6)
+
+
+def test_camera_matrices_match_reference(golden):
+    for i, (fx, fy) in enumerate(golden["g2_fovs"]):
+        np.testing.assert_allclose(cam_mod.getProjectionMatrix(0.01, 100.0, fx, fy).numpy(), golden["g2_proj"][i], rtol=1e-6, atol=1e-7)
+    for i in range(4):
+        np.testing.assert_allclose(cam_mod.getWorld2View2(golden["g2_R"][i], golden["g2_t"][i]), golden["g2_w2v"][i], atol=1e-6)
+        np.testing.assert_allclose(cam_mod.getWorld2View2(golden["g2_R"][i], golden["g2_t"][i], np.array([0.1, -0.2, 0.3]), 1.5),
+                                   golden["g2_w2v_ts"][i], atol=1e-6)
+    np.testing.assert_allclose([cam_mod.fov2focal(1.0471976, 1600), cam_mod.focal2fov(1385.64, 1200)], golden["g2_focal"], rtol=1e-12)
+
+
+def test_quaternion_convention_matches_reference(golden):
+    q = torch.tensor(golden["g5_q"]).double()
+    qn = q / q.norm(dim=1, keepdim=True)
+    np.testing.assert_allclose(torch_dense.quat_to_rot(qn).numpy(), golden["g5_R"], atol=1e-5)
+
+
+def test_camera_class_layout():
+    """Transposed storage, full_proj = view @ proj, centre = inverse(view)[3,:3] (cameras.py:82-97)."""
+    c = cam_mod.look_at_camera((4, 0, 1), (0, 0, 0), (0, 0, 1), math.radians(60), (160, 120))
+    V = c.world_view_transform.T.numpy()
+    np.testing.assert_allclose(V[:3, :3] @ np.array([4, 0, 1.0]) + V[:3, 3], 0, atol=1e-5)      # camera centre -> origin
+    origin_view = V[:3, 3]
+    assert origin_view[2] > 0 and abs(origin_view[0]) < 1e-5 and abs(origin_view[1]) < 1e-5     # looks at the origin
+    np.testing.assert_allclose(c.camera_center.numpy(), [4, 0, 1], atol=1e-5)
+    np.testing.assert_allclose(c.full_proj_transform.numpy(), (c.world_view_transform @ c.projection_matrix).numpy(), atol=1e-6)
+
+
+CASES = [
+    dict(N=300, W=48, H=40, deg=3, seed=1, bg=(0.2, 0.5, 0.7), scale_modifier=1.3),
+    dict(N=400, W=37, H=50, deg=2, seed=2),
+    dict(N=300, W=64, H=33, deg=1, seed=3, precomp_color=True),
+    dict(N=300, W=48, H=48, deg=0, seed=4, precomp_cov=True),
+    dict(N=500, W=40, H=40, deg=3, seed=7, radius=1.2),    # camera inside the cloud: near culls + FoV-guard clamps
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_f64_matches_dense_autograd(case):
+    case = dict(case)
+    kw, _ = make_case(log_scale=math.log(0.08), **case)
+    W, H = kw["W"], kw["H"]
+    t = {}
+    for k in ("means3D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"):
+        if k in kw:
+            t[k] = torch.tensor(kw[k].astype(np.float64), requires_grad=True)
+    means2D = torch.zeros(kw["means3D"].shape[0], 3, dtype=torch.float64, requires_grad=True)
+    T64 = lambda a: torch.tensor(np.asarray(a, np.float64))
+    color, radii, depth, alpha = torch_dense.render_dense(
+        t["means3D"], t["opacities"], T64(kw["view"]), T64(kw["proj"]), T64(kw["campos"]), T64(kw["bg"]), W, H,
+        kw["tanfovx"], kw["tanfovy"], shs=t.get("shs"), sh_degree=kw.get("sh_degree", 0),
+        colors_precomp=t.get("colors_precomp"), scales=t.get("scales"), rotations=t.get("rotations"),
+        cov3D_precomp=t.get("cov3D_precomp"), scale_modifier=kw.get("scale_modifier", 1.0), means2D=means2D)
+    wc, wd, wa = (torch.tensor(w.astype(np.float64)) for w in image_weights(H, W, case["seed"]))
+    ((color * wc).sum() + (depth * wd).sum() + (alpha * wa).sum()).backward()
+    o = OracleRender(np.float64, **{k: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    assert o.num_pairs > 0
+    np.testing.assert_array_equal(o.radii, radii.numpy())
+    np.testing.assert_allclose(o.color, color.detach().numpy(), atol=1e-12)
+    np.testing.assert_allclose(o.depth, depth.detach().numpy(), atol=1e-11)
+    np.testing.assert_allclose(o.alpha, alpha.detach().numpy(), atol=1e-12)
+    g = o.backward(wc.numpy(), wd.numpy(), wa.numpy())
+
+    def close(name, got, ref):
+        ref = ref.numpy().reshape(got.shape)
+        scale = max(np.abs(ref).max(), 1e-12)
+        assert np.abs(got - ref).max() / scale < 2e-6, f"{name}: {np.abs(got - ref).max()} vs scale {scale}"
+
+    close("means3D", g["means3D"], t["means3D"].grad)
+    close("means2D", g["means2D"], means2D.grad)
+    close("opacities", g["opacities"], t["opacities"].grad)
+    if "shs" in t:
+        close("shs", g["shs"], t["shs"].grad)
+    else:
+        close("colors", g["colors_precomp"], t["colors_precomp"].grad)
+    if "scales" in t:
+        close("scales", g["scales"], t["scales"].grad)
+        close("rotations", g["rotations"], t["rotations"].grad)
+    else:
+        close("cov3D", g["cov3D_precomp"], t["cov3D_precomp"].grad)
+
+
+def test_oracle_f32_close_to_f64():
+    kw, _ = make_case(2000, 128, 96, 3, 11, bg=(0.1, 0.2, 0.3))
+    o32 = OracleRender(np.float32, **kw)
+    o64 = OracleRender(np.float64, **{k: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    assert np.abs(o32.color - o64.color).mean() < 1e-5
+    assert np.abs(o32.alpha - o64.alpha).mean() < 1e-5
+
+
+def test_oracle_edge_cases():
+    # no Gaussians at all: background only
+    kw, _ = make_case(1, 33, 17, 0, 5, bg=(0.3, 0.6, 0.9))
+    kw["means3D"] = kw["means3D"] + 100.0   # behind / far outside: culled
+    o = OracleRender(np.float32, **kw)
+    assert o.num_pairs == 0 and (o.radii == 0).all()
+    np.testing.assert_allclose(o.color[:, 0, 0], [0.3, 0.6, 0.9], atol=1e-7)
+    assert (o.alpha == 0).all() and (o.depth == 0).all()
+    g = o.backward(*image_weights(17, 33, 0))
+    assert all(np.all(v == 0) for v in g.values() if v is not None)
+    # backward is repeatable on one forward (utils/mask.py relies on it)
+    kw, _ = make_case(500, 64, 48, 2, 6)
+    o = OracleRender(np.float32, **kw)
+    w = image_weights(48, 64, 6)
+    g1, g2 = o.backward(*w), o.backward(*w)
+    for k in g1:
+        if g1[k] is not None:
+            np.testing.assert_array_equal(g1[k], g2[k])
