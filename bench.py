@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py — fwd+bwd views/s of the 3DGS hot path on synthetic Gaussians (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scene S3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one view of the workload: render() through the HIP rasterizer (GaussianModel activations + SH/cov in
+kernel) -> 0.8*L1 + 0.2*(1-SSIM) against a resident ground-truth image -> backward to all 59 per-Gaussian
+parameters (+ the means2D gradient).  The optimizer step is NOT part of the metric ("fwd+bwd views/s") and is not
+in the timed region.  Inputs (parameters, cameras, GT images) are resident in HBM before the timed region.
+With N > 1 every rank holds a replica of the scene (broadcast once from rank 0 over RCCL) and renders its own
+views (view i -> rank i mod N): weak scaling, no collective on the data path; value = views of all ranks / time.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+class Pipe:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+
+
+def kernel_algorithmic_bytes(name, N, Nvis, K, HW, D):
+    """Compulsory HBM bytes of one launch of each kernel: every datum moved once."""
+    per_g_in = 12 + 4 + 12 + 16                      # xyz, opacity, scale, quaternion
+    return {
+        "preprocess": N * (per_g_in + 16 + 4) + Nvis * (K * 12 + 48) + D * 4,
+        "scan_tiles": 0,
+        "scatter_pairs": N * 16 + D * (8 + 4),
+        "sort_tiles": D * (8 + 4),
+        "blend_forward": D * 4 + Nvis * 48 + HW * (20 + 8),
+        "blend_backward": D * 4 + Nvis * 48 + HW * (20 + 8) + Nvis * 40,
+        "preprocess_backward": N * (per_g_in + 16) + Nvis * (K * 12 + 48) + N * 248,
+    }[name]
+
+
+def cpu_baseline(raw, cam, deg, W, H):
+    """The CPU oracle (OpenMP C restatement) on ONE view of the same workload, forward + backward."""
+    from oracle import gs_oracle
+    from oracle.gs_oracle import OracleRender
+    from scorp_amd.synthetic import activate
+    gs_oracle.build()
+    act = activate(raw)
+    kw = dict(means3D=act["means3D"], opacities=act["opacities"], shs=act["shs"], sh_degree=deg, scales=act["scales"],
+              rotations=act["rotations"], W=W, H=H, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2),
+              view=cam.world_view_transform.cpu().numpy(), proj=cam.full_proj_transform.cpu().numpy(),
+              campos=cam.camera_center.cpu().numpy(), bg=np.zeros(3, np.float32))
+    gs_oracle.set_parallel_backward(True)
+    w = np.full((3, H, W), 1.0 / (3 * H * W), np.float32)
+    t0 = time.perf_counter()
+    o = OracleRender(np.float32, **kw)
+    o.backward(w, None, None)
+    dt = time.perf_counter() - t0
+    gs_oracle.set_parallel_backward(False)
+    return dict(value=1.0 / dt, unit="views/s", cores=os.cpu_count(), kind="port",
+                sample=f"1 view of the same workload (render fwd+bwd, no loss), {dt:.2f} s, OpenMP over {os.cpu_count()} host threads"), o
+
+
+def small_parity(dev):
+    """Quality half of the metric: PSNR / L1 of the HIP render vs the CPU oracle on BASELINE config #1 (S1)."""
+    from oracle.gs_oracle import OracleRender
+    from scorp_amd.synthetic import activate, scene
+    from tests.test_gs3d_gpu import hip_render
+    raw, cams, deg = scene("S1")
+    act = activate(raw)
+    cam = cams[0]
+    kw = dict(means3D=act["means3D"], opacities=act["opacities"], shs=act["shs"], sh_degree=deg, scales=act["scales"],
+              rotations=act["rotations"], W=256, H=256, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2),
+              view=cam.world_view_transform.numpy(), proj=cam.full_proj_transform.numpy(),
+              campos=cam.camera_center.numpy(), bg=np.zeros(3, np.float32))
+    o = OracleRender(np.float32, **kw)
+    with torch.no_grad():
+        (color, _, _, _), _ = hip_render(kw, dev, requires_grad=False)
+    c = color.cpu().numpy()
+    mse = float(((c - o.color) ** 2).mean())
+    return dict(workload="S1: 10k Gaussians, 256x256, SH0", l1=float(np.abs(c - o.color).mean()),
+                psnr_db=(99.0 if mse == 0 else float(10 * math.log10(1.0 / mse))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scene", default="S3")
+    ap.add_argument("--cams", type=int, default=8, help="distinct cameras (with resident GT images) cycled per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from scorp_amd import _C
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.loss import photometric_loss
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.renderer import render
+    from scorp_amd.synthetic import SCENES, make_gaussians, ring_cameras
+    _C.lib()  # fail loudly if the HIP extension is missing
+
+    N, W, H, deg, seed, ncam_total = SCENES[args.scene]
+    K = (deg + 1) ** 2
+    # rank 0 draws the scene; the others receive it over RCCL (the one collective of this workload, outside the timed region)
+    raw = make_gaussians(N, deg, seed) if rank == 0 else None
+    if world > 1:
+        shapes = dict(xyz=(N, 3), scaling=(N, 3), rotation=(N, 4), opacity=(N, 1), features_dc=(N, 1, 3), features_rest=(N, K - 1, 3))
+        recv = {}
+        for k, shp in shapes.items():
+            t = torch.tensor(raw[k], device=dev) if rank == 0 else torch.empty(shp, dtype=torch.float32, device=dev)
+            dist.broadcast(t, src=0)
+            recv[k] = t
+        model = GaussianModel(deg, device=dev)
+        P = lambda t: torch.nn.Parameter(t.contiguous().requires_grad_(True))
+        model._xyz, model._features_dc, model._features_rest = P(recv["xyz"]), P(recv["features_dc"]), P(recv["features_rest"])
+        model._scaling, model._rotation, model._opacity = P(recv["scaling"]), P(recv["rotation"]), P(recv["opacity"])
+    else:
+        model = GaussianModel.from_raw(raw, deg, device=dev)
+    model.active_sh_degree = deg
+    params = [model._xyz, model._features_dc, model._features_rest, model._scaling, model._rotation, model._opacity]
+
+    all_cams = ring_cameras(ncam_total, W, H, seed, device=dev)
+    my_cams = [all_cams[(rank + world * i) % ncam_total] for i in range(args.cams)]   # view i -> rank i mod world
+    bg = torch.zeros(3, device=dev)
+    pipe = Pipe()
+
+    # resident ground truth + per-camera pair / visibility counts (exact mode, outside the timed region)
+    gts, Ds, Nvis = [], [], []
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    with torch.no_grad():
+        for cam in my_cams:
+            out = render(cam, model, pipe, bg)
+            gts.append((out["render"] + 0.05 * torch.randn(out["render"].shape, device=dev, generator=g)).clamp(0, 1))
+            Nvis.append(int((out["radii"] > 0).sum()))
+    from scorp_amd import rasterizer3d as R
+    Ds = list(R.LAST_NUM_PAIRS_LOG[-len(my_cams):])
+    D_mean, Nvis_mean = float(np.mean(Ds)), float(np.mean(Nvis))
+
+    def step(i):
+        cam, gt = my_cams[i % len(my_cams)], gts[i % len(my_cams)]
+        out = render(cam, model, pipe, bg)
+        loss = photometric_loss(out["render"], gt, 0.2)
+        loss.backward()
+        for p in params:
+            p.grad = None
+        return loss
+
+    PairPolicy.mode, PairPolicy.reserve = "reserve", int(max(Ds) * 1.25) + 1024
+    for i in range(args.warmup):
+        step(i)
+    PairPolicy.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.no_kernel_events:
+        _C.prof_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    PairPolicy.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kern = {} if args.no_kernel_events else _C.prof_collect()
+    _C.prof_enable(False)
+    PairPolicy.mode = "exact"
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        ll = torch.tensor([float(loss)], device=dev)
+        gathered = [torch.zeros_like(ll) for _ in range(world)]
+        dist.all_gather(gathered, ll)     # gather of per-rank results (scalars)
+
+    if rank == 0:
+        views = args.steps * world
+        value = views / dt
+        HW = W * H
+        # dominant kernel by summed event time
+        roof = None
+        kernels = {}
+        if kern:
+            for name, (ms, cnt) in kern.items():
+                if cnt:
+                    b = kernel_algorithmic_bytes(name, N, Nvis_mean, K, HW, D_mean)
+                    avg_ms = ms / cnt
+                    kernels[name] = dict(avg_us=round(avg_ms * 1e3, 2), launches=cnt, alg_MB=round(b / 1e6, 2),
+                                         GBs=round(b / (avg_ms * 1e-3) / 1e9, 1))
+            dom = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
+            roof = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(kernels[dom]["GBs"] / HBM_PEAK_GBS, 5), traffic=None,
+                        avg_launch_us=kernels[dom]["avg_us"], algorithmic_bytes=int(kernel_algorithmic_bytes(dom, N, Nvis_mean, K, HW, D_mean)),
+                        note="blend kernels are bound by pixel-splat evaluation rate, not HBM; see DESIGN.md")
+        B_view = N * 720 + HW * 40 + 28 * D_mean
+        line = {
+            "metric": "fwd+bwd views/sec @1M Gaussians 1600x1200 SH3" if args.scene == "S3" else f"fwd+bwd views/sec ({args.scene})",
+            "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene}: {N} Gaussians, {W}x{H}, SH degree {deg}, ring cameras (SURVEY §8d)",
+                       "step": "render fwd + 0.8*L1+0.2*(1-SSIM) + backward to 59 params/Gaussian; no optimizer step",
+                       "views_per_rank": args.steps, "distinct_cameras_per_rank": len(my_cams),
+                       "pairs_per_view_D": round(D_mean), "D_over_N": round(D_mean / N, 3), "visible": round(Nvis_mean),
+                       "parallelism": f"view-sharded replicas x{world}"},
+            "roofline": roof,
+            "view_hbm": {"algorithmic_bytes_per_view": int(B_view), "achieved_GBs": round(value / world * B_view / 1e9, 1),
+                         "frac_of_8TBs": round(value / world * B_view / 8e12, 5)},
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"], _ = cpu_baseline(raw, my_cams[0].to("cpu"), deg, W, H)
+            line["parity"] = small_parity(dev)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,6 +126,14 @@ int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint64_t capaci
                            int32_t image_width, int32_t image_height, uint32_t *tile_start, uint32_t *point_list,
                            scorp_stream_t stream);
 
+/* ---- in-library kernel timing: hipEvent pairs recorded on the launch stream around every kernel ---- */
+/* Off by default. scorp_prof_enable(1) clears the accumulators and starts recording; collect() synchronises the
+ * recorded events and returns, per kernel id, the summed duration in ms and the number of launches. */
+int scorp_prof_enable(int on);
+int scorp_prof_num_kernels(void);
+const char *scorp_prof_kernel_name(int kernel_id);
+int scorp_prof_collect(double *total_ms, uint64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

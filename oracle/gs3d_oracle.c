@@ -358,6 +358,10 @@ void gs3d_oracle_tiles(const GsState *S, int64_t *tile_start, int *point_list) {
   if (point_list) memcpy(point_list, S->point_list, (size_t)S->D * sizeof(int));
 }
 
+static int g_parallel_backward = 0;
+void gs3d_oracle_parallel_backward(int on) { g_parallel_backward = on; }
+#define ACC(dst, val) do { REAL v_ = (val); if (par) { _Pragma("omp atomic") dst += v_; } else { dst += v_; } } while (0)
+
 /*
  * Backward. dL_dcolor[3,H,W], dL_ddepth[H,W], dL_dalpha[H,W] in; per-Gaussian gradients out (each may be
  * NULL, each is fully overwritten): means3D[N,3], means2D[N,3] (x,y in NDC-scaled units, z = 0), shs[N,K,3],
@@ -376,7 +380,11 @@ void gs3d_oracle_backward(const GsState *S, const REAL *dL_dcolor, const REAL *d
   REAL *a_rgb = (REAL *)calloc(n * 3, sizeof(REAL));
   REAL *a_dep = (REAL *)calloc(n, sizeof(REAL));
   int tiles = S->tiles_x * S->tiles_y;
-  for (int tile = 0; tile < tiles; tile++) { /* serial: accumulation order is then deterministic */
+  /* Serial by default: the accumulation order is then deterministic (tests compare runs bit for bit). The CPU
+   * baseline timing sets gs3d_oracle_parallel_backward(1): tiles in parallel, accumulators updated atomically. */
+  const int par = g_parallel_backward;
+#pragma omp parallel for schedule(dynamic, 4) if (par)
+  for (int tile = 0; tile < tiles; tile++) {
     int tx0 = (tile % S->tiles_x) * GS_TILE, ty0 = (tile / S->tiles_x) * GS_TILE;
     int64_t beg = S->tile_start[tile];
     for (int py = ty0; py < imin(ty0 + GS_TILE, H); py++)
@@ -405,13 +413,13 @@ void gs3d_oracle_backward(const GsState *S, const REAL *dL_dcolor, const REAL *d
             acc_c[c] = last_alpha * last_c[c] + (1 - last_alpha) * acc_c[c];
             last_c[c] = col;
             dL_dal += (col - acc_c[c]) * dpix[c];
-            a_rgb[3 * (size_t)g + c] += w * dpix[c];
+            ACC(a_rgb[3 * (size_t)g + c], w * dpix[c]);
           }
           REAL dep = S->depth[g];
           acc_d = last_alpha * last_d + (1 - last_alpha) * acc_d;
           last_d = dep;
           dL_dal += (dep - acc_d) * ddep;
-          a_dep[g] += w * ddep;
+          ACC(a_dep[g], w * ddep);
           acc_a = last_alpha + (1 - last_alpha) * acc_a;
           dL_dal += (1 - acc_a) * dalp;
           dL_dal *= T;
@@ -420,12 +428,12 @@ void gs3d_oracle_backward(const GsState *S, const REAL *dL_dcolor, const REAL *d
           REAL dL_dG = co[3] * dL_dal;
           REAL gdx = G * dx, gdy = G * dy;
           REAL dG_ddx = -gdx * co[0] - gdy * co[1], dG_ddy = -gdy * co[2] - gdx * co[1];
-          a_xy[2 * (size_t)g] += dL_dG * dG_ddx * (REAL)0.5 * W;
-          a_xy[2 * (size_t)g + 1] += dL_dG * dG_ddy * (REAL)0.5 * H;
-          a_con[3 * (size_t)g] += (REAL)-0.5 * gdx * dx * dL_dG;
-          a_con[3 * (size_t)g + 1] += -gdx * dy * dL_dG;
-          a_con[3 * (size_t)g + 2] += (REAL)-0.5 * gdy * dy * dL_dG;
-          a_op[g] += G * dL_dal;
+          ACC(a_xy[2 * (size_t)g], dL_dG * dG_ddx * (REAL)0.5 * W);
+          ACC(a_xy[2 * (size_t)g + 1], dL_dG * dG_ddy * (REAL)0.5 * H);
+          ACC(a_con[3 * (size_t)g], (REAL)-0.5 * gdx * dx * dL_dG);
+          ACC(a_con[3 * (size_t)g + 1], -gdx * dy * dL_dG);
+          ACC(a_con[3 * (size_t)g + 2], (REAL)-0.5 * gdy * dy * dL_dG);
+          ACC(a_op[g], G * dL_dal);
         }
       }
   }

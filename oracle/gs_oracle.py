@@ -41,6 +41,11 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+def set_parallel_backward(on, dtype=np.float32):
+    """Tiles of the backward replay in parallel (atomic accumulation; order no longer deterministic). Timing only."""
+    _lib(dtype).gs3d_oracle_parallel_backward(ctypes.c_int(1 if on else 0))
+
+
 class OracleRender:
     """One forward pass; keeps the inputs alive because the C state borrows their pointers."""
 

@@ -33,6 +33,7 @@ EXPORTS = [
     "scorp_version", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
     "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
+    "scorp_prof_enable", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
 ]
 
 _lib = None
@@ -64,8 +65,26 @@ def lib():
                                       ctypes.POINTER(ScorpGs3dGrads), vp, sz, vp]
     L.scorp_gs3d_debug_geom.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.scorp_gs3d_debug_tiles.argtypes = [vp, vp, u64, i32, i32, i32, vp, vp, vp]
+    L.scorp_prof_enable.argtypes = [ctypes.c_int]
+    L.scorp_prof_kernel_name.restype = ctypes.c_char_p
+    L.scorp_prof_kernel_name.argtypes = [ctypes.c_int]
+    L.scorp_prof_collect.argtypes = [vp, vp]
     _lib = L
     return L
+
+
+def prof_enable(on=True):
+    check(lib().scorp_prof_enable(1 if on else 0), "scorp_prof_enable")
+
+
+def prof_collect():
+    """{kernel name: (total ms, launches)} of the kernels timed since prof_enable(True); synchronises."""
+    L = lib()
+    n = L.scorp_prof_num_kernels()
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_uint64 * n)()
+    check(L.scorp_prof_collect(ms, cnt), "scorp_prof_collect")
+    return {L.scorp_prof_kernel_name(k).decode(): (ms[k], int(cnt[k])) for k in range(n)}
 
 
 def check(code, what):

@@ -87,6 +87,20 @@ struct PairLayout {
   }
 };
 
+// ---- in-library kernel timing (api.hip) ----
+enum KernelId {
+  kKPreprocess = 0, kKScanTiles, kKScatterPairs, kKSortTiles, kKBlendForward, kKBlendBackward, kKPreprocessBackward,
+  kKNumKernels
+};
+extern bool g_prof_on;
+void prof_begin(int kernel_id, hipStream_t stream);
+void prof_end(int kernel_id, hipStream_t stream);
+struct ProfScope {  // brackets one kernel launch with an event pair when profiling is enabled
+  int id; hipStream_t s;
+  ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { if (g_prof_on) prof_begin(id, s); }
+  ~ProfScope() { if (g_prof_on) prof_end(id, s); }
+};
+
 // ---- host error plumbing ----
 void set_error(const char *fmt, ...);
 

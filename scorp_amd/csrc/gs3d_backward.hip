@@ -399,16 +399,22 @@ extern "C" int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state,
   const char *base = (const char *)state, *pb = (const char *)pairs;
   float *acc = (float *)scratch;
   SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAccStride * sizeof(float), stream));
+  {
+  ProfScope prof(kKBlendBackward, stream);
   blend_backward_kernel<<<L.tiles, 256, 0, stream>>>(
       (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const SplatRec *)(base + L.rec),
       (uint32_t)capacity, W, H, L.tiles_x, in->bg, (const float *)(base + L.final_T),
       (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc);
+  }
   SCORP_KERNEL_CHECK("blend_backward", in->debug, stream);
+  {
+  ProfScope prof(kKPreprocessBackward, stream);
   preprocess_backward_kernel<<<(N + 255) / 256, 256, 0, stream>>>(
       N, in->sh_coeffs, in->sh_degree, W, H, in->tanfovx, in->tanfovy, in->scale_modifier, in->viewmatrix,
       in->projmatrix, in->campos, in->means3D, in->shs, in->colors_precomp, in->scales, in->rotations,
       in->cov3D_precomp, (const BinRec *)(base + L.bin), acc, grads->means3D, grads->means2D, grads->shs,
       grads->colors_precomp, grads->opacities, grads->scales, grads->rotations, grads->cov3D_precomp);
+  }
   SCORP_KERNEL_CHECK("preprocess_backward", in->debug, stream);
   return SCORP_OK;
 }

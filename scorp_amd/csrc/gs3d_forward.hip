@@ -462,6 +462,7 @@ extern "C" int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_rad
   uint32_t *tile_count = (uint32_t *)(base + L.tile_count);
   SCORP_HIP_CHECK(hipMemsetAsync(tile_count, 0, ((size_t)L.tiles + 1) * 4, stream));
   if (N > 0) {
+    ProfScope prof(kKPreprocess, stream);
     preprocess_kernel<<<(N + 255) / 256, 256, 0, stream>>>(
         N, in->sh_coeffs, in->sh_degree, W, H, in->tanfovx, in->tanfovy, in->scale_modifier, in->viewmatrix,
         in->projmatrix, in->campos, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
@@ -469,8 +470,11 @@ extern "C" int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_rad
         tile_count, L.tiles_x, L.tiles_y);
     SCORP_KERNEL_CHECK("preprocess", in->debug, stream);
   }
-  scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, (uint32_t *)(base + L.tile_start), L.tiles,
-                                            (StateHeader *)(base + L.header));
+  {
+    ProfScope prof(kKScanTiles, stream);
+    scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, (uint32_t *)(base + L.tile_start), L.tiles,
+                                              (StateHeader *)(base + L.header));
+  }
   SCORP_KERNEL_CHECK("scan_tiles", in->debug, stream);
   return SCORP_OK;
 }
@@ -516,15 +520,24 @@ extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *p
   uint64_t *keys = (uint64_t *)(pb + P.keys);
   uint32_t *point_list = (uint32_t *)(pb + P.list);
   StateHeader *header = (StateHeader *)(base + L.header);
-  scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), tile_count,
-                                                                    tile_start, L.tiles_x, keys, (uint32_t)capacity,
-                                                                    header);
+  {
+    ProfScope prof(kKScatterPairs, stream);
+    scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), tile_count,
+                                                                      tile_start, L.tiles_x, keys, (uint32_t)capacity,
+                                                                      header);
+  }
   SCORP_KERNEL_CHECK("scatter_pairs", in->debug, stream);
-  sort_tiles_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, (uint32_t)capacity, kSortLds);
+  {
+    ProfScope prof(kKSortTiles, stream);
+    sort_tiles_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, (uint32_t)capacity, kSortLds);
+  }
   SCORP_KERNEL_CHECK("sort_tiles", in->debug, stream);
-  blend_forward_kernel<true><<<L.tiles, 256, 0, stream>>>(
-      tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, in->bg,
-      out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib));
+  {
+    ProfScope prof(kKBlendForward, stream);
+    blend_forward_kernel<true><<<L.tiles, 256, 0, stream>>>(
+        tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, in->bg,
+        out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib));
+  }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;
 }

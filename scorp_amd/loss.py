@@ -1,0 +1,65 @@
+"""Photometric losses of the training step — mirrors gs3dgs/utils/loss_utils.py:17-73 and
+gs3dgs/utils/image_utils.py:18-20: `l1_loss`, `ssim` (11x11 Gaussian window, sigma 1.5, zero padding 5,
+C1=0.01^2, C2=0.03^2, mean over all elements) and `psnr`.
+
+`ssim` here is the torch formulation (five depthwise convolutions, as in the reference) with the window cached
+per device instead of rebuilt on the CPU and uploaded on every call (loss_utils.py:45-49).  The fused HIP
+version lives behind scorp_amd.fused_loss (same numbers, one pass).
+"""
+from math import exp
+
+import torch
+import torch.nn.functional as F
+
+_WINDOWS = {}
+
+
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()
+
+
+def l2_loss(network_output, gt):
+    return ((network_output - gt) ** 2).mean()
+
+
+def gaussian(window_size, sigma):
+    g = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    return g / g.sum()
+
+
+def create_window(window_size, channel):
+    w1 = gaussian(window_size, 1.5).unsqueeze(1)
+    w2 = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(channel, 1, window_size, window_size).contiguous()
+
+
+def _window(window_size, channel, like):
+    key = (window_size, channel, like.device, like.dtype)
+    if key not in _WINDOWS:
+        _WINDOWS[key] = create_window(window_size, channel).to(device=like.device, dtype=like.dtype)
+    return _WINDOWS[key]
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    channel = img1.size(-3)
+    window = _window(window_size, channel, img1)
+    pad = window_size // 2
+    conv = lambda x: F.conv2d(x, window, padding=pad, groups=channel)
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = conv(img1 * img1) - mu1_sq
+    sigma2_sq = conv(img2 * img2) - mu2_sq
+    sigma12 = conv(img1 * img2) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+    return ssim_map.mean() if size_average else ssim_map.mean(1).mean(1).mean(1)
+
+
+def psnr(img1, img2):
+    mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+def photometric_loss(image, gt, lambda_dssim=0.2):
+    """(1-lambda) L1 + lambda (1-SSIM), train_3dgs.py:106-107."""
+    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))

@@ -64,6 +64,9 @@ class PairPolicy:
         return worst
 
 
+LAST_NUM_PAIRS_LOG = []   # pair counts of the most recent "exact"-mode forwards (diagnostics / bench bookkeeping)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -129,6 +132,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             n = ctypes.c_uint64(0)
             _C.check(L.scorp_gs3d_num_pairs(_ptr(state), stream, ctypes.byref(n)), "scorp_gs3d_num_pairs")
             capacity = max(int(n.value), 1)
+            LAST_NUM_PAIRS_LOG.append(int(n.value))
+            del LAST_NUM_PAIRS_LOG[:-64]
         else:
             if PairPolicy.reserve <= 0:
                 PairPolicy.reserve = max(4 * N, 1 << 20)

@@ -173,7 +173,7 @@ def test_empty_and_fully_culled(dev):
     out, t = hip_render(kw, dev)
     color, radii, depth, alpha = out
     assert radii.numel() == 0
-    np.testing.assert_allclose(color[:, 0, 0].cpu().numpy(), [0.3, 0.6, 0.9], atol=1e-7)
+    np.testing.assert_allclose(color[:, 0, 0].detach().cpu().numpy(), [0.3, 0.6, 0.9], atol=1e-7)
     assert float(alpha.abs().max()) == 0.0 and float(depth.abs().max()) == 0.0
     # everything behind the camera
     kw, _ = make_case(100, 50, 30, 2, 2, bg=(0.1, 0.2, 0.3))
@@ -181,7 +181,7 @@ def test_empty_and_fully_culled(dev):
     out, t = hip_render(kw, dev)
     color, radii, depth, alpha = out
     assert int(radii.abs().max()) == 0
-    np.testing.assert_allclose(color[:, 5, 7].cpu().numpy(), [0.1, 0.2, 0.3], atol=1e-7)
+    np.testing.assert_allclose(color[:, 5, 7].detach().cpu().numpy(), [0.1, 0.2, 0.3], atol=1e-7)
     (color.sum() + depth.sum() + alpha.sum()).backward()
     for k in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
         assert float(t[k].grad.abs().max()) == 0.0
