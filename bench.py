@@ -48,6 +48,8 @@ def kernel_algorithmic_bytes(name, N, Nvis, K, HW, D):
         "blend_forward": D * 4 + Nvis * 48 + HW * (20 + 8),
         "blend_backward": D * 4 + Nvis * 48 + HW * (20 + 8) + Nvis * 40,
         "preprocess_backward": N * (per_g_in + 16) + Nvis * (K * 12 + 48) + N * 248,
+        "ssim_l1_forward": HW * 3 * (8 + 12),       # read img+gt, write 3 derivative maps
+        "ssim_l1_backward": HW * 3 * (12 + 8 + 4),  # read 3 maps + img+gt, write grad
     }[name]
 
 
@@ -120,7 +122,7 @@ def main():
 
     from scorp_amd import _C
     from scorp_amd.gaussian_model import GaussianModel
-    from scorp_amd.loss import photometric_loss
+    from scorp_amd.fused_loss import fused_l1_ssim_loss
     from scorp_amd.rasterizer3d import PairPolicy
     from scorp_amd.renderer import render
     from scorp_amd.synthetic import SCENES, make_gaussians, ring_cameras
@@ -166,7 +168,7 @@ def main():
     def step(i):
         cam, gt = my_cams[i % len(my_cams)], gts[i % len(my_cams)]
         out = render(cam, model, pipe, bg)
-        loss = photometric_loss(out["render"], gt, 0.2)
+        loss = fused_l1_ssim_loss(out["render"], gt, 0.2)
         loss.backward()
         for p in params:
             p.grad = None

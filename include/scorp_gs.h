@@ -126,6 +126,20 @@ int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint64_t capaci
                            int32_t image_width, int32_t image_height, uint32_t *tile_start, uint32_t *point_list,
                            scorp_stream_t stream);
 
+/* ---- fused photometric loss (rows a8/a9 of the hot path) ----
+ * loss = (1-lambda) * mean|x-y| + lambda * (1 - mean SSIM(x,y)), x = img*mask, y = gt*mask (mask [H,W] or NULL):
+ * train_3dgs.py:106-107, post_refine_gs.py:103-111 over gs3dgs/utils/loss_utils.py:17-73 (11x11 Gaussian window,
+ * sigma 1.5, zero padding, C1=1e-4, C2=9e-4).  img/gt are [C,H,W].  out_loss3 (device) = {loss, l1, ssim}.
+ * The workspace carries the forward's derivative maps to the backward (read-only there). */
+size_t scorp_loss_workspace_bytes(int32_t channels, int32_t height, int32_t width);
+int scorp_loss_l1_ssim_forward(const float *img, const float *gt, const float *mask, int32_t channels, int32_t height,
+                               int32_t width, float lambda_dssim, float *out_loss3, void *workspace,
+                               size_t workspace_bytes, int32_t need_backward, scorp_stream_t stream);
+/* grad_img[C,H,W] = grad_out[0] * d loss / d img (grad_out: device scalar, NULL = 1). */
+int scorp_loss_l1_ssim_backward(const float *img, const float *gt, const float *mask, int32_t channels, int32_t height,
+                                int32_t width, float lambda_dssim, const void *workspace, const float *grad_out,
+                                float *grad_img, scorp_stream_t stream);
+
 /* ---- in-library kernel timing: hipEvent pairs recorded on the launch stream around every kernel ---- */
 /* Off by default. scorp_prof_enable(1) clears the accumulators and starts recording; collect() synchronises the
  * recorded events and returns, per kernel id, the summed duration in ms and the number of launches. */

@@ -33,6 +33,7 @@ EXPORTS = [
     "scorp_version", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
     "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
+    "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
     "scorp_prof_enable", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
 ]
 
@@ -65,6 +66,10 @@ def lib():
                                       ctypes.POINTER(ScorpGs3dGrads), vp, sz, vp]
     L.scorp_gs3d_debug_geom.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.scorp_gs3d_debug_tiles.argtypes = [vp, vp, u64, i32, i32, i32, vp, vp, vp]
+    L.scorp_loss_workspace_bytes.restype = sz
+    L.scorp_loss_workspace_bytes.argtypes = [i32, i32, i32]
+    L.scorp_loss_l1_ssim_forward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, sz, i32, vp]
+    L.scorp_loss_l1_ssim_backward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, vp, vp]
     L.scorp_prof_enable.argtypes = [ctypes.c_int]
     L.scorp_prof_kernel_name.restype = ctypes.c_char_p
     L.scorp_prof_kernel_name.argtypes = [ctypes.c_int]

@@ -90,7 +90,7 @@ struct PairLayout {
 // ---- in-library kernel timing (api.hip) ----
 enum KernelId {
   kKPreprocess = 0, kKScanTiles, kKScatterPairs, kKSortTiles, kKBlendForward, kKBlendBackward, kKPreprocessBackward,
-  kKNumKernels
+  kKLossForward, kKLossBackward, kKNumKernels
 };
 extern bool g_prof_on;
 void prof_begin(int kernel_id, hipStream_t stream);
