@@ -4,6 +4,8 @@
 // train_3dgs.py:152; colour-only at post_refine_gs.py:53-56; w.r.t. colors_precomp at utils/mask.py:47-70).
 // Arithmetic follows oracle/gs3d_oracle.c::gs3d_oracle_backward.  The forward state and the pair buffer are
 // only read, so the backward can be replayed on one forward.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace scorp {
@@ -29,8 +31,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // 256 records, per-wave ballot cull). Each lane produces 10 partial gradients per splat; they are summed over
 // the wave and added to the per-Gaussian accumulator with float atomics (one add per wave per value).
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-blend_backward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+__device__ __forceinline__ void
+blend_backward_body(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                       const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x,
                       const float *__restrict__ bg, const float *__restrict__ final_T,
                       const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
@@ -140,6 +142,249 @@ blend_backward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *_
         if (lane < 10) atomicAdd(acc + (size_t)s_id[jj] * kAccStride + lane, v);
       }
     }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+blend_backward_kernel_abl(const uint32_t *tile_start, const uint32_t *point_list, const SplatRec *rec, uint32_t capacity,
+                          int W, int H, int tiles_x, const float *bg, const float *final_T, const uint32_t *n_contrib,
+                          const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha, float *acc, int) {
+  // same signature as the MFMA kernel so the launcher can switch between them
+  blend_backward_body(tile_start, point_list, rec, capacity, W, H, tiles_x, bg, final_T, n_contrib, dL_dcolor, dL_ddepth,
+                      dL_dalpha, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// B1m: the same replay with the pixel->splat reduction done on the matrix cores.
+//
+// For one splat the ten sums over pixels factor as  sum_p v_p * {1, x_p, y_p, x_p^2, x_p y_p, y_p^2}  (geometry:
+// v_p = G * opacity * dL/dalpha, pixel coordinates relative to the tile centre) and  sum_p w_p * {dL/dr, dL/dg, dL/db,
+// dL/ddepth}_p  (w_p = alpha * T).  With a wave's 64 pixels as the K dimension that is D[16 splats][16] =
+// [V | W](16 x 128) * [basis_v ; basis_w](128 x 16): 32 exact-fp32 v_mfma_f32_16x16x4_f32 per 16 splats instead of
+// 60 cross-lane shuffles per splat.
+//
+// Per wave and 16-splat group:
+//   1a (straight-line, no dependence between splats): alpha and G*opacity of the 16 splats at this lane's pixel;
+//   1b (the sequential part): T, the blended-behind recurrence and dL/dalpha.  A splat that does not contribute to
+//      this pixel is carried through as alpha = 0, which leaves every recurrence bit-for-bit unchanged, so the
+//      group is branch-free.  The five "accumulated colour/depth/alpha behind" recurrences of the textbook form
+//      collapse into ONE, because only their dot product with this pixel's upstream gradient is ever used:
+//      s = c.dL/dcolor + z*dL/ddepth + dL/dalpha,  R <- last_alpha * s_last + (1 - last_alpha) * R,
+//      dL/dalpha_i = (s - R) * T - T_final / (1 - alpha) * (bg . dL/dcolor);
+//   lane (= pixel) writes v, w into a wave-private LDS matrix [slot][pixel] (row stride 65 floats: the row writes and
+//   the transposed A-operand reads are both conflict-free); the per-pixel basis is loop-invariant and lives in 32
+//   registers as the B operand;
+//   the 16x16 MFMA result is added to per-tile LDS accumulators (one row per splat of the batch).
+// After the batch the rows are turned from tile-frame moments into the ten gradients and flushed with float atomics
+// shaped as whole 40-byte row segments (lanes = consecutive floats).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kXStride = 65;                 // floats per slot row of the wave-private v / w matrices
+constexpr int kGroup = 16;                   // splats per MFMA group
+constexpr float kLog2e = 1.4426950408889634f;
+
+template <int kBatch>
+__global__ void __launch_bounds__(256, 3)
+blend_backward_mfma_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x,
+                           const float *__restrict__ bg, const float *__restrict__ final_T,
+                           const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
+                           const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dalpha,
+                           float *__restrict__ acc, int ablate) {
+  // s_a = (x, y, A', B'), s_b = (C', opacity, r, g), s_c = (b, depth, rcut, -): conic pre-scaled for exp2
+  __shared__ float4 s_a[kBatch], s_b[kBatch], s_c[kBatch];
+  __shared__ uint32_t s_id[kBatch];
+  __shared__ float s_acc[kBatch * kAccStride];
+  __shared__ uint32_t s_touched[kBatch];
+  __shared__ float s_xv[4][kGroup * kXStride], s_xw[4][kGroup * kXStride];
+  __shared__ uint16_t s_list[4][kBatch + kGroup];
+  __shared__ uint32_t s_max;
+  const int tile = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tx0 = (tile % tiles_x) * kTile, ty0 = (tile / tiles_x) * kTile;
+  const int bx = tx0 + (wave & 1) * 8, by = ty0 + (wave >> 1) * 8;
+  const int px = bx + (lane & 7), py = by + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const float cx = (float)tx0 + 7.5f, cy = (float)ty0 + 7.5f;  // tile-frame origin
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  if (end == beg) return;
+  const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+  const float T_final = inside ? final_T[pix] : 0.0f;
+  const uint32_t last = inside ? n_contrib[pix] : 0u;
+  float dpix0 = 0.0f, dpix1 = 0.0f, dpix2 = 0.0f, ddep = 0.0f, dalp = 0.0f;
+  if (last > 0) {  // a pixel nothing was blended into never reads its upstream gradient (it may hold NaN: 0/0 of depth/alpha)
+    dpix0 = dL_dcolor[pix]; dpix1 = dL_dcolor[HW + pix]; dpix2 = dL_dcolor[2 * HW + pix];
+    if (dL_ddepth) ddep = dL_ddepth[pix];
+    if (dL_dalpha) dalp = dL_dalpha[pix];
+  }
+  const float tf_bg = T_final * (bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2);
+  // B operand of the MFMAs: lane (n = lane&15, k = lane>>4) holds basis[pixel q = t + 16k][n] for K-step t
+  const int bn = lane & 15, bk = lane >> 4;
+  float bv[16], bw[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    const int q = t + 16 * bk;
+    const int qx = bx + (q & 7), qy = by + (q >> 3);
+    const float xl = (float)qx - cx, yl = (float)qy - cy;
+    float v = 0.0f;
+    v = bn == 0 ? 1.0f : v; v = bn == 1 ? xl : v; v = bn == 2 ? yl : v;
+    v = bn == 3 ? xl * xl : v; v = bn == 4 ? xl * yl : v; v = bn == 5 ? yl * yl : v;
+    bv[t] = v;
+    float w = 0.0f;
+    if (qx < W && qy < H && bn >= 6 && bn <= 9) {
+      const size_t qp = (size_t)qy * W + qx;
+      if (n_contrib[qp] > 0) {  // same guard as above: 0 * NaN would poison the matrix product
+        if (bn <= 8) w = dL_dcolor[(size_t)(bn - 6) * HW + qp];
+        else w = dL_ddepth ? dL_ddepth[qp] : 0.0f;
+      }
+    }
+    bw[t] = w;
+  }
+  if (threadIdx.x == 0) s_max = 0;
+  for (int e = threadIdx.x; e < kBatch * kAccStride; e += 256) s_acc[e] = 0.0f;
+  if ((int)threadIdx.x < kBatch) s_touched[threadIdx.x] = 0;
+  __syncthreads();
+  atomicMax(&s_max, last);
+  __syncthreads();
+  const uint32_t todo = s_max;
+  float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
+  float *xv = s_xv[wave], *xw = s_xw[wave];
+  uint16_t *list = s_list[wave];
+  const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
+
+  for (uint32_t done_n = 0; done_n < todo; done_n += kBatch) {
+    const uint32_t top = todo - 1 - done_n;  // list position (0-based) held by batch slot 0
+    const int cnt = (int)min((uint32_t)kBatch, todo - done_n);
+    if ((int)threadIdx.x < cnt) {
+      const uint32_t id = point_list[beg + top - threadIdx.x];
+      const float4 *src = reinterpret_cast<const float4 *>(rec + id);
+      const float4 a = src[0], b = src[1], c = src[2];
+      s_a[threadIdx.x] = make_float4(a.x, a.y, -0.5f * kLog2e * a.z, -kLog2e * a.w);
+      s_b[threadIdx.x] = make_float4(-0.5f * kLog2e * b.x, b.y, b.z, b.w);
+      s_c[threadIdx.x] = c;
+      s_id[threadIdx.x] = id;
+    }
+    __syncthreads();
+    // compact the batch slots whose alpha >= 1/255 disc reaches this wave's 8x8 block
+    int nh = 0;
+    for (int q = 0; q < cnt; q += 64) {
+      const int j = q + lane;
+      bool hit = false;
+      if (j < cnt) {
+        const float4 a = s_a[j];
+        const float rc = s_c[j].z;
+        const float ddx = fmaxf(fmaxf(bx0 - a.x, a.x - bx1), 0.0f), ddy = fmaxf(fmaxf(by0 - a.y, a.y - by1), 0.0f);
+        hit = ddx * ddx + ddy * ddy <= rc * rc;
+      }
+      const uint64_t m = __ballot(hit);
+      if (hit) list[nh + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)j;
+      nh += __builtin_popcountll(m);
+    }
+    if (lane < kGroup) list[nh + lane] = 0;  // padding entries of the last group point at a real slot
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    for (int g0 = 0; g0 < nh; g0 += kGroup) {
+      const int nslots = min(kGroup, nh - g0);
+      float Go[kGroup], al[kGroup];
+      uint32_t jjs[kGroup];
+      bool any = false;
+      // ---- 1a: independent per splat ----
+#pragma unroll
+      for (int i = 0; i < kGroup; i++) {
+        const uint32_t jj = __builtin_amdgcn_readfirstlane((uint32_t)list[g0 + i]);
+        jjs[i] = jj;
+        const float4 a = s_a[jj];
+        const float2 co = *reinterpret_cast<const float2 *>(&s_b[jj]);
+        const float dx = a.x - pxf, dy = a.y - pyf;
+        const float p2 = a.z * dx * dx + co.x * dy * dy + a.w * dx * dy;  // log2 of the Gaussian falloff
+        const float G = __builtin_amdgcn_exp2f(p2);
+        const float alpha = fminf(kAlphaMax, co.y * G);
+        const bool ok = i < nslots && (top - jj + 1u) <= last && p2 <= 0.0f && alpha >= kAlphaMin;
+        al[i] = ok ? alpha : 0.0f;
+        Go[i] = ok ? G * co.y : 0.0f;
+        any |= ok;
+      }
+      if (__ballot(any) == 0 || (ablate & 2)) continue;  // nothing of this group reaches any pixel of the block
+      // ---- 1b: the sequential recurrence, branch-free (alpha = 0 is an exact no-op) ----
+#pragma unroll
+      for (int i = 0; i < kGroup; i++) {
+        const uint32_t jj = jjs[i];
+        const float2 rg = *reinterpret_cast<const float2 *>(&s_b[jj].z);
+        const float2 bz = *reinterpret_cast<const float2 *>(&s_c[jj]);
+        const float alpha = al[i];
+        const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+        T *= rinv;
+        const float w = alpha * T;
+        R = last_alpha * (s_last - R) + R;
+        const float sc = rg.x * dpix0 + rg.y * dpix1 + bz.x * dpix2 + bz.y * ddep + dalp;
+        const float dL_dal = (sc - R) * T - tf_bg * rinv;
+        s_last = sc;
+        last_alpha = alpha;
+        xv[i * kXStride + lane] = Go[i] * dL_dal;
+        xw[i * kXStride + lane] = w;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (ablate & 4) continue;
+      // ---- MFMA: D[slot][n] = sum over the 64 pixels ----
+      f32x4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[abase + t], bv[t], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[abase + t + 1], bv[t + 1], d1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[abase + t], bw[t], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[abase + t + 1], bw[t + 1], d1, 0, 0, 0);
+      }
+      const f32x4 d = d0 + d1;
+      // D: this lane holds column n = lane&15 of rows (slots) 4*(lane>>4) + r
+      if (bn < 10) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int sl = 4 * bk + r;
+          if (sl < nslots) {
+            const uint32_t jj = list[g0 + sl];
+            atomicAdd(&s_acc[jj * kAccStride + bn], d[r]);
+            if (bn == 0) s_touched[jj] = 1u;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // moments (tile frame) -> the ten screen-space gradients, in place
+    if ((int)threadIdx.x < cnt && s_touched[threadIdx.x]) {
+      float *m = s_acc + threadIdx.x * kAccStride;
+      const float4 a = s_a[threadIdx.x], b = s_b[threadIdx.x];
+      const float cA = a.z * (-2.0f / kLog2e), cB = a.w * (-1.0f / kLog2e), cC = b.x * (-2.0f / kLog2e);
+      const float xl = a.x - cx, yl = a.y - cy;
+      const float m0 = m[0], mx = m[1], my = m[2], mxx = m[3], mxy = m[4], myy = m[5];
+      const float svdx = xl * m0 - mx, svdy = yl * m0 - my;
+      const float svdx2 = xl * xl * m0 - 2.0f * xl * mx + mxx;
+      const float svdxdy = xl * yl * m0 - xl * my - yl * mx + mxy;
+      const float svdy2 = yl * yl * m0 - 2.0f * yl * my + myy;
+      m[0] = 0.5f * W * (-cA * svdx - cB * svdy);
+      m[1] = 0.5f * H * (-cC * svdy - cB * svdx);
+      m[2] = -0.5f * svdx2;
+      m[3] = -svdxdy;
+      m[4] = -0.5f * svdy2;
+      m[5] = m0 / b.y;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt * kAccStride; e += 256) {
+      const int row = e / kAccStride, col = e - row * kAccStride;
+      if (col < 10 && s_touched[row] && !(ablate & 1)) atomicAdd(acc + (size_t)s_id[row] * kAccStride + col, s_acc[e]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt * kAccStride; e += 256) s_acc[e] = 0.0f;
+    if ((int)threadIdx.x < kBatch) s_touched[threadIdx.x] = 0;
+    __syncthreads();
   }
 }
 
@@ -399,12 +644,16 @@ extern "C" int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state,
   const char *base = (const char *)state, *pb = (const char *)pairs;
   float *acc = (float *)scratch;
   SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAccStride * sizeof(float), stream));
+  static const bool use_shuffle = getenv("SCORP_BWD_SHUFFLE") != nullptr;  // A/B switch: the pre-MFMA reduction
   {
   ProfScope prof(kKBlendBackward, stream);
-  blend_backward_kernel<<<L.tiles, 256, 0, stream>>>(
+  static const bool batch256 = getenv("SCORP_BWD_BATCH256") != nullptr;
+  static const int ablate = getenv("SCORP_BWD_ABLATE") ? atoi(getenv("SCORP_BWD_ABLATE")) : 0;  // timing experiments only
+  auto kern = use_shuffle ? blend_backward_kernel_abl : (batch256 ? blend_backward_mfma_kernel<256> : blend_backward_mfma_kernel<128>);
+  kern<<<L.tiles, 256, 0, stream>>>(
       (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const SplatRec *)(base + L.rec),
       (uint32_t)capacity, W, H, L.tiles_x, in->bg, (const float *)(base + L.final_T),
-      (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc);
+      (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc, ablate);
   }
   SCORP_KERNEL_CHECK("blend_backward", in->debug, stream);
   {
