@@ -41,9 +41,10 @@ def kernel_algorithmic_bytes(name, N, Nvis, K, HW, D):
     """Compulsory HBM bytes of one launch of each kernel: every datum moved once."""
     per_g_in = 12 + 4 + 12 + 16                      # xyz, opacity, scale, quaternion
     return {
-        "preprocess": N * (per_g_in + 16 + 4) + Nvis * (K * 12 + 48) + D * 4,
+        "preprocess": N * (per_g_in + 16 + 4) + Nvis * (K * 12 + 48),
+        "count_tiles": N * 16,
         "scan_tiles": 0,
-        "scatter_pairs": N * 16 + D * (8 + 4),
+        "scatter_pairs": N * 16 + D * 8,
         "sort_tiles": D * (8 + 4),
         "blend_forward": D * 4 + Nvis * 48 + HW * (20 + 8),
         "blend_backward": D * 4 + Nvis * 48 + HW * (20 + 8) + Nvis * 40,

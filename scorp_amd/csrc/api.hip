@@ -22,7 +22,7 @@ void set_error(const char *fmt, ...) {
 namespace scorp {
 bool g_prof_on = false;
 namespace {
-const char *kKernelNames[kKNumKernels] = {"preprocess", "scan_tiles", "scatter_pairs", "sort_tiles", "blend_forward",
+const char *kKernelNames[kKNumKernels] = {"preprocess", "count_tiles", "scan_tiles", "scatter_pairs", "sort_tiles", "blend_forward",
                                           "blend_backward", "preprocess_backward", "ssim_l1_forward", "ssim_l1_backward"};
 struct Pending { hipEvent_t start, stop; int id; };
 std::vector<Pending> g_pending;

@@ -56,9 +56,15 @@ constexpr int kAccStride = 12;  // dx, dy, dA, dB, dC, dopacity, dr, dg, db, dde
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Forward state layout (one caller-owned blob, 256-byte aligned sub-buffers).
+constexpr int kMaxLdsTiles = 16384;   // per-block tile histograms live in LDS up to this many tiles (64 KiB)
+constexpr int kBinBlocksMax = 512;    // blocks of the LDS-histogram binning (each owns a contiguous Gaussian range)
+
+inline int bin_blocks(int N) { int b = (N + 1023) / 1024; return b < 1 ? 1 : (b > kBinBlocksMax ? kBinBlocksMax : b); }
+
 struct StateLayout {
-  size_t header, rec, bin, tile_count, tile_start, final_T, n_contrib, total;
-  int tiles_x, tiles_y, tiles;
+  size_t header, rec, bin, tile_count, tile_start, final_T, n_contrib, block_hist, total;
+  int tiles_x, tiles_y, tiles, nb;
+  bool lds_binning;
   StateLayout(int N, int W, int H) {
     tiles_x = (W + kTile - 1) / kTile;
     tiles_y = (H + kTile - 1) / kTile;
@@ -72,6 +78,9 @@ struct StateLayout {
     tile_start = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
     final_T = off; off = align_up(off + hw * 4, 256);
     n_contrib = off; off = align_up(off + hw * 4, 256);
+    nb = bin_blocks(N);
+    lds_binning = tiles <= kMaxLdsTiles;
+    block_hist = off; off = align_up(off + (lds_binning ? (size_t)nb * tiles * 4 : 0), 256);
     total = off;
   }
 };
@@ -89,7 +98,7 @@ struct PairLayout {
 
 // ---- in-library kernel timing (api.hip) ----
 enum KernelId {
-  kKPreprocess = 0, kKScanTiles, kKScatterPairs, kKSortTiles, kKBlendForward, kKBlendBackward, kKPreprocessBackward,
+  kKPreprocess = 0, kKCountTiles, kKScanTiles, kKScatterPairs, kKSortTiles, kKBlendForward, kKBlendBackward, kKPreprocessBackward,
   kKLossForward, kKLossBackward, kKNumKernels
 };
 extern bool g_prof_on;

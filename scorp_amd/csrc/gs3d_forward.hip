@@ -92,7 +92,7 @@ preprocess_kernel(int N, int K, int deg, int W, int H, float tanfovx, float tanf
                   const float *__restrict__ opacities, const float *__restrict__ scales,
                   const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
                   SplatRec *__restrict__ rec, BinRec *__restrict__ bin, int32_t *__restrict__ radii,
-                  uint32_t *__restrict__ tile_count, int tiles_x, int tiles_y) {
+                  uint32_t *__restrict__ tile_count, int tiles_x, int tiles_y, int count_with_atomics) {
 #pragma clang fp contract(off)
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
@@ -200,8 +200,9 @@ preprocess_kernel(int N, int K, int deg, int W, int H, float tanfovx, float tanf
         br.depth_bits = __float_as_uint(tz);
         br.radius = radius | (clamp_bits << kClampShift);
         radius_out = radius;
-        for (int y = y0; y < y1; y++)
-          for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * tiles_x + x], 1u);
+        if (count_with_atomics)  // fallback binning for images with more tiles than an LDS histogram holds
+          for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * tiles_x + x], 1u);
       }
     }
   }
@@ -265,6 +266,87 @@ scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, uint32_t *__restrict
       const uint32_t slot = tile_start[t] + atomicSub(&tile_count[t], 1u) - 1u;
       if (slot < capacity) keys[slot] = key;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-histogram binning (the default).  Device-scope atomics on random addresses execute at the memory side, one
+// request per lane (~14 G/s measured here), so counting and bucketing 3.3 M pairs through global counters cost
+// ~450 us.  Instead each block owns a contiguous range of Gaussians and a private per-tile histogram in LDS:
+//   count : LDS atomics; the histogram is written out as one coalesced row  hist[block][tile];
+//   scan  : per tile, an exclusive prefix over blocks (column of hist, coalesced across threads) + the tile total;
+//           then the existing single-block scan of the totals gives tile_start;
+//   scatter: the block reloads its row (+ tile_start) as LDS cursors and ranks its pairs with returning LDS atomics.
+// Slot order inside a tile is arbitrary but deterministic; the per-tile depth sort fixes the final order.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+count_tiles_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, int tiles, int tiles_x,
+                       uint32_t *__restrict__ block_hist) {
+  extern __shared__ uint32_t s_hist[];
+  for (int t = threadIdx.x; t < tiles; t += 256) s_hist[t] = 0;
+  __syncthreads();
+  const int lo = blockIdx.x * per_block, hi = min(N, lo + per_block);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
+    const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
+    if ((br.radius & kRadiusMask) == 0) continue;
+    for (int y = br.y0; y < br.y1; y++)
+      for (int x = br.x0; x < br.x1; x++) atomicAdd(&s_hist[y * tiles_x + x], 1u);
+  }
+  __syncthreads();
+  uint32_t *row = block_hist + (size_t)blockIdx.x * tiles;
+  for (int t = threadIdx.x; t < tiles; t += 256) row[t] = s_hist[t];
+}
+
+// 64 tiles x 16 segments of the block range per workgroup: wave `seg` sums its blocks for 64 consecutive tiles
+// (coalesced 256-byte rows), the segment totals are exchanged through LDS, then the prefixes are written in place.
+__global__ void __launch_bounds__(1024)
+scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uint32_t *__restrict__ tile_count) {
+  __shared__ uint32_t s_seg[16][64];
+  const int tl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tl;
+  const int per = (nb + 15) / 16;
+  const int b0 = min(nb, seg * per), b1 = min(nb, b0 + per);
+  uint32_t sum = 0;
+  if (t < tiles)
+    for (int b = b0; b < b1; b++) sum += block_hist[(size_t)b * tiles + t];
+  s_seg[seg][tl] = sum;
+  __syncthreads();
+  uint32_t run = 0;
+  for (int q = 0; q < seg; q++) run += s_seg[q][tl];
+  if (t < tiles) {
+    for (int b = b0; b < b1; b++) {
+      const uint32_t c = block_hist[(size_t)b * tiles + t];
+      block_hist[(size_t)b * tiles + t] = run;
+      run += c;
+    }
+    if (seg == 15) tile_count[t] = run;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, int tiles, int tiles_x,
+                         const uint32_t *__restrict__ block_hist, const uint32_t *__restrict__ tile_start,
+                         uint64_t *__restrict__ keys, uint32_t capacity, StateHeader *__restrict__ header) {
+  extern __shared__ uint32_t s_cur[];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    header->capacity = capacity;
+    if (header->num_pairs > capacity) header->overflow = 1;
+  }
+  const uint32_t *row = block_hist + (size_t)blockIdx.x * tiles;
+  for (int t = threadIdx.x; t < tiles; t += 256) s_cur[t] = tile_start[t] + row[t];
+  __syncthreads();
+  const int lo = blockIdx.x * per_block, hi = min(N, lo + per_block);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
+    const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
+    if ((br.radius & kRadiusMask) == 0) continue;
+    const uint64_t key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
+    for (int y = br.y0; y < br.y1; y++)
+      for (int x = br.x0; x < br.x1; x++) {
+        const uint32_t slot = atomicAdd(&s_cur[y * tiles_x + x], 1u);
+        if (slot < capacity) keys[slot] = key;
+      }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -460,15 +542,26 @@ extern "C" int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_rad
   if (N > 0 && !out_radii) { set_error("out_radii is NULL"); return SCORP_ERR_INVALID; }
   char *base = (char *)state;
   uint32_t *tile_count = (uint32_t *)(base + L.tile_count);
-  SCORP_HIP_CHECK(hipMemsetAsync(tile_count, 0, ((size_t)L.tiles + 1) * 4, stream));
+  if (!L.lds_binning) SCORP_HIP_CHECK(hipMemsetAsync(tile_count, 0, ((size_t)L.tiles + 1) * 4, stream));
   if (N > 0) {
     ProfScope prof(kKPreprocess, stream);
     preprocess_kernel<<<(N + 255) / 256, 256, 0, stream>>>(
         N, in->sh_coeffs, in->sh_degree, W, H, in->tanfovx, in->tanfovy, in->scale_modifier, in->viewmatrix,
         in->projmatrix, in->campos, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
         in->rotations, in->cov3D_precomp, (SplatRec *)(base + L.rec), (BinRec *)(base + L.bin), out_radii,
-        tile_count, L.tiles_x, L.tiles_y);
+        tile_count, L.tiles_x, L.tiles_y, L.lds_binning ? 0 : 1);
     SCORP_KERNEL_CHECK("preprocess", in->debug, stream);
+  }
+  if (L.lds_binning) {
+    const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
+    uint32_t *block_hist = (uint32_t *)(base + L.block_hist);
+    {
+      ProfScope prof(kKCountTiles, stream);
+      count_tiles_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(N, per_block, (const BinRec *)(base + L.bin),
+                                                                        L.tiles, L.tiles_x, block_hist);
+      scan_block_hist_kernel<<<(L.tiles + 63) / 64, 1024, 0, stream>>>(L.nb, L.tiles, block_hist, tile_count);
+    }
+    SCORP_KERNEL_CHECK("count_tiles", in->debug, stream);
   }
   {
     ProfScope prof(kKScanTiles, stream);
@@ -522,9 +615,16 @@ extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *p
   StateHeader *header = (StateHeader *)(base + L.header);
   {
     ProfScope prof(kKScatterPairs, stream);
-    scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), tile_count,
-                                                                      tile_start, L.tiles_x, keys, (uint32_t)capacity,
-                                                                      header);
+    if (L.lds_binning) {
+      const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
+      scatter_pairs_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(
+          N, per_block, (const BinRec *)(base + L.bin), L.tiles, L.tiles_x, (const uint32_t *)(base + L.block_hist),
+          tile_start, keys, (uint32_t)capacity, header);
+    } else {
+      scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), tile_count,
+                                                                        tile_start, L.tiles_x, keys, (uint32_t)capacity,
+                                                                        header);
+    }
   }
   SCORP_KERNEL_CHECK("scatter_pairs", in->debug, stream);
   {
