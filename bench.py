@@ -35,6 +35,7 @@ class Pipe:
     convert_SHs_python = False
     compute_cov3D_python = False
     debug = False
+    fused_activations = True   # raw GaussianModel leaves go straight to the kernels (same numbers, no torch.cat / activations)
 
 
 def kernel_algorithmic_bytes(name, N, Nvis, K, HW, D):
@@ -106,6 +107,7 @@ def main():
     ap.add_argument("--cams", type=int, default=8, help="distinct cameras (with resident GT images) cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="reference call-site convention: torch activations + cat per view")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,6 +155,7 @@ def main():
     my_cams = [all_cams[(rank + world * i) % ncam_total] for i in range(args.cams)]   # view i -> rank i mod world
     bg = torch.zeros(3, device=dev)
     pipe = Pipe()
+    pipe.fused_activations = not args.unfused
 
     # resident ground truth + per-camera pair / visibility counts (exact mode, outside the timed region)
     gts, Ds, Nvis = [], [], []

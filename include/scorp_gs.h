@@ -67,6 +67,14 @@ typedef struct ScorpGs3dInputs {
   const float *scales;      /* [N,3] or NULL */
   const float *rotations;   /* [N,4] or NULL */
   const float *cov3D_precomp; /* [N,6] or NULL */
+  /* ---- optional "raw parameter" convention (zero / NULL = the reference call-site convention above) ----
+   * The GaussianModel stores logit opacity, log scale, an un-normalised quaternion and the SH coefficients split
+   * into _features_dc[N,1,3] / _features_rest[N,K-1,3]; its properties activate and torch.cat them on every view
+   * (gs3dgs/scene/gaussian_model.py:126-146).  With these fields the kernels do that themselves and the backward
+   * returns gradients w.r.t. the raw values, so the training harness skips six elementwise/cat kernels per view. */
+  const float *shs_rest;    /* non-NULL: `shs` is [N,1,3] (degree 0) and shs_rest is [N,sh_coeffs-1,3] */
+  int32_t raw_params;       /* bit 0: opacities are logits (sigmoid); bit 1: scales are logs (exp); bit 2: rotations
+                               are un-normalised (x / max(|x|, 1e-12)) */
 } ScorpGs3dInputs;
 
 /* Gradients w.r.t. the 8 call arguments; any pointer may be NULL (not wanted). Each is fully overwritten. */
@@ -79,6 +87,7 @@ typedef struct ScorpGs3dGrads {
   float *scales;         /* [N,3] */
   float *rotations;      /* [N,4] */
   float *cov3D_precomp;  /* [N,6] */
+  float *shs_rest;       /* [N,sh_coeffs-1,3] when the forward was given shs_rest (then `shs` is [N,1,3]) */
 } ScorpGs3dGrads;
 
 int scorp_version(void);

@@ -110,6 +110,12 @@ struct ProfScope {  // brackets one kernel launch with an event pair when profil
   ~ProfScope() { if (g_prof_on) prof_end(id, s); }
 };
 
+// ---- per-Gaussian kernels (gs3d_pergaussian.hip) ----
+void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec *rec, BinRec *bin, int32_t *radii,
+                       uint32_t *tile_count, hipStream_t stream);
+void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L, const BinRec *bin, const float *acc,
+                                const ScorpGs3dGrads *grads, hipStream_t stream);
+
 // ---- host error plumbing ----
 void set_error(const char *fmt, ...);
 

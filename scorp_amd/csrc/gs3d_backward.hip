@@ -11,14 +11,6 @@
 namespace scorp {
 namespace {
 
-constexpr float SH_C0 = 0.28209479177387814f;
-constexpr float SH_C1 = 0.4886025119029199f;
-__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                       -1.0925484305920792f, 0.5462742152960396f};
-__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
-                                       -0.5900435899266435f};
-
 // Sum over the 64 lanes of a wave; every lane gets the total.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -388,234 +380,6 @@ blend_backward_mfma_kernel(const uint32_t *__restrict__ tile_start, const uint32
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// B2: per-Gaussian chain rule: screen-space accumulators -> gradients of the 8 call arguments.
-// One thread per Gaussian; rebuilds the forward intermediates (cov3D, EWA Jacobian, SH basis) instead of
-// storing them. Writes zeros for culled Gaussians, so no separate memset of the gradient tensors is needed.
-// ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-preprocess_backward_kernel(int N, int K, int deg, int W, int H, float tanfovx, float tanfovy, float scale_mod,
-                           const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
-                           const float *__restrict__ campos, const float *__restrict__ means3D,
-                           const float *__restrict__ shs, const float *__restrict__ colors_precomp,
-                           const float *__restrict__ scales, const float *__restrict__ rotations,
-                           const float *__restrict__ cov3D_precomp, const BinRec *__restrict__ bin,
-                           const float *__restrict__ acc, float *__restrict__ g_means3D,
-                           float *__restrict__ g_means2D, float *__restrict__ g_shs, float *__restrict__ g_colors,
-                           float *__restrict__ g_opac, float *__restrict__ g_scales, float *__restrict__ g_rot,
-                           float *__restrict__ g_cov3D) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  float vm[16], pm[16];
-#pragma unroll
-  for (int q = 0; q < 16; q++) { vm[q] = viewmatrix[q]; pm[q] = projmatrix[q]; }
-  float gm[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gc6[6] = {0, 0, 0, 0, 0, 0};
-  float a_[kAccStride];
-#pragma unroll
-  for (int q = 0; q < kAccStride; q++) a_[q] = 0.0f;
-  float gsh[48];
-#pragma unroll
-  for (int q = 0; q < 48; q++) gsh[q] = 0.0f;
-  const int32_t rad_bits = bin[i].radius;
-  const bool visible = (rad_bits & kRadiusMask) != 0;
-  if (visible) {
-    const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAccStride);
-    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-    a_[0] = a0.x; a_[1] = a0.y; a_[2] = a0.z; a_[3] = a0.w; a_[4] = a1.x; a_[5] = a1.y; a_[6] = a1.z; a_[7] = a1.w;
-    a_[8] = a2.x; a_[9] = a2.y;
-    const float p0 = means3D[3 * (size_t)i], p1 = means3D[3 * (size_t)i + 1], p2 = means3D[3 * (size_t)i + 2];
-    const float tx = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
-    const float ty = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
-    const float tz = __builtin_fmaf(vm[10], p2, __builtin_fmaf(vm[6], p1, __builtin_fmaf(vm[2], p0, vm[14])));
-    float c6[6];
-    float R[9], sm[3] = {0, 0, 0};
-    if (cov3D_precomp) {
-#pragma unroll
-      for (int q = 0; q < 6; q++) c6[q] = cov3D_precomp[6 * (size_t)i + q];
-    } else {
-      const float4 q4 = reinterpret_cast<const float4 *>(rotations)[i];
-      const float r = q4.x, x = q4.y, y = q4.z, z = q4.w;
-      R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - r * z);     R[2] = 2 * (x * z + r * y);
-      R[3] = 2 * (x * y + r * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - r * x);
-      R[6] = 2 * (x * z - r * y);     R[7] = 2 * (y * z + r * x);     R[8] = 1 - 2 * (x * x + y * y);
-#pragma unroll
-      for (int k = 0; k < 3; k++) sm[k] = scale_mod * scales[3 * (size_t)i + k];
-      float L[9];
-#pragma unroll
-      for (int r_ = 0; r_ < 3; r_++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) L[r_ * 3 + k] = R[r_ * 3 + k] * sm[k];
-      c6[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
-      c6[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
-      c6[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
-      c6[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
-      c6[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
-      c6[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
-    }
-    const float limx = kFovGuard * tanfovx, limy = kFovGuard * tanfovy;
-    const float txtz = tx / tz, tytz = ty / tz;
-    const bool clamp_x = (txtz < -limx) || (txtz > limx), clamp_y = (tytz < -limy) || (tytz > limy);
-    const float txc = fminf(limx, fmaxf(-limx, txtz)) * tz, tyc = fminf(limy, fmaxf(-limy, tytz)) * tz;
-    const float fx = (float)W / (2 * tanfovx), fy = (float)H / (2 * tanfovy);
-    const float J00 = fx / tz, J02 = -(fx * txc) / (tz * tz), J11 = fy / tz, J12 = -(fy * tyc) / (tz * tz);
-    float M0[3], M1[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      M0[c] = J00 * vm[c * 4 + 0] + J02 * vm[c * 4 + 2];
-      M1[c] = J11 * vm[c * 4 + 1] + J12 * vm[c * 4 + 2];
-    }
-    float s0[3], s1[3];
-    s0[0] = c6[0] * M0[0] + c6[1] * M0[1] + c6[2] * M0[2];
-    s0[1] = c6[1] * M0[0] + c6[3] * M0[1] + c6[4] * M0[2];
-    s0[2] = c6[2] * M0[0] + c6[4] * M0[1] + c6[5] * M0[2];
-    s1[0] = c6[0] * M1[0] + c6[1] * M1[1] + c6[2] * M1[2];
-    s1[1] = c6[1] * M1[0] + c6[3] * M1[1] + c6[4] * M1[2];
-    s1[2] = c6[2] * M1[0] + c6[4] * M1[1] + c6[5] * M1[2];
-    const float a = M0[0] * s0[0] + M0[1] * s0[1] + M0[2] * s0[2] + kDilation;
-    const float b = M0[0] * s1[0] + M0[1] * s1[1] + M0[2] * s1[2];
-    const float c = M1[0] * s1[0] + M1[1] * s1[1] + M1[2] * s1[2] + kDilation;
-    const float det = a * c - b * b, d2 = 1.0f / (det * det + kDet2Eps);
-    const float gA = a_[2], gB = a_[3], gC = a_[4];
-    const float ga = d2 * (-c * c * gA + b * c * gB - b * b * gC);
-    const float gc = d2 * (-b * b * gA + a * b * gB - a * a * gC);
-    const float gb = d2 * (2 * b * c * gA - (a * c + b * b) * gB + 2 * a * b * gC);
-    const float h = 0.5f * gb;
-    float F[9];
-#pragma unroll
-    for (int r_ = 0; r_ < 3; r_++)
-#pragma unroll
-      for (int q = 0; q < 3; q++)
-        F[r_ * 3 + q] = ga * M0[r_] * M0[q] + h * (M0[r_] * M1[q] + M1[r_] * M0[q]) + gc * M1[r_] * M1[q];
-    gc6[0] = F[0]; gc6[1] = 2 * F[1]; gc6[2] = 2 * F[2]; gc6[3] = F[4]; gc6[4] = 2 * F[5]; gc6[5] = F[8];
-    float gM0[3], gM1[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      gM0[q] = 2 * (ga * s0[q] + h * s1[q]);
-      gM1[q] = 2 * (h * s0[q] + gc * s1[q]);
-    }
-    float gJ00 = 0, gJ02 = 0, gJ11 = 0, gJ12 = 0;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      gJ00 += gM0[q] * vm[q * 4 + 0]; gJ02 += gM0[q] * vm[q * 4 + 2];
-      gJ11 += gM1[q] * vm[q * 4 + 1]; gJ12 += gM1[q] * vm[q * 4 + 2];
-    }
-    const float tz2 = 1.0f / (tz * tz), tz3 = tz2 / tz;
-    float gt[3];
-    gt[0] = clamp_x ? 0.0f : -fx * tz2 * gJ02;
-    gt[1] = clamp_y ? 0.0f : -fy * tz2 * gJ12;
-    gt[2] = -fx * tz2 * gJ00 - fy * tz2 * gJ11 + 2 * fx * txc * tz3 * gJ02 + 2 * fy * tyc * tz3 * gJ12;
-    gt[2] += a_[9];
-#pragma unroll
-    for (int q = 0; q < 3; q++) gm[q] += vm[q * 4 + 0] * gt[0] + vm[q * 4 + 1] * gt[1] + vm[q * 4 + 2] * gt[2];
-    const float hx = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
-    const float hy = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
-    const float hw = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
-    const float pw = 1.0f / (hw + kWEps);
-#pragma unroll
-    for (int q = 0; q < 3; q++)
-      gm[q] += (pm[q * 4 + 0] * pw - pm[q * 4 + 3] * hx * pw * pw) * a_[0] +
-               (pm[q * 4 + 1] * pw - pm[q * 4 + 3] * hy * pw * pw) * a_[1];
-    if (!colors_precomp) {
-      const float *sh = shs + (size_t)i * K * 3;
-      const float d0 = p0 - campos[0], d1 = p1 - campos[1], d2_ = p2 - campos[2];
-      const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2_ * d2_);
-      const float x = d0 * inv, y = d1 * inv, z = d2_ * inv;
-      float gdir[3] = {0, 0, 0};
-#pragma unroll
-      for (int ch = 0; ch < 3; ch++) {
-        float rx = 0, ry = 0, rz = 0;
-        float basis[16];
-        basis[0] = SH_C0;
-        if (deg > 0) {
-          basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x;
-          rx = -SH_C1 * sh[9 + ch]; ry = -SH_C1 * sh[3 + ch]; rz = SH_C1 * sh[6 + ch];
-          if (deg > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz; basis[6] = SH_C2[2] * (2 * zz - xx - yy);
-            basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
-            rx += SH_C2[0] * y * sh[12 + ch] + SH_C2[2] * 2 * -x * sh[18 + ch] + SH_C2[3] * z * sh[21 + ch] + SH_C2[4] * 2 * x * sh[24 + ch];
-            ry += SH_C2[0] * x * sh[12 + ch] + SH_C2[1] * z * sh[15 + ch] + SH_C2[2] * 2 * -y * sh[18 + ch] + SH_C2[4] * 2 * -y * sh[24 + ch];
-            rz += SH_C2[1] * y * sh[15 + ch] + SH_C2[2] * 4 * z * sh[18 + ch] + SH_C2[3] * x * sh[21 + ch];
-            if (deg > 2) {
-              basis[9] = SH_C3[0] * y * (3 * xx - yy); basis[10] = SH_C3[1] * xy * z;
-              basis[11] = SH_C3[2] * y * (4 * zz - xx - yy); basis[12] = SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy);
-              basis[13] = SH_C3[4] * x * (4 * zz - xx - yy); basis[14] = SH_C3[5] * z * (xx - yy);
-              basis[15] = SH_C3[6] * x * (xx - 3 * yy);
-              rx += SH_C3[0] * sh[27 + ch] * 6 * xy + SH_C3[1] * sh[30 + ch] * yz + SH_C3[2] * sh[33 + ch] * -2 * xy +
-                    SH_C3[3] * sh[36 + ch] * -6 * xz + SH_C3[4] * sh[39 + ch] * (-3 * xx + 4 * zz - yy) +
-                    SH_C3[5] * sh[42 + ch] * 2 * xz + SH_C3[6] * sh[45 + ch] * 3 * (xx - yy);
-              ry += SH_C3[0] * sh[27 + ch] * 3 * (xx - yy) + SH_C3[1] * sh[30 + ch] * xz +
-                    SH_C3[2] * sh[33 + ch] * (-3 * yy + 4 * zz - xx) + SH_C3[3] * sh[36 + ch] * -6 * yz +
-                    SH_C3[4] * sh[39 + ch] * -2 * xy + SH_C3[5] * sh[42 + ch] * -2 * yz + SH_C3[6] * sh[45 + ch] * -6 * xy;
-              rz += SH_C3[1] * sh[30 + ch] * xy + SH_C3[2] * sh[33 + ch] * 8 * yz +
-                    SH_C3[3] * sh[36 + ch] * 3 * (2 * zz - xx - yy) + SH_C3[4] * sh[39 + ch] * 8 * xz +
-                    SH_C3[5] * sh[42 + ch] * (xx - yy);
-            }
-          }
-        }
-        const float gr = ((rad_bits >> (kClampShift + ch)) & 1) ? 0.0f : a_[6 + ch];
-        const int ncoef = (deg + 1) * (deg + 1);
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-          if (k < ncoef) gsh[3 * k + ch] = basis[k] * gr;
-        gdir[0] += rx * gr; gdir[1] += ry * gr; gdir[2] += rz * gr;
-      }
-      const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
-      gm[0] += (gdir[0] - x * dot) * inv; gm[1] += (gdir[1] - y * dot) * inv; gm[2] += (gdir[2] - z * dot) * inv;
-    }
-    if (!cov3D_precomp) {
-      const float4 q4 = reinterpret_cast<const float4 *>(rotations)[i];
-      const float r = q4.x, x = q4.y, y = q4.z, z = q4.w;
-      const float Gs[9] = {gc6[0], 0.5f * gc6[1], 0.5f * gc6[2], 0.5f * gc6[1], gc6[3], 0.5f * gc6[4],
-                           0.5f * gc6[2], 0.5f * gc6[4], gc6[5]};
-      float gL[9], gR[9];
-#pragma unroll
-      for (int r_ = 0; r_ < 3; r_++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          float s = 0;
-#pragma unroll
-          for (int m = 0; m < 3; m++) s += Gs[r_ * 3 + m] * R[m * 3 + k] * sm[k];
-          gL[r_ * 3 + k] = 2 * s;
-        }
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        gs[k] = scale_mod * (R[k] * gL[k] + R[3 + k] * gL[3 + k] + R[6 + k] * gL[6 + k]);
-#pragma unroll
-        for (int r_ = 0; r_ < 3; r_++) gR[r_ * 3 + k] = gL[r_ * 3 + k] * sm[k];
-      }
-      gq[0] = 2 * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
-      gq[1] = 2 * (y * gR[1] + z * gR[2] + y * gR[3] - 2 * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] - 2 * x * gR[8]);
-      gq[2] = 2 * (-2 * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] - 2 * y * gR[8]);
-      gq[3] = 2 * (-2 * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2 * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
-    }
-  }
-  if (g_means3D) { g_means3D[3 * (size_t)i] = gm[0]; g_means3D[3 * (size_t)i + 1] = gm[1]; g_means3D[3 * (size_t)i + 2] = gm[2]; }
-  if (g_means2D) { g_means2D[3 * (size_t)i] = a_[0]; g_means2D[3 * (size_t)i + 1] = a_[1]; g_means2D[3 * (size_t)i + 2] = 0.0f; }
-  if (g_colors) { g_colors[3 * (size_t)i] = a_[6]; g_colors[3 * (size_t)i + 1] = a_[7]; g_colors[3 * (size_t)i + 2] = a_[8]; }
-  if (g_opac) g_opac[i] = a_[5];
-  if (g_scales) { g_scales[3 * (size_t)i] = gs[0]; g_scales[3 * (size_t)i + 1] = gs[1]; g_scales[3 * (size_t)i + 2] = gs[2]; }
-  if (g_rot) reinterpret_cast<float4 *>(g_rot)[i] = make_float4(gq[0], gq[1], gq[2], gq[3]);
-  if (g_cov3D) {
-#pragma unroll
-    for (int q = 0; q < 6; q++) g_cov3D[6 * (size_t)i + q] = gc6[q];
-  }
-  if (g_shs) {
-    float *dst = g_shs + (size_t)i * K * 3;
-    if ((K & 3) == 0) {
-      float4 *d4 = reinterpret_cast<float4 *>(dst);
-      const int n4 = K * 3 / 4;
-#pragma unroll
-      for (int q = 0; q < 12; q++)
-        if (q < n4) d4[q] = make_float4(gsh[4 * q], gsh[4 * q + 1], gsh[4 * q + 2], gsh[4 * q + 3]);
-      for (int q = 12; q < n4; q++) d4[q] = make_float4(0, 0, 0, 0);
-    } else {
-      const int nfl = K * 3;
-      for (int q = 0; q < nfl; q++) dst[q] = q < 48 ? gsh[q] : 0.0f;
-    }
-  }
-}
-
 }  // namespace
 }  // namespace scorp
 
@@ -657,12 +421,8 @@ extern "C" int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state,
   }
   SCORP_KERNEL_CHECK("blend_backward", in->debug, stream);
   {
-  ProfScope prof(kKPreprocessBackward, stream);
-  preprocess_backward_kernel<<<(N + 255) / 256, 256, 0, stream>>>(
-      N, in->sh_coeffs, in->sh_degree, W, H, in->tanfovx, in->tanfovy, in->scale_modifier, in->viewmatrix,
-      in->projmatrix, in->campos, in->means3D, in->shs, in->colors_precomp, in->scales, in->rotations,
-      in->cov3D_precomp, (const BinRec *)(base + L.bin), acc, grads->means3D, grads->means2D, grads->shs,
-      grads->colors_precomp, grads->opacities, grads->scales, grads->rotations, grads->cov3D_precomp);
+    ProfScope prof(kKPreprocessBackward, stream);
+    launch_preprocess_backward(in, L, (const BinRec *)(base + L.bin), acc, grads, stream);
   }
   SCORP_KERNEL_CHECK("preprocess_backward", in->debug, stream);
   return SCORP_OK;

@@ -13,203 +13,6 @@
 namespace scorp {
 namespace {
 
-struct Camera {
-  float view[16];
-  float proj[16];
-  float campos[3];
-};
-
-__device__ __forceinline__ Camera load_camera(const float *__restrict__ view, const float *__restrict__ proj,
-                                              const float *__restrict__ campos) {
-  Camera c;
-#pragma unroll
-  for (int i = 0; i < 16; i++) { c.view[i] = view[i]; c.proj[i] = proj[i]; }
-#pragma unroll
-  for (int i = 0; i < 3; i++) c.campos[i] = campos[i];
-  return c;
-}
-
-constexpr float SH_C0 = 0.28209479177387814f;
-constexpr float SH_C1 = 0.4886025119029199f;
-__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                       -1.0925484305920792f, 0.5462742152960396f};
-__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
-                                       -0.5900435899266435f};
-
-// SH -> RGB for one Gaussian (gs3dgs/utils/sh_utils.py:57-112 restated for the [K,3] layout the rasterizer gets).
-__device__ __forceinline__ void sh_to_rgb(int deg, const float *__restrict__ sh, float x, float y, float z,
-                                          float *rgb) {
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
-    float r = SH_C0 * sh[c];
-    if (deg > 0) {
-      r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
-      if (deg > 1) {
-        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        r = r + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] + SH_C2[2] * (2 * zz - xx - yy) * sh[18 + c] +
-            SH_C2[3] * xz * sh[21 + c] + SH_C2[4] * (xx - yy) * sh[24 + c];
-        if (deg > 2) {
-          r = r + SH_C3[0] * y * (3 * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
-              SH_C3[2] * y * (4 * zz - xx - yy) * sh[33 + c] + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[36 + c] +
-              SH_C3[4] * x * (4 * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
-              SH_C3[6] * x * (xx - 3 * yy) * sh[45 + c];
-        }
-      }
-    }
-    rgb[c] = r + 0.5f;
-  }
-}
-
-// Load the first 3*(deg+1)^2 floats of one Gaussian's SH block; 16-byte loads when the block is 16-byte aligned.
-__device__ __forceinline__ void load_sh(const float *__restrict__ base, int K, int deg, float *sh) {
-  const int nfl = 3 * (deg + 1) * (deg + 1);
-  if ((K & 3) == 0) {
-    const float4 *b4 = reinterpret_cast<const float4 *>(base);
-#pragma unroll
-    for (int q = 0; q < 12; q++)
-      if (q * 4 < nfl) {
-        float4 v = b4[q];
-        sh[q * 4 + 0] = v.x; sh[q * 4 + 1] = v.y; sh[q * 4 + 2] = v.z; sh[q * 4 + 3] = v.w;
-      }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 48; q++)
-      if (q < nfl) sh[q] = base[q];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// K1: per-Gaussian projection. One thread per Gaussian.  Floating-point contraction is OFF in this kernel so
-// the discrete decisions (cull, radius, tile rectangle) round exactly like the CPU oracle; it is HBM-bound
-// (236 B in, 68 B out per Gaussian), so the extra multiplies are free.
-// ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-preprocess_kernel(int N, int K, int deg, int W, int H, float tanfovx, float tanfovy, float scale_mod,
-                  const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix,
-                  const float *__restrict__ campos_p, const float *__restrict__ means3D,
-                  const float *__restrict__ shs, const float *__restrict__ colors_precomp,
-                  const float *__restrict__ opacities, const float *__restrict__ scales,
-                  const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
-                  SplatRec *__restrict__ rec, BinRec *__restrict__ bin, int32_t *__restrict__ radii,
-                  uint32_t *__restrict__ tile_count, int tiles_x, int tiles_y, int count_with_atomics) {
-#pragma clang fp contract(off)
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  const Camera cam = load_camera(viewmatrix, projmatrix, campos_p);
-  const float *vm = cam.view, *pm = cam.proj;
-  BinRec br;
-  br.x0 = br.y0 = br.x1 = br.y1 = 0; br.depth_bits = 0; br.radius = 0;
-  int radius_out = 0;
-  const float px_ = means3D[3 * (size_t)i], py_ = means3D[3 * (size_t)i + 1], pz_ = means3D[3 * (size_t)i + 2];
-  const float tx = vm[0] * px_ + vm[4] * py_ + vm[8] * pz_ + vm[12];
-  const float ty = vm[1] * px_ + vm[5] * py_ + vm[9] * pz_ + vm[13];
-  const float tz = __builtin_fmaf(vm[10], pz_, __builtin_fmaf(vm[6], py_, __builtin_fmaf(vm[2], px_, vm[14])));
-  if (tz > kNearZ) {
-    const float hx = pm[0] * px_ + pm[4] * py_ + pm[8] * pz_ + pm[12];
-    const float hy = pm[1] * px_ + pm[5] * py_ + pm[9] * pz_ + pm[13];
-    const float hw = pm[3] * px_ + pm[7] * py_ + pm[11] * pz_ + pm[15];
-    const float pw = 1.0f / (hw + kWEps);
-    const float ndcx = hx * pw, ndcy = hy * pw;
-    float c6[6];
-    if (cov3D_precomp) {
-#pragma unroll
-      for (int q = 0; q < 6; q++) c6[q] = cov3D_precomp[6 * (size_t)i + q];
-    } else {
-      const float4 q4 = reinterpret_cast<const float4 *>(rotations)[i];
-      const float r = q4.x, x = q4.y, y = q4.z, z = q4.w;
-      const float s0 = scale_mod * scales[3 * (size_t)i], s1 = scale_mod * scales[3 * (size_t)i + 1],
-                  s2 = scale_mod * scales[3 * (size_t)i + 2];
-      float L[9];
-      L[0] = (1 - 2 * (y * y + z * z)) * s0; L[1] = (2 * (x * y - r * z)) * s1;     L[2] = (2 * (x * z + r * y)) * s2;
-      L[3] = (2 * (x * y + r * z)) * s0;     L[4] = (1 - 2 * (x * x + z * z)) * s1; L[5] = (2 * (y * z - r * x)) * s2;
-      L[6] = (2 * (x * z - r * y)) * s0;     L[7] = (2 * (y * z + r * x)) * s1;     L[8] = (1 - 2 * (x * x + y * y)) * s2;
-      c6[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
-      c6[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
-      c6[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
-      c6[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
-      c6[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
-      c6[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
-    }
-    // EWA: M = J * Wrot (2x3), cov2D = M Sigma M^T + dilation
-    const float limx = kFovGuard * tanfovx, limy = kFovGuard * tanfovy;
-    const float txc = fminf(limx, fmaxf(-limx, tx / tz)) * tz;
-    const float tyc = fminf(limy, fmaxf(-limy, ty / tz)) * tz;
-    const float fx = (float)W / (2 * tanfovx), fy = (float)H / (2 * tanfovy);
-    const float J00 = fx / tz, J02 = -(fx * txc) / (tz * tz), J11 = fy / tz, J12 = -(fy * tyc) / (tz * tz);
-    float M0[3], M1[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      M0[c] = J00 * vm[c * 4 + 0] + J02 * vm[c * 4 + 2];
-      M1[c] = J11 * vm[c * 4 + 1] + J12 * vm[c * 4 + 2];
-    }
-    float s0v[3], s1v[3];
-    s0v[0] = c6[0] * M0[0] + c6[1] * M0[1] + c6[2] * M0[2];
-    s0v[1] = c6[1] * M0[0] + c6[3] * M0[1] + c6[4] * M0[2];
-    s0v[2] = c6[2] * M0[0] + c6[4] * M0[1] + c6[5] * M0[2];
-    s1v[0] = c6[0] * M1[0] + c6[1] * M1[1] + c6[2] * M1[2];
-    s1v[1] = c6[1] * M1[0] + c6[3] * M1[1] + c6[4] * M1[2];
-    s1v[2] = c6[2] * M1[0] + c6[4] * M1[1] + c6[5] * M1[2];
-    const float a = M0[0] * s0v[0] + M0[1] * s0v[1] + M0[2] * s0v[2] + kDilation;
-    const float b = M0[0] * s1v[0] + M0[1] * s1v[1] + M0[2] * s1v[2];
-    const float c = M1[0] * s1v[0] + M1[1] * s1v[1] + M1[2] * s1v[2] + kDilation;
-    const float det = a * c - b * b;
-    if (det != 0.0f) {
-      const float det_inv = 1.0f / det;
-      const float mid = 0.5f * (a + c);
-      const float disc = sqrtf(fmaxf(kLambdaFloor, mid * mid - det));
-      const float lam = fmaxf(mid + disc, mid - disc);
-      const int radius = (int)ceilf(kRadiusSigma * sqrtf(lam));
-      const float sx = ((ndcx + 1) * W - 1) * 0.5f, sy = ((ndcy + 1) * H - 1) * 0.5f;
-      const int x0 = min(tiles_x, max(0, (int)((sx - radius) / kTile)));
-      const int y0 = min(tiles_y, max(0, (int)((sy - radius) / kTile)));
-      const int x1 = min(tiles_x, max(0, (int)((sx + radius + kTile - 1) / kTile)));
-      const int y1 = min(tiles_y, max(0, (int)((sy + radius + kTile - 1) / kTile)));
-      if ((x1 - x0) * (y1 - y0) > 0) {
-        float rgb[3];
-        int clamp_bits = 0;
-        if (colors_precomp) {
-#pragma unroll
-          for (int q = 0; q < 3; q++) rgb[q] = colors_precomp[3 * (size_t)i + q];
-        } else {
-          float sh[48];
-          load_sh(shs + (size_t)i * K * 3, K, deg, sh);
-          const float dx = px_ - cam.campos[0], dy = py_ - cam.campos[1], dz = pz_ - cam.campos[2];
-          const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-          sh_to_rgb(deg, sh, dx * inv, dy * inv, dz * inv, rgb);
-#pragma unroll
-          for (int q = 0; q < 3; q++) {
-            if (rgb[q] < 0.0f) clamp_bits |= 1 << q;  // remembered for the backward (zero gradient where clamped)
-            rgb[q] = fmaxf(rgb[q], 0.0f);
-          }
-        }
-        const float op = opacities[i];
-        // Beyond rcut the splat's alpha is < 1/255 everywhere (|d|^2 / (2 lambda_max) > ln(255 o)), so a pixel
-        // block farther than rcut can skip it without changing a single output bit. 1% + 0.1 px of slack.
-        const float lg = logf(fmaxf(255.0f * op, 1.0f));
-        const float rcut = 1.01f * sqrtf(2.0f * lam * lg) + 0.1f;
-        SplatRec s;
-        s.x = sx; s.y = sy; s.A = c * det_inv; s.B = -b * det_inv;
-        s.C = a * det_inv; s.o = op; s.r = rgb[0]; s.g = rgb[1];
-        s.b = rgb[2]; s.depth = tz; s.rcut = rcut; s._ = 0.0f;
-        float4 *dst = reinterpret_cast<float4 *>(rec + i);
-        dst[0] = make_float4(s.x, s.y, s.A, s.B);
-        dst[1] = make_float4(s.C, s.o, s.r, s.g);
-        dst[2] = make_float4(s.b, s.depth, s.rcut, 0.0f);
-        br.x0 = (uint16_t)x0; br.y0 = (uint16_t)y0; br.x1 = (uint16_t)x1; br.y1 = (uint16_t)y1;
-        br.depth_bits = __float_as_uint(tz);
-        br.radius = radius | (clamp_bits << kClampShift);
-        radius_out = radius;
-        if (count_with_atomics)  // fallback binning for images with more tiles than an LDS histogram holds
-          for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * tiles_x + x], 1u);
-      }
-    }
-  }
-  reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
-  radii[i] = radius_out;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // K2: exclusive prefix sum of the per-tile counts (one workgroup; T is 7.5k at 1600x1200, <100k at 5400x4050).
 // ---------------------------------------------------------------------------------------------------------
@@ -501,6 +304,7 @@ int validate(const ScorpGs3dInputs *in) {
   }
   if (in->num_gaussians > 0) {
     if (!in->means3D || !in->opacities) { set_error("means3D / opacities is NULL"); return SCORP_ERR_INVALID; }
+    if (in->shs_rest && !in->shs) { set_error("shs_rest given without shs (the degree-0 block)"); return SCORP_ERR_INVALID; }
     if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) {
       set_error("provide exactly one of shs / colors_precomp"); return SCORP_ERR_INVALID;
     }
@@ -545,11 +349,7 @@ extern "C" int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_rad
   if (!L.lds_binning) SCORP_HIP_CHECK(hipMemsetAsync(tile_count, 0, ((size_t)L.tiles + 1) * 4, stream));
   if (N > 0) {
     ProfScope prof(kKPreprocess, stream);
-    preprocess_kernel<<<(N + 255) / 256, 256, 0, stream>>>(
-        N, in->sh_coeffs, in->sh_degree, W, H, in->tanfovx, in->tanfovy, in->scale_modifier, in->viewmatrix,
-        in->projmatrix, in->campos, in->means3D, in->shs, in->colors_precomp, in->opacities, in->scales,
-        in->rotations, in->cov3D_precomp, (SplatRec *)(base + L.rec), (BinRec *)(base + L.bin), out_radii,
-        tile_count, L.tiles_x, L.tiles_y, L.lds_binning ? 0 : 1);
+    launch_preprocess(in, L, (SplatRec *)(base + L.rec), (BinRec *)(base + L.bin), out_radii, tile_count, stream);
     SCORP_KERNEL_CHECK("preprocess", in->debug, stream);
   }
   if (L.lds_binning) {

@@ -1,0 +1,600 @@
+// gs3d_pergaussian.hip — the two per-Gaussian (one thread per splat) kernels of the 3DGS path for gfx950:
+//   preprocess          : project, cull, EWA covariance, conic, tile rectangle, SH -> RGB      (forward)
+//   preprocess_backward : screen-space accumulators -> gradients of the call arguments         (backward)
+// Both are HBM-streaming kernels (236 B in / 68 B out, resp. ~300 B in / 248 B out per splat).  The wide rows
+// (spherical harmonics, 36..192 B per splat) go through LDS so that global accesses are coalesced 16-byte streams
+// whatever the row length: a block stages its 256 rows with stride 49 floats (odd, so the later one-thread-per-row
+// walks are bank-conflict free), and the backward overwrites each row in place with its gradient before streaming
+// it back out.
+//
+// Two argument conventions share the kernels:
+//   * the reference call site (gs3dgs/gaussian_renderer/__init__.py:101-109): activated opacities / scales /
+//     unit quaternions and one shs[N,K,3] tensor;
+//   * "raw" parameters (ScorpGs3dInputs.raw_params / shs_rest): the GaussianModel's own storage — logit opacity,
+//     log scale, un-normalised quaternion, _features_dc[N,1,3] + _features_rest[N,K-1,3] — with the activations of
+//     gs3dgs/scene/gaussian_model.py:126-146 applied in-kernel and differentiated in the backward, which removes the
+//     torch.cat and five elementwise kernels (and their autograd mirrors) from every view.
+// Arithmetic follows oracle/gs3d_oracle.c.  Contraction is off in the forward so discrete decisions round like the
+// oracle.
+#include "common.hpp"
+
+namespace scorp {
+namespace {
+
+constexpr int kShStride = 49;
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct PgArgs {
+  int N, K, W, H, tiles_x, tiles_y, raw, count_with_atomics;
+  float tanfovx, tanfovy, scale_mod;
+  const float *view, *proj, *campos;
+  const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+};
+
+// ---- coalesced staging of the SH rows of one block (rows i0 .. i0+nrows) into LDS, columns [0, NFL) ----
+template <int NFL, bool SPLIT>
+__device__ __forceinline__ void stage_sh_rows(float *__restrict__ lds, const float *__restrict__ shs,
+                                              const float *__restrict__ shs_rest, int K, size_t i0, int nrows) {
+  const int tid = threadIdx.x;
+  if constexpr (!SPLIT) {
+    const int K3 = K * 3;
+    if constexpr (NFL % 4 == 0) {
+      if ((K & 3) == 0) {
+        constexpr int Q = NFL / 4;
+        for (int e = tid; e < nrows * Q; e += 256) {
+          const int r = e / Q, q = e % Q;
+          const float4 v = *reinterpret_cast<const float4 *>(shs + (i0 + r) * K3 + 4 * q);
+          float *d = lds + r * kShStride + 4 * q;
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        return;
+      }
+    }
+    for (int e = tid; e < nrows * NFL; e += 256) {
+      const int r = e / NFL, c = e % NFL;
+      lds[r * kShStride + c] = shs[(i0 + r) * K3 + c];
+    }
+  } else {
+    for (int e = tid; e < nrows * 3; e += 256) {
+      const int r = e / 3, c = e % 3;
+      lds[r * kShStride + c] = shs[(i0 + r) * 3 + c];
+    }
+    if constexpr (NFL > 3) {
+      constexpr int NR = NFL - 3;
+      const int R3 = (K - 1) * 3;
+      if (NR == 45 && R3 == 45 && nrows == 256) {  // whole rows of a full block: one contiguous 16-byte-aligned stream
+        const float4 *src = reinterpret_cast<const float4 *>(shs_rest + i0 * 45);
+        for (int e4 = tid; e4 < 256 * 45 / 4; e4 += 256) {
+          const float4 v = src[e4];
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int f = 4 * e4 + j;
+            lds[(f / 45) * kShStride + 3 + f % 45] = vv[j];
+          }
+        }
+      } else {
+        for (int e = tid; e < nrows * NR; e += 256) {
+          const int r = e / NR, c = e % NR;
+          lds[r * kShStride + 3 + c] = shs_rest[(i0 + r) * R3 + c];
+        }
+      }
+    }
+  }
+}
+
+// ---- the reverse: stream the (gradient) rows back out; columns >= 48 of very wide rows are zero-filled ----
+template <bool SPLIT>
+__device__ __forceinline__ void unstage_sh_rows(const float *__restrict__ lds, float *__restrict__ g_shs,
+                                                float *__restrict__ g_rest, int K, size_t i0, int nrows) {
+  const int tid = threadIdx.x;
+  if constexpr (!SPLIT) {
+    const int K3 = K * 3;
+    if (K == 16) {
+      for (int e = tid; e < nrows * 12; e += 256) {
+        const int r = e / 12, q = e % 12;
+        const float *s = lds + r * kShStride + 4 * q;
+        *reinterpret_cast<float4 *>(g_shs + (i0 + r) * 48 + 4 * q) = make_float4(s[0], s[1], s[2], s[3]);
+      }
+    } else {
+      for (int e = tid; e < nrows * K3; e += 256) {
+        const int r = e / K3, c = e % K3;
+        g_shs[(i0 + r) * K3 + c] = c < 48 ? lds[r * kShStride + c] : 0.0f;
+      }
+    }
+  } else {
+    for (int e = tid; e < nrows * 3; e += 256) {
+      const int r = e / 3, c = e % 3;
+      g_shs[(i0 + r) * 3 + c] = lds[r * kShStride + c];
+    }
+    const int R3 = (K - 1) * 3;
+    if (R3 == 45 && nrows == 256) {
+      float4 *dst = reinterpret_cast<float4 *>(g_rest + i0 * 45);
+      for (int e4 = tid; e4 < 256 * 45 / 4; e4 += 256) {
+        float vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int f = 4 * e4 + j;
+          vv[j] = lds[(f / 45) * kShStride + 3 + f % 45];
+        }
+        dst[e4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
+    } else if (R3 > 0) {
+      for (int e = tid; e < nrows * R3; e += 256) {
+        const int r = e / R3, c = e % R3;
+        g_rest[(i0 + r) * R3 + c] = c < 45 ? lds[r * kShStride + 3 + c] : 0.0f;
+      }
+    }
+  }
+}
+
+// SH -> RGB + 0.5 from a staged row (gs3dgs/utils/sh_utils.py:57-112 restated for [K,3] rows)
+template <int DEG>
+__device__ __forceinline__ void sh_row_to_rgb(const float *__restrict__ sh, float x, float y, float z, float *rgb) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float r = SH_C0 * sh[c];
+    if constexpr (DEG > 0) {
+      r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+      if constexpr (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        r = r + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] + SH_C2[2] * (2 * zz - xx - yy) * sh[18 + c] +
+            SH_C2[3] * xz * sh[21 + c] + SH_C2[4] * (xx - yy) * sh[24 + c];
+        if constexpr (DEG > 2) {
+          r = r + SH_C3[0] * y * (3 * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
+              SH_C3[2] * y * (4 * zz - xx - yy) * sh[33 + c] + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[36 + c] +
+              SH_C3[4] * x * (4 * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
+              SH_C3[6] * x * (xx - 3 * yy) * sh[45 + c];
+        }
+      }
+    }
+    rgb[c] = r + 0.5f;
+  }
+}
+
+// activations of the raw-parameter convention (gaussian_model.py:37-45: sigmoid, exp, F.normalize)
+__device__ __forceinline__ float act_opacity(float v, int raw) { return (raw & 1) ? 1.0f / (1.0f + expf(-v)) : v; }
+__device__ __forceinline__ float act_scale(float v, int raw) { return (raw & 2) ? expf(v) : v; }
+__device__ __forceinline__ float4 act_quat(float4 q, int raw, float *inv_norm) {
+  if (!(raw & 4)) { *inv_norm = 1.0f; return q; }
+  const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  const float inv = 1.0f / fmaxf(n, 1e-12f);
+  *inv_norm = inv;
+  return make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int DEG, bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin, int32_t *__restrict__ radii,
+                  uint32_t *__restrict__ tile_count) {
+#pragma clang fp contract(off)
+  __shared__ float s_sh[256 * kShStride];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool active = i < a.N;
+  float vm[16], pm[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
+  BinRec br;
+  br.x0 = br.y0 = br.x1 = br.y1 = 0; br.depth_bits = 0; br.radius = 0;
+  int radius_out = 0;
+  bool vis = false;
+  float px_ = 0, py_ = 0, pz_ = 0, tz = 0, sx = 0, sy = 0, cA = 0, cB = 0, cC = 0, op = 0, rcut = 0;
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0, radius = 0;
+  if (active) {
+    px_ = a.means3D[3 * (size_t)i]; py_ = a.means3D[3 * (size_t)i + 1]; pz_ = a.means3D[3 * (size_t)i + 2];
+    const float tx = vm[0] * px_ + vm[4] * py_ + vm[8] * pz_ + vm[12];
+    const float ty = vm[1] * px_ + vm[5] * py_ + vm[9] * pz_ + vm[13];
+    tz = __builtin_fmaf(vm[10], pz_, __builtin_fmaf(vm[6], py_, __builtin_fmaf(vm[2], px_, vm[14])));
+    if (tz > kNearZ) {
+      const float hx = pm[0] * px_ + pm[4] * py_ + pm[8] * pz_ + pm[12];
+      const float hy = pm[1] * px_ + pm[5] * py_ + pm[9] * pz_ + pm[13];
+      const float hw = pm[3] * px_ + pm[7] * py_ + pm[11] * pz_ + pm[15];
+      const float pw = 1.0f / (hw + kWEps);
+      const float ndcx = hx * pw, ndcy = hy * pw;
+      float c6[6];
+      if (a.cov3D_precomp) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) c6[q] = a.cov3D_precomp[6 * (size_t)i + q];
+      } else {
+        float invn;
+        const float4 q4 = act_quat(reinterpret_cast<const float4 *>(a.rotations)[i], a.raw, &invn);
+        const float r = q4.x, x = q4.y, y = q4.z, z = q4.w;
+        const float s0 = a.scale_mod * act_scale(a.scales[3 * (size_t)i], a.raw),
+                    s1 = a.scale_mod * act_scale(a.scales[3 * (size_t)i + 1], a.raw),
+                    s2 = a.scale_mod * act_scale(a.scales[3 * (size_t)i + 2], a.raw);
+        float L[9];
+        L[0] = (1 - 2 * (y * y + z * z)) * s0; L[1] = (2 * (x * y - r * z)) * s1;     L[2] = (2 * (x * z + r * y)) * s2;
+        L[3] = (2 * (x * y + r * z)) * s0;     L[4] = (1 - 2 * (x * x + z * z)) * s1; L[5] = (2 * (y * z - r * x)) * s2;
+        L[6] = (2 * (x * z - r * y)) * s0;     L[7] = (2 * (y * z + r * x)) * s1;     L[8] = (1 - 2 * (x * x + y * y)) * s2;
+        c6[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+        c6[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+        c6[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
+        c6[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+        c6[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
+        c6[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+      }
+      const float limx = kFovGuard * a.tanfovx, limy = kFovGuard * a.tanfovy;
+      const float txc = fminf(limx, fmaxf(-limx, tx / tz)) * tz;
+      const float tyc = fminf(limy, fmaxf(-limy, ty / tz)) * tz;
+      const float fx = (float)a.W / (2 * a.tanfovx), fy = (float)a.H / (2 * a.tanfovy);
+      const float J00 = fx / tz, J02 = -(fx * txc) / (tz * tz), J11 = fy / tz, J12 = -(fy * tyc) / (tz * tz);
+      float M0[3], M1[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        M0[c] = J00 * vm[c * 4 + 0] + J02 * vm[c * 4 + 2];
+        M1[c] = J11 * vm[c * 4 + 1] + J12 * vm[c * 4 + 2];
+      }
+      float s0v[3], s1v[3];
+      s0v[0] = c6[0] * M0[0] + c6[1] * M0[1] + c6[2] * M0[2];
+      s0v[1] = c6[1] * M0[0] + c6[3] * M0[1] + c6[4] * M0[2];
+      s0v[2] = c6[2] * M0[0] + c6[4] * M0[1] + c6[5] * M0[2];
+      s1v[0] = c6[0] * M1[0] + c6[1] * M1[1] + c6[2] * M1[2];
+      s1v[1] = c6[1] * M1[0] + c6[3] * M1[1] + c6[4] * M1[2];
+      s1v[2] = c6[2] * M1[0] + c6[4] * M1[1] + c6[5] * M1[2];
+      const float ca = M0[0] * s0v[0] + M0[1] * s0v[1] + M0[2] * s0v[2] + kDilation;
+      const float cb = M0[0] * s1v[0] + M0[1] * s1v[1] + M0[2] * s1v[2];
+      const float cc = M1[0] * s1v[0] + M1[1] * s1v[1] + M1[2] * s1v[2] + kDilation;
+      const float det = ca * cc - cb * cb;
+      if (det != 0.0f) {
+        const float det_inv = 1.0f / det;
+        const float mid = 0.5f * (ca + cc);
+        const float disc = sqrtf(fmaxf(kLambdaFloor, mid * mid - det));
+        const float lam = fmaxf(mid + disc, mid - disc);
+        radius = (int)ceilf(kRadiusSigma * sqrtf(lam));
+        sx = ((ndcx + 1) * a.W - 1) * 0.5f; sy = ((ndcy + 1) * a.H - 1) * 0.5f;
+        x0 = min(a.tiles_x, max(0, (int)((sx - radius) / kTile)));
+        y0 = min(a.tiles_y, max(0, (int)((sy - radius) / kTile)));
+        x1 = min(a.tiles_x, max(0, (int)((sx + radius + kTile - 1) / kTile)));
+        y1 = min(a.tiles_y, max(0, (int)((sy + radius + kTile - 1) / kTile)));
+        if ((x1 - x0) * (y1 - y0) > 0) {
+          vis = true;
+          cA = cc * det_inv; cB = -cb * det_inv; cC = ca * det_inv;
+          op = act_opacity(a.opacities[i], a.raw);
+          // Beyond rcut the splat's alpha is < 1/255 everywhere (|d|^2 / (2 lambda_max) > ln(255 o)), so a pixel
+          // block farther than rcut can skip it without changing a single output bit. 1% + 0.1 px of slack.
+          rcut = 1.01f * sqrtf(2.0f * lam * logf(fmaxf(255.0f * op, 1.0f))) + 0.1f;
+        }
+      }
+    }
+  }
+  float rgb[3] = {0.0f, 0.0f, 0.0f};
+  int clamp_bits = 0;
+  if (a.shs) {
+    if (__syncthreads_or(vis ? 1 : 0)) {  // a block with nothing visible never touches its SH rows
+      constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
+      const size_t i0 = (size_t)blockIdx.x * 256;
+      stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, min(256, a.N - (int)i0));
+      __syncthreads();
+      if (vis) {
+        const float dx = px_ - a.campos[0], dy = py_ - a.campos[1], dz = pz_ - a.campos[2];
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        sh_row_to_rgb<DEG>(s_sh + threadIdx.x * kShStride, dx * inv, dy * inv, dz * inv, rgb);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          if (rgb[q] < 0.0f) clamp_bits |= 1 << q;  // remembered for the backward (zero gradient where clamped)
+          rgb[q] = fmaxf(rgb[q], 0.0f);
+        }
+      }
+    }
+  } else if (vis) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) rgb[q] = a.colors_precomp[3 * (size_t)i + q];
+  }
+  if (!active) return;
+  if (vis) {
+    float4 *dst = reinterpret_cast<float4 *>(rec + i);
+    dst[0] = make_float4(sx, sy, cA, cB);
+    dst[1] = make_float4(cC, op, rgb[0], rgb[1]);
+    dst[2] = make_float4(rgb[2], tz, rcut, 0.0f);
+    br.x0 = (uint16_t)x0; br.y0 = (uint16_t)y0; br.x1 = (uint16_t)x1; br.y1 = (uint16_t)y1;
+    br.depth_bits = __float_as_uint(tz);
+    br.radius = radius | (clamp_bits << kClampShift);
+    radius_out = radius;
+    if (a.count_with_atomics)  // fallback binning for images with more tiles than an LDS histogram holds
+      for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * a.tiles_x + x], 1u);
+  }
+  reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
+  radii[i] = radius_out;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int DEG, bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float *__restrict__ acc,
+                           ScorpGs3dGrads g) {
+  __shared__ float s_sh[256 * kShStride];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool active = i < a.N;
+  const size_t i0 = (size_t)blockIdx.x * 256;
+  const int nrows = min(256, a.N - (int)i0);
+  constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
+  const int32_t rad_bits = active ? bin[i].radius : 0;
+  const bool visible = (rad_bits & kRadiusMask) != 0;
+  const bool want_sh_grad = a.shs != nullptr && g.shs != nullptr;
+  bool staged = false;
+  if (a.shs) {
+    if (__syncthreads_or(visible ? 1 : 0)) {
+      stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows);
+      staged = true;
+    }
+    __syncthreads();
+  }
+  float vm[16], pm[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
+  float gm[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gc6[6] = {0, 0, 0, 0, 0, 0};
+  float a_[kAccStride];
+#pragma unroll
+  for (int q = 0; q < kAccStride; q++) a_[q] = 0.0f;
+  float g_op = 0.0f;
+  float *row = s_sh + threadIdx.x * kShStride;
+  if (visible) {
+    const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAccStride);
+    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+    a_[0] = a0.x; a_[1] = a0.y; a_[2] = a0.z; a_[3] = a0.w; a_[4] = a1.x; a_[5] = a1.y; a_[6] = a1.z; a_[7] = a1.w;
+    a_[8] = a2.x; a_[9] = a2.y;
+    const float p0 = a.means3D[3 * (size_t)i], p1 = a.means3D[3 * (size_t)i + 1], p2 = a.means3D[3 * (size_t)i + 2];
+    const float tx = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
+    const float ty = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
+    const float tz = __builtin_fmaf(vm[10], p2, __builtin_fmaf(vm[6], p1, __builtin_fmaf(vm[2], p0, vm[14])));
+    float c6[6];
+    float R[9], sm[3] = {0, 0, 0}, sact[3] = {0, 0, 0}, inv_qn = 1.0f;
+    float4 qn = make_float4(1, 0, 0, 0);
+    if (a.cov3D_precomp) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) c6[q] = a.cov3D_precomp[6 * (size_t)i + q];
+    } else {
+      qn = act_quat(reinterpret_cast<const float4 *>(a.rotations)[i], a.raw, &inv_qn);
+      const float r = qn.x, x = qn.y, y = qn.z, z = qn.w;
+      R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - r * z);     R[2] = 2 * (x * z + r * y);
+      R[3] = 2 * (x * y + r * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - r * x);
+      R[6] = 2 * (x * z - r * y);     R[7] = 2 * (y * z + r * x);     R[8] = 1 - 2 * (x * x + y * y);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { sact[k] = act_scale(a.scales[3 * (size_t)i + k], a.raw); sm[k] = a.scale_mod * sact[k]; }
+      float L[9];
+#pragma unroll
+      for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) L[r_ * 3 + k] = R[r_ * 3 + k] * sm[k];
+      c6[0] = L[0] * L[0] + L[1] * L[1] + L[2] * L[2];
+      c6[1] = L[0] * L[3] + L[1] * L[4] + L[2] * L[5];
+      c6[2] = L[0] * L[6] + L[1] * L[7] + L[2] * L[8];
+      c6[3] = L[3] * L[3] + L[4] * L[4] + L[5] * L[5];
+      c6[4] = L[3] * L[6] + L[4] * L[7] + L[5] * L[8];
+      c6[5] = L[6] * L[6] + L[7] * L[7] + L[8] * L[8];
+    }
+    const float limx = kFovGuard * a.tanfovx, limy = kFovGuard * a.tanfovy;
+    const float txtz = tx / tz, tytz = ty / tz;
+    const bool clamp_x = (txtz < -limx) || (txtz > limx), clamp_y = (tytz < -limy) || (tytz > limy);
+    const float txc = fminf(limx, fmaxf(-limx, txtz)) * tz, tyc = fminf(limy, fmaxf(-limy, tytz)) * tz;
+    const float fx = (float)a.W / (2 * a.tanfovx), fy = (float)a.H / (2 * a.tanfovy);
+    const float J00 = fx / tz, J02 = -(fx * txc) / (tz * tz), J11 = fy / tz, J12 = -(fy * tyc) / (tz * tz);
+    float M0[3], M1[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      M0[c] = J00 * vm[c * 4 + 0] + J02 * vm[c * 4 + 2];
+      M1[c] = J11 * vm[c * 4 + 1] + J12 * vm[c * 4 + 2];
+    }
+    float s0[3], s1[3];
+    s0[0] = c6[0] * M0[0] + c6[1] * M0[1] + c6[2] * M0[2];
+    s0[1] = c6[1] * M0[0] + c6[3] * M0[1] + c6[4] * M0[2];
+    s0[2] = c6[2] * M0[0] + c6[4] * M0[1] + c6[5] * M0[2];
+    s1[0] = c6[0] * M1[0] + c6[1] * M1[1] + c6[2] * M1[2];
+    s1[1] = c6[1] * M1[0] + c6[3] * M1[1] + c6[4] * M1[2];
+    s1[2] = c6[2] * M1[0] + c6[4] * M1[1] + c6[5] * M1[2];
+    const float ca = M0[0] * s0[0] + M0[1] * s0[1] + M0[2] * s0[2] + kDilation;
+    const float cb = M0[0] * s1[0] + M0[1] * s1[1] + M0[2] * s1[2];
+    const float cc = M1[0] * s1[0] + M1[1] * s1[1] + M1[2] * s1[2] + kDilation;
+    const float det = ca * cc - cb * cb, d2 = 1.0f / (det * det + kDet2Eps);
+    const float gA = a_[2], gB = a_[3], gC = a_[4];
+    const float ga = d2 * (-cc * cc * gA + cb * cc * gB - cb * cb * gC);
+    const float gc = d2 * (-cb * cb * gA + ca * cb * gB - ca * ca * gC);
+    const float gb = d2 * (2 * cb * cc * gA - (ca * cc + cb * cb) * gB + 2 * ca * cb * gC);
+    const float h = 0.5f * gb;
+    float F[9];
+#pragma unroll
+    for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        F[r_ * 3 + q] = ga * M0[r_] * M0[q] + h * (M0[r_] * M1[q] + M1[r_] * M0[q]) + gc * M1[r_] * M1[q];
+    gc6[0] = F[0]; gc6[1] = 2 * F[1]; gc6[2] = 2 * F[2]; gc6[3] = F[4]; gc6[4] = 2 * F[5]; gc6[5] = F[8];
+    float gM0[3], gM1[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      gM0[q] = 2 * (ga * s0[q] + h * s1[q]);
+      gM1[q] = 2 * (h * s0[q] + gc * s1[q]);
+    }
+    float gJ00 = 0, gJ02 = 0, gJ11 = 0, gJ12 = 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      gJ00 += gM0[q] * vm[q * 4 + 0]; gJ02 += gM0[q] * vm[q * 4 + 2];
+      gJ11 += gM1[q] * vm[q * 4 + 1]; gJ12 += gM1[q] * vm[q * 4 + 2];
+    }
+    const float tz2 = 1.0f / (tz * tz), tz3 = tz2 / tz;
+    float gt[3];
+    gt[0] = clamp_x ? 0.0f : -fx * tz2 * gJ02;
+    gt[1] = clamp_y ? 0.0f : -fy * tz2 * gJ12;
+    gt[2] = -fx * tz2 * gJ00 - fy * tz2 * gJ11 + 2 * fx * txc * tz3 * gJ02 + 2 * fy * tyc * tz3 * gJ12;
+    gt[2] += a_[9];
+#pragma unroll
+    for (int q = 0; q < 3; q++) gm[q] += vm[q * 4 + 0] * gt[0] + vm[q * 4 + 1] * gt[1] + vm[q * 4 + 2] * gt[2];
+    const float hx = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
+    const float hy = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
+    const float hw = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
+    const float pw = 1.0f / (hw + kWEps);
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      gm[q] += (pm[q * 4 + 0] * pw - pm[q * 4 + 3] * hx * pw * pw) * a_[0] +
+               (pm[q * 4 + 1] * pw - pm[q * 4 + 3] * hy * pw * pw) * a_[1];
+    g_op = a_[5];
+    if (a.raw & 1) {
+      const float o = act_opacity(a.opacities[i], a.raw);
+      g_op *= o * (1.0f - o);
+    }
+    if (a.shs) {
+      const float d0 = p0 - a.campos[0], d1 = p1 - a.campos[1], d2_ = p2 - a.campos[2];
+      const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2_ * d2_);
+      const float x = d0 * inv, y = d1 * inv, z = d2_ * inv;
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      float basis[16];
+      basis[0] = SH_C0;
+      if constexpr (DEG > 0) { basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x; }
+      if constexpr (DEG > 1) {
+        basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz; basis[6] = SH_C2[2] * (2 * zz - xx - yy);
+        basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
+      }
+      if constexpr (DEG > 2) {
+        basis[9] = SH_C3[0] * y * (3 * xx - yy); basis[10] = SH_C3[1] * xy * z;
+        basis[11] = SH_C3[2] * y * (4 * zz - xx - yy); basis[12] = SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy);
+        basis[13] = SH_C3[4] * x * (4 * zz - xx - yy); basis[14] = SH_C3[5] * z * (xx - yy);
+        basis[15] = SH_C3[6] * x * (xx - 3 * yy);
+      }
+      float gdir[3] = {0, 0, 0};
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) {
+        const float gr = ((rad_bits >> (kClampShift + ch)) & 1) ? 0.0f : a_[6 + ch];
+        float rx = 0, ry = 0, rz = 0;
+        if constexpr (DEG > 0) {
+          const float s1_ = row[3 + ch], s2_ = row[6 + ch], s3_ = row[9 + ch];
+          rx = -SH_C1 * s3_; ry = -SH_C1 * s1_; rz = SH_C1 * s2_;
+        }
+        if constexpr (DEG > 1) {
+          const float s4 = row[12 + ch], s5 = row[15 + ch], s6 = row[18 + ch], s7 = row[21 + ch], s8 = row[24 + ch];
+          rx += SH_C2[0] * y * s4 + SH_C2[2] * 2 * -x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2 * x * s8;
+          ry += SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * 2 * -y * s6 + SH_C2[4] * 2 * -y * s8;
+          rz += SH_C2[1] * y * s5 + SH_C2[2] * 4 * z * s6 + SH_C2[3] * x * s7;
+        }
+        if constexpr (DEG > 2) {
+          const float s9 = row[27 + ch], s10 = row[30 + ch], s11 = row[33 + ch], s12 = row[36 + ch], s13 = row[39 + ch],
+                      s14 = row[42 + ch], s15 = row[45 + ch];
+          rx += SH_C3[0] * s9 * 6 * xy + SH_C3[1] * s10 * yz + SH_C3[2] * s11 * -2 * xy + SH_C3[3] * s12 * -6 * xz +
+                SH_C3[4] * s13 * (-3 * xx + 4 * zz - yy) + SH_C3[5] * s14 * 2 * xz + SH_C3[6] * s15 * 3 * (xx - yy);
+          ry += SH_C3[0] * s9 * 3 * (xx - yy) + SH_C3[1] * s10 * xz + SH_C3[2] * s11 * (-3 * yy + 4 * zz - xx) +
+                SH_C3[3] * s12 * -6 * yz + SH_C3[4] * s13 * -2 * xy + SH_C3[5] * s14 * -2 * yz + SH_C3[6] * s15 * -6 * xy;
+          rz += SH_C3[1] * s10 * xy + SH_C3[2] * s11 * 8 * yz + SH_C3[3] * s12 * 3 * (2 * zz - xx - yy) +
+                SH_C3[4] * s13 * 8 * xz + SH_C3[5] * s14 * (xx - yy);
+        }
+        gdir[0] += rx * gr; gdir[1] += ry * gr; gdir[2] += rz * gr;
+        // the coefficients of this channel are consumed: overwrite them in place with their gradients
+        if (want_sh_grad) {
+#pragma unroll
+          for (int k = 0; k < 16; k++) row[3 * k + ch] = k < (DEG + 1) * (DEG + 1) ? basis[k] * gr : 0.0f;
+        }
+      }
+      const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
+      gm[0] += (gdir[0] - x * dot) * inv; gm[1] += (gdir[1] - y * dot) * inv; gm[2] += (gdir[2] - z * dot) * inv;
+    }
+    if (!a.cov3D_precomp) {
+      const float r = qn.x, x = qn.y, y = qn.z, z = qn.w;
+      const float Gs[9] = {gc6[0], 0.5f * gc6[1], 0.5f * gc6[2], 0.5f * gc6[1], gc6[3], 0.5f * gc6[4],
+                           0.5f * gc6[2], 0.5f * gc6[4], gc6[5]};
+      float gL[9], gR[9];
+#pragma unroll
+      for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          float s = 0;
+#pragma unroll
+          for (int m = 0; m < 3; m++) s += Gs[r_ * 3 + m] * R[m * 3 + k] * sm[k];
+          gL[r_ * 3 + k] = 2 * s;
+        }
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        gs[k] = a.scale_mod * (R[k] * gL[k] + R[3 + k] * gL[3 + k] + R[6 + k] * gL[6 + k]);
+        if (a.raw & 2) gs[k] *= sact[k];  // d exp(v) / dv
+#pragma unroll
+        for (int r_ = 0; r_ < 3; r_++) gR[r_ * 3 + k] = gL[r_ * 3 + k] * sm[k];
+      }
+      gq[0] = 2 * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
+      gq[1] = 2 * (y * gR[1] + z * gR[2] + y * gR[3] - 2 * x * gR[4] - r * gR[5] + z * gR[6] + r * gR[7] - 2 * x * gR[8]);
+      gq[2] = 2 * (-2 * y * gR[0] + x * gR[1] + r * gR[2] + x * gR[3] + z * gR[5] - r * gR[6] + z * gR[7] - 2 * y * gR[8]);
+      gq[3] = 2 * (-2 * z * gR[0] - r * gR[1] + x * gR[2] + r * gR[3] - 2 * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
+      if (a.raw & 4) {  // through q / |q|
+        const float dotq = r * gq[0] + x * gq[1] + y * gq[2] + z * gq[3];
+        gq[0] = (gq[0] - r * dotq) * inv_qn; gq[1] = (gq[1] - x * dotq) * inv_qn;
+        gq[2] = (gq[2] - y * dotq) * inv_qn; gq[3] = (gq[3] - z * dotq) * inv_qn;
+      }
+    }
+  } else if (want_sh_grad && active) {
+#pragma unroll
+    for (int c = 0; c < 48; c++) row[c] = 0.0f;
+  }
+  if (active) {
+    if (g.means3D) { g.means3D[3 * (size_t)i] = gm[0]; g.means3D[3 * (size_t)i + 1] = gm[1]; g.means3D[3 * (size_t)i + 2] = gm[2]; }
+    if (g.means2D) { g.means2D[3 * (size_t)i] = a_[0]; g.means2D[3 * (size_t)i + 1] = a_[1]; g.means2D[3 * (size_t)i + 2] = 0.0f; }
+    if (g.colors_precomp) { g.colors_precomp[3 * (size_t)i] = a_[6]; g.colors_precomp[3 * (size_t)i + 1] = a_[7]; g.colors_precomp[3 * (size_t)i + 2] = a_[8]; }
+    if (g.opacities) g.opacities[i] = g_op;
+    if (g.scales) { g.scales[3 * (size_t)i] = gs[0]; g.scales[3 * (size_t)i + 1] = gs[1]; g.scales[3 * (size_t)i + 2] = gs[2]; }
+    if (g.rotations) reinterpret_cast<float4 *>(g.rotations)[i] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+    if (g.cov3D_precomp) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) g.cov3D_precomp[6 * (size_t)i + q] = gc6[q];
+    }
+  }
+  if (want_sh_grad) {
+    if (!staged && active) {  // nothing visible in this block: rows were never staged, they are all zero
+#pragma unroll
+      for (int c = 0; c < 48; c++) row[c] = 0.0f;
+    }
+    __syncthreads();
+    unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
+  }
+}
+
+PgArgs make_args(const ScorpGs3dInputs *in, const StateLayout &L) {
+  PgArgs a;
+  a.N = in->num_gaussians; a.K = in->sh_coeffs; a.W = in->image_width; a.H = in->image_height;
+  a.tiles_x = L.tiles_x; a.tiles_y = L.tiles_y; a.raw = in->raw_params; a.count_with_atomics = L.lds_binning ? 0 : 1;
+  a.tanfovx = in->tanfovx; a.tanfovy = in->tanfovy; a.scale_mod = in->scale_modifier;
+  a.view = in->viewmatrix; a.proj = in->projmatrix; a.campos = in->campos;
+  a.means3D = in->means3D; a.shs = in->shs; a.shs_rest = in->shs_rest; a.colors_precomp = in->colors_precomp;
+  a.opacities = in->opacities; a.scales = in->scales; a.rotations = in->rotations; a.cov3D_precomp = in->cov3D_precomp;
+  return a;
+}
+
+}  // namespace
+
+void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec *rec, BinRec *bin, int32_t *radii,
+                       uint32_t *tile_count, hipStream_t stream) {
+  const PgArgs a = make_args(in, L);
+  const dim3 grid((a.N + 255) / 256), block(256);
+  const int deg = in->shs ? in->sh_degree : 0;
+  const bool split = in->shs_rest != nullptr;
+#define SCORP_LAUNCH_PRE(D, S) preprocess_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, radii, tile_count)
+  if (split) {
+    switch (deg) { case 0: SCORP_LAUNCH_PRE(0, true); break; case 1: SCORP_LAUNCH_PRE(1, true); break;
+                   case 2: SCORP_LAUNCH_PRE(2, true); break; default: SCORP_LAUNCH_PRE(3, true); }
+  } else {
+    switch (deg) { case 0: SCORP_LAUNCH_PRE(0, false); break; case 1: SCORP_LAUNCH_PRE(1, false); break;
+                   case 2: SCORP_LAUNCH_PRE(2, false); break; default: SCORP_LAUNCH_PRE(3, false); }
+  }
+#undef SCORP_LAUNCH_PRE
+}
+
+void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L, const BinRec *bin, const float *acc,
+                                const ScorpGs3dGrads *grads, hipStream_t stream) {
+  const PgArgs a = make_args(in, L);
+  const dim3 grid((a.N + 255) / 256), block(256);
+  const int deg = in->shs ? in->sh_degree : 0;
+  const bool split = in->shs_rest != nullptr;
+  const ScorpGs3dGrads g = *grads;
+#define SCORP_LAUNCH_PB(D, S) preprocess_backward_kernel<D, S><<<grid, block, 0, stream>>>(a, bin, acc, g)
+  if (split) {
+    switch (deg) { case 0: SCORP_LAUNCH_PB(0, true); break; case 1: SCORP_LAUNCH_PB(1, true); break;
+                   case 2: SCORP_LAUNCH_PB(2, true); break; default: SCORP_LAUNCH_PB(3, true); }
+  } else {
+    switch (deg) { case 0: SCORP_LAUNCH_PB(0, false); break; case 1: SCORP_LAUNCH_PB(1, false); break;
+                   case 2: SCORP_LAUNCH_PB(2, false); break; default: SCORP_LAUNCH_PB(3, false); }
+  }
+#undef SCORP_LAUNCH_PB
+}
+
+}  // namespace scorp

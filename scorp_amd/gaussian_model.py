@@ -161,6 +161,10 @@ class GaussianModel:
         L = build_scaling_rotation(scaling_modifier * self.get_scaling, self._rotation)
         return strip_symmetric(L @ L.transpose(1, 2))
 
+    def raw_leaves(self):
+        """(_features_dc, _features_rest, _opacity, _scaling, _rotation) for the fused-activation render path."""
+        return self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation
+
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1

@@ -86,7 +86,7 @@ def _prep(t, name, shape_tail=None):
     return t.contiguous()
 
 
-def _inputs_struct(s, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D, keep):
+def _inputs_struct(s, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D, keep, sh_rest=None, raw=0):
     """Fill the C struct; `keep` collects tensors that must outlive the call."""
     bg, vm, pm, cp = (_prep(s.bg, "bg"), _prep(s.viewmatrix, "viewmatrix"), _prep(s.projmatrix, "projmatrix"),
                       _prep(s.campos, "campos"))
@@ -94,7 +94,9 @@ def _inputs_struct(s, means3D, sh, colors_precomp, opacities, scales, rotations,
     a = _C.ScorpGs3dInputs()
     a.num_gaussians = means3D.shape[0]
     a.sh_degree = int(s.sh_degree)
-    a.sh_coeffs = 0 if sh is None else sh.shape[1]
+    a.sh_coeffs = 0 if sh is None else (sh.shape[1] if sh_rest is None else 1 + sh_rest.shape[1])
+    a.shs_rest = None if sh_rest is None else sh_rest.data_ptr()
+    a.raw_params = int(raw)
     a.image_width, a.image_height = int(s.image_width), int(s.image_height)
     a.tanfovx, a.tanfovy, a.scale_modifier = float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier)
     a.prefiltered, a.debug = int(bool(s.prefiltered)), int(bool(s.debug))
@@ -112,38 +114,12 @@ def _inputs_struct(s, means3D, sh, colors_precomp, opacities, scales, rotations,
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
-        L = _C.lib()
         dev = means3D.device
         means3D, sh, colors_precomp = _prep(means3D, "means3D"), _prep(sh, "shs"), _prep(colors_precomp, "colors_precomp")
         opacities, scales, rotations = _prep(opacities, "opacities"), _prep(scales, "scales"), _prep(rotations, "rotations")
         cov3Ds_precomp = _prep(cov3Ds_precomp, "cov3D_precomp")
-        N, H, W = means3D.shape[0], int(settings.image_height), int(settings.image_width)
-        keep = []
-        args = _inputs_struct(settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, keep)
-        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-        alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-        radii = torch.empty((N,), dtype=torch.int32, device=dev)
-        state_bytes = L.scorp_gs3d_state_bytes(N, W, H)
-        state = torch.empty(state_bytes, dtype=torch.uint8, device=dev)
-        stream = _stream()
-        _C.check(L.scorp_gs3d_preprocess(ctypes.byref(args), _ptr(radii), _ptr(state), state_bytes, stream), "scorp_gs3d_preprocess")
-        if PairPolicy.mode == "exact":
-            n = ctypes.c_uint64(0)
-            _C.check(L.scorp_gs3d_num_pairs(_ptr(state), stream, ctypes.byref(n)), "scorp_gs3d_num_pairs")
-            capacity = max(int(n.value), 1)
-            LAST_NUM_PAIRS_LOG.append(int(n.value))
-            del LAST_NUM_PAIRS_LOG[:-64]
-        else:
-            if PairPolicy.reserve <= 0:
-                PairPolicy.reserve = max(4 * N, 1 << 20)
-            capacity = PairPolicy.reserve
-            PairPolicy._pending.append(state)
-        pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
-        _C.check(L.scorp_gs3d_render(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(depth),
-                                     _ptr(alpha), stream), "scorp_gs3d_render")
-        ctx.settings = settings
-        ctx.capacity = capacity
+        color, radii, depth, alpha, state, pairs, keep = _forward_common(
+            ctx, settings, means3D, sh, None, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raw=0)
         ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         none = torch.empty(0, device=dev)
         ctx.save_for_backward(means3D, none if sh is None else sh, none if colors_precomp is None else colors_precomp,
@@ -187,6 +163,90 @@ class _RasterizeGaussians(torch.autograd.Function):
                                        _ptr(ga), ctypes.byref(grads), _ptr(scratch), scratch_bytes, _stream()),
                  "scorp_gs3d_backward")
         return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None
+
+
+def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opacities, scales, rotations, cov3D, raw):
+    """Shared by the two autograd Functions: allocate outputs + workspaces, run preprocess / render."""
+    L = _C.lib()
+    dev = means3D.device
+    N, H, W = means3D.shape[0], int(settings.image_height), int(settings.image_width)
+    keep = []
+    args = _inputs_struct(settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D, keep, sh_rest, raw)
+    color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((N,), dtype=torch.int32, device=dev)
+    state_bytes = L.scorp_gs3d_state_bytes(N, W, H)
+    state = torch.empty(state_bytes, dtype=torch.uint8, device=dev)
+    stream = _stream()
+    _C.check(L.scorp_gs3d_preprocess(ctypes.byref(args), _ptr(radii), _ptr(state), state_bytes, stream), "scorp_gs3d_preprocess")
+    if PairPolicy.mode == "exact":
+        n = ctypes.c_uint64(0)
+        _C.check(L.scorp_gs3d_num_pairs(_ptr(state), stream, ctypes.byref(n)), "scorp_gs3d_num_pairs")
+        capacity = max(int(n.value), 1)
+        LAST_NUM_PAIRS_LOG.append(int(n.value))
+        del LAST_NUM_PAIRS_LOG[:-64]
+    else:
+        if PairPolicy.reserve <= 0:
+            PairPolicy.reserve = max(4 * N, 1 << 20)
+        capacity = PairPolicy.reserve
+        PairPolicy._pending.append(state)
+    pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
+    _C.check(L.scorp_gs3d_render(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(depth),
+                                 _ptr(alpha), stream), "scorp_gs3d_render")
+    ctx.settings, ctx.capacity = settings, capacity
+    return color, radii, depth, alpha, state, pairs, keep
+
+
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """Same rasterizer on the GaussianModel's RAW storage (logit opacity, log scale, un-normalised quaternion,
+    _features_dc / _features_rest kept apart): the activations of gaussian_model.py:126-146 and the SH concat run
+    inside the per-Gaussian kernels, and the gradients come back w.r.t. the raw leaves."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, settings):
+        means3D, f_dc, f_rest = _prep(means3D, "means3D"), _prep(f_dc, "features_dc"), _prep(f_rest, "features_rest")
+        opacity_raw, scaling_raw, rotation_raw = _prep(opacity_raw, "opacity"), _prep(scaling_raw, "scaling"), _prep(rotation_raw, "rotation")
+        color, radii, depth, alpha, state, pairs, keep = _forward_common(
+            ctx, settings, means3D, f_dc, f_rest, None, opacity_raw, scaling_raw, rotation_raw, None, raw=7)
+        ctx.save_for_backward(means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, state, pairs, *keep)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        L = _C.lib()
+        means3D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, state, pairs, bg, vm, pm, cp = ctx.saved_tensors
+        s = ctx.settings._replace(bg=bg, viewmatrix=vm, projmatrix=pm, campos=cp)
+        keep = []
+        args = _inputs_struct(s, means3D, f_dc, None, opacity_raw, scaling_raw, rotation_raw, None, keep, f_rest, 7)
+        N, dev = means3D.shape[0], means3D.device
+        need = ctx.needs_input_grad
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        g_means3D = new(N, 3) if need[0] else None
+        g_means2D = new(N, 3) if need[1] else None
+        want_sh = need[2] or need[3]
+        g_dc = torch.empty_like(f_dc) if want_sh else None
+        g_rest = torch.empty_like(f_rest) if want_sh else None
+        g_op = torch.empty_like(opacity_raw) if need[4] else None
+        g_sc = new(N, 3) if need[5] else None
+        g_rot = new(N, 4) if need[6] else None
+        grads = _C.ScorpGs3dGrads()
+        grads.means3D, grads.means2D, grads.shs, grads.shs_rest = _ptr(g_means3D), _ptr(g_means2D), _ptr(g_dc), _ptr(g_rest)
+        grads.opacities, grads.scales, grads.rotations = _ptr(g_op), _ptr(g_sc), _ptr(g_rot)
+        gc = _prep(grad_color, "grad_color")
+        gd = _prep(grad_depth, "grad_depth") if grad_depth is not None else None
+        ga = _prep(grad_alpha, "grad_alpha") if grad_alpha is not None else None
+        scratch_bytes = L.scorp_gs3d_backward_scratch_bytes(N)
+        scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+        _C.check(L.scorp_gs3d_backward(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(gd),
+                                       _ptr(ga), ctypes.byref(grads), _ptr(scratch), scratch_bytes, _stream()),
+                 "scorp_gs3d_backward")
+        return (g_means3D, g_means2D, g_dc if need[2] else None, g_rest if need[3] else None, g_op, g_sc, g_rot, None)
+
+
+def rasterize_gaussians_raw(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings):
+    return _RasterizeGaussiansRaw.apply(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):

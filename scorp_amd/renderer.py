@@ -8,7 +8,7 @@ import math
 
 import torch
 
-from .rasterizer3d import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer3d import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
 from .sh import eval_sh
 
 
@@ -28,6 +28,17 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    # Fast path of the build's own harnesses: hand the model's raw leaves to the kernels (activations + SH concat fused
+    # in). Same numbers as the branch below; taken only when no python-side colour / covariance branch is requested.
+    if (override_color is None and getattr(pipe, "fused_activations", False) and hasattr(pc, "raw_leaves")
+            and not getattr(pipe, "compute_cov3D_python", False) and not getattr(pipe, "convert_SHs_python", False)):
+        f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw = pc.raw_leaves()
+        rendered_image, radii, rendered_depth, rendered_alpha = rasterize_gaussians_raw(
+            xyz, screenspace_points, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings)
+        rendered_depth = torch.nan_to_num(rendered_depth / rendered_alpha, 0, 0)
+        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                "radii": radii, "render_depth": rendered_depth, "render_alpha": rendered_alpha}
 
     means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
     scales = rotations = cov3D_precomp = None

@@ -47,8 +47,8 @@ def test_binding_lists_every_declared_symbol(built_lib):
 
 def test_struct_layout_matches_header():
     from scorp_amd import _C
-    assert ctypes.sizeof(_C.ScorpGs3dInputs) == 40 + 11 * 8
-    assert ctypes.sizeof(_C.ScorpGs3dGrads) == 8 * 8
+    assert ctypes.sizeof(_C.ScorpGs3dInputs) == 40 + 12 * 8 + 8   # 10 ints/floats, 12 pointers, raw_params + padding
+    assert ctypes.sizeof(_C.ScorpGs3dGrads) == 9 * 8
 
 
 def test_shim_packages_expose_reference_names(built_lib):

@@ -319,3 +319,43 @@ def test_full_size_properties(dev):
     seg_start = np.zeros(r["n"], bool); seg_start[ts[:-1][ts[:-1] < r["n"]]] = True
     nondecr = (d[1:] > d[:-1]) | ((d[1:] == d[:-1]) & (pl[1:] > pl[:-1])) | seg_start[1:]
     assert nondecr.all()
+
+
+@pytest.mark.parametrize("deg,maxdeg", [(3, 3), (1, 3), (0, 3), (2, 2), (0, 0)])
+def test_fused_activation_path_matches_reference_convention(deg, maxdeg, dev):
+    """render() with the model's raw leaves (sigmoid / exp / normalise / SH concat inside the kernels) gives the same
+    image and the same gradients on the raw leaves as the reference convention (torch activations + torch.cat)."""
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.renderer import render
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+
+    class Pipe:
+        convert_SHs_python = False
+        compute_cov3D_python = False
+        debug = False
+        fused_activations = False
+
+    raw = make_gaussians(5000 + 37, maxdeg, 31 + deg, log_scale_mean=math.log(0.04))   # not a multiple of 256
+    cam = ring_cameras(3, 150, 110, 5, device=dev)[2]
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    wc = torch.randn(3, 110, 150, device=dev, generator=g)
+    wd = torch.randn(1, 110, 150, device=dev, generator=g)
+    res = []
+    for fused in (False, True):
+        pc = GaussianModel.from_raw(raw, maxdeg, device=dev)
+        pc.active_sh_degree = deg
+        Pipe.fused_activations = fused
+        r = render(cam, pc, Pipe(), bg)
+        ((r["render"] * wc).sum() + (r["render_alpha"] * wd).sum()).backward()
+        res.append((r, pc))
+    (r0, p0), (r1, p1) = res
+    assert torch.equal(r0["radii"], r1["radii"])
+    assert (r0["render"] - r1["render"]).abs().max() < 2e-5
+    assert (r0["render_depth"] - r1["render_depth"]).abs().max() < 1e-3
+    for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        a, b = getattr(p0, name).grad, getattr(p1, name).grad
+        assert a.shape == b.shape
+        if a.numel():
+            assert (a - b).abs().max() <= 2e-3 * a.abs().max() + 1e-12, name
+    assert (r0["viewspace_points"].grad - r1["viewspace_points"].grad).abs().max() <= 2e-3 * r0["viewspace_points"].grad.abs().max()
