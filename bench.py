@@ -57,6 +57,8 @@ def kernel_algorithmic_bytes(name, N, Nvis, K, HW, D):
 
 def cpu_baseline(raw, cam, deg, W, H):
     """The CPU oracle (OpenMP C restatement) on ONE view of the same workload, forward + backward."""
+    cores = len(os.sched_getaffinity(0))
+    os.environ["OMP_NUM_THREADS"] = str(cores)     # read by libgomp when the oracle library is first loaded
     from oracle import gs_oracle
     from oracle.gs_oracle import OracleRender
     from scorp_amd.synthetic import activate
@@ -73,8 +75,9 @@ def cpu_baseline(raw, cam, deg, W, H):
     o.backward(w, None, None)
     dt = time.perf_counter() - t0
     gs_oracle.set_parallel_backward(False)
-    return dict(value=1.0 / dt, unit="views/s", cores=os.cpu_count(), kind="port",
-                sample=f"1 view of the same workload (render fwd+bwd, no loss), {dt:.2f} s, OpenMP over {os.cpu_count()} host threads"), o
+    return dict(value=1.0 / dt, unit="views/s", cores=cores, kind="port",
+                sample=f"1 view of the same workload (render fwd+bwd, no loss), {dt:.2f} s, OpenMP over {cores} host threads "
+                       f"(os.cpu_count()={os.cpu_count()})"), o
 
 
 def small_parity(dev):
@@ -222,8 +225,12 @@ def main():
                     kernels[name] = dict(avg_us=round(avg_ms * 1e3, 2), launches=cnt, alg_MB=round(b / 1e6, 2),
                                          GBs=round(b / (avg_ms * 1e-3) / 1e9, 1))
             dom = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches"])
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch (see profiles/README.md)
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(args.scene, {}).get(dom)
             roof = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(kernels[dom]["GBs"] / HBM_PEAK_GBS, 5), traffic=None,
+                        frac=round(kernels[dom]["GBs"] / HBM_PEAK_GBS, 5), traffic=traffic,
                         avg_launch_us=kernels[dom]["avg_us"], algorithmic_bytes=int(kernel_algorithmic_bytes(dom, N, Nvis_mean, K, HW, D_mean)),
                         note="blend kernels are bound by pixel-splat evaluation rate, not HBM; see DESIGN.md")
         B_view = N * 720 + HW * 40 + 28 * D_mean
