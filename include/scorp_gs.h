@@ -149,6 +149,28 @@ int scorp_loss_l1_ssim_backward(const float *img, const float *gt, const float *
                                 int32_t width, float lambda_dssim, const void *workspace, const float *grad_out,
                                 float *grad_img, scorp_stream_t stream);
 
+/* ---- simple_knn replacement ----
+ * out[i] = mean of the squared distances from point i to its 3 nearest other points, as
+ * `simple_knn._C.distCUDA2(points)` (gs3dgs/scene/gaussian_model.py:177).  xyz[N,3], out[N]. */
+int scorp_knn_dist2(const float *xyz, int32_t num_points, float *out, scorp_stream_t stream);
+
+/* ---- fused multi-tensor Adam (row a10) ----
+ * One launch for all parameter groups of torch.optim.Adam(lr per group, betas, eps=1e-15, no weight decay)
+ * (gs3dgs/scene/gaussian_model.py:197-206): m,v moments and parameters updated in place. `step` is the 1-based
+ * step count used for the bias corrections. */
+#define SCORP_ADAM_MAX_TENSORS 8
+typedef struct ScorpAdamTensor {
+  float *param;
+  const float *grad;
+  float *exp_avg;
+  float *exp_avg_sq;
+  uint64_t numel;
+  float lr;
+  float _pad;
+} ScorpAdamTensor;
+int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t num_tensors, double beta1, double beta2, double eps,
+                    int32_t step, scorp_stream_t stream);
+
 /* ---- in-library kernel timing: hipEvent pairs recorded on the launch stream around every kernel ---- */
 /* Off by default. scorp_prof_enable(1) clears the accumulators and starts recording; collect() synchronises the
  * recorded events and returns, per kernel id, the summed duration in ms and the number of launches. */

@@ -30,11 +30,17 @@ class ScorpGs3dGrads(ctypes.Structure):
                                          "rotations", "cov3D_precomp", "shs_rest")]
 
 
+class ScorpAdamTensor(ctypes.Structure):
+    _fields_ = [("param", c_float_p), ("grad", c_float_p), ("exp_avg", c_float_p), ("exp_avg_sq", c_float_p),
+                ("numel", ctypes.c_uint64), ("lr", ctypes.c_float), ("_pad", ctypes.c_float)]
+
+
 EXPORTS = [
     "scorp_version", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
     "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
+    "scorp_knn_dist2", "scorp_adam_step",
     "scorp_prof_enable", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
 ]
 
@@ -71,6 +77,8 @@ def lib():
     L.scorp_loss_workspace_bytes.argtypes = [i32, i32, i32]
     L.scorp_loss_l1_ssim_forward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, sz, i32, vp]
     L.scorp_loss_l1_ssim_backward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, vp, vp]
+    L.scorp_knn_dist2.argtypes = [vp, i32, vp, vp]
+    L.scorp_adam_step.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i32, vp]
     L.scorp_prof_enable.argtypes = [ctypes.c_int]
     L.scorp_prof_kernel_name.restype = ctypes.c_char_p
     L.scorp_prof_kernel_name.argtypes = [ctypes.c_int]

@@ -23,7 +23,7 @@ namespace scorp {
 bool g_prof_on = false;
 namespace {
 const char *kKernelNames[kKNumKernels] = {"preprocess", "count_tiles", "scan_tiles", "scatter_pairs", "sort_tiles", "blend_forward",
-                                          "blend_backward", "preprocess_backward", "ssim_l1_forward", "ssim_l1_backward"};
+                                          "blend_backward", "preprocess_backward", "ssim_l1_forward", "ssim_l1_backward", "knn_dist2", "adam"};
 struct Pending { hipEvent_t start, stop; int id; };
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_pool;

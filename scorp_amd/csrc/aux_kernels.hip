@@ -1,0 +1,152 @@
+// aux_kernels.hip — the two small hot-path helpers that are not rasterization:
+//   scorp_knn_dist2 : replaces simple_knn._C.distCUDA2 (gs3dgs/scene/gaussian_model.py:22,177) — mean squared
+//                     distance of every point to its 3 nearest neighbours, used once to initialise the scales;
+//   scorp_adam_step : the per-iteration Adam update of all parameter groups in ONE launch (replaces the six-group
+//                     torch.optim.Adam(eps=1e-15) step of gaussian_model.py:197-206 / train_3dgs.py:191-193).
+#include "common.hpp"
+
+namespace scorp {
+namespace {
+
+// ---- exact 3-NN by tiled brute force ------------------------------------------------------------------------------
+// N is 1e5..4e5 at initialisation (dataset_readers.py:321,378) and the call happens once per run, so the O(N^2)
+// form is the robust choice: every thread owns a query, the block sweeps all points through LDS 1024 at a time
+// (broadcast reads), 3 smallest squared distances kept in registers.  ~8 VALU per pair: 360k points = 1.3e11 pairs
+// ~ 30 ms.  A point is its own nearest neighbour by index, not by distance, so duplicates count with distance 0.
+constexpr int kKnnTile = 1024;
+__global__ void __launch_bounds__(256)
+knn_dist2_kernel(int N, const float *__restrict__ xyz, float *__restrict__ out) {
+  __shared__ float s_x[kKnnTile], s_y[kKnnTile], s_z[kKnnTile];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool active = i < N;
+  float qx = 0, qy = 0, qz = 0;
+  if (active) { qx = xyz[3 * (size_t)i]; qy = xyz[3 * (size_t)i + 1]; qz = xyz[3 * (size_t)i + 2]; }
+  float b0 = 3.4e38f, b1 = 3.4e38f, b2 = 3.4e38f;  // b0 <= b1 <= b2
+  for (int base = 0; base < N; base += kKnnTile) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < kKnnTile; k += 256) {
+      const int j = base + k;
+      if (j < N) { s_x[k] = xyz[3 * (size_t)j]; s_y[k] = xyz[3 * (size_t)j + 1]; s_z[k] = xyz[3 * (size_t)j + 2]; }
+    }
+    __syncthreads();
+    const int cnt = min(kKnnTile, N - base);
+    for (int k = 0; k < cnt; k++) {
+      const float dx = s_x[k] - qx, dy = s_y[k] - qy, dz = s_z[k] - qz;
+      float d = dx * dx + dy * dy + dz * dz;
+      d = (base + k == i) ? 3.4e38f : d;
+      // insert into the sorted triple
+      const float n2 = fminf(b2, fmaxf(b1, d));
+      const float n1 = fminf(b1, fmaxf(b0, d));
+      b0 = fminf(b0, d); b1 = n1; b2 = n2;
+    }
+  }
+  if (active) {
+    // with fewer than 4 points some slots stay "infinite": average what exists, as a k-d tree query would
+    float s = 0.0f; int c = 0;
+    if (b0 < 3.0e38f) { s += b0; c++; }
+    if (b1 < 3.0e38f) { s += b1; c++; }
+    if (b2 < 3.0e38f) { s += b2; c++; }
+    out[i] = c ? s / 3.0f : 0.0f;
+  }
+}
+
+// ---- multi-tensor Adam -------------------------------------------------------------------------------------------
+struct AdamPack {
+  ScorpAdamTensor t[SCORP_ADAM_MAX_TENSORS];
+  uint32_t first_block[SCORP_ADAM_MAX_TENSORS + 1];  // block range of each tensor
+  int n;
+};
+constexpr int kAdamPerBlock = 256 * 4 * 4;  // 4 float4 per thread
+
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float omb1, float b2, float omb2,
+                                         float step_size, float inv_sqrt_bc2, float eps) {
+  // same operation order as torch.optim.Adam (single-tensor, non-capturable): exp_avg.lerp_, addcmul_, sqrt/div/add, addcdiv_
+  // (1 - beta) is formed in double on the host, as torch does, not as 1.0f - float(beta)
+  m = m + (g - m) * omb1;
+  v = v * b2 + omb2 * g * g;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p = p - step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(256)
+adam_kernel(AdamPack pk, float omb1, float beta2, float omb2, float eps, float bc1, float inv_sqrt_bc2) {
+  int ti = 0;
+#pragma unroll
+  for (int k = 1; k < SCORP_ADAM_MAX_TENSORS; k++)
+    if (k < pk.n && blockIdx.x >= pk.first_block[k]) ti = k;
+  const ScorpAdamTensor T = pk.t[ti];
+  const size_t base = (size_t)(blockIdx.x - pk.first_block[ti]) * kAdamPerBlock;
+  const float step_size = T.lr / bc1;
+  const bool vec = (((uintptr_t)T.param | (uintptr_t)T.grad | (uintptr_t)T.exp_avg | (uintptr_t)T.exp_avg_sq) & 15) == 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const size_t e = base + ((size_t)r * 256 + threadIdx.x) * 4;
+    if (e >= T.numel) break;
+    if (vec && e + 4 <= T.numel) {
+      float4 p = *reinterpret_cast<float4 *>(T.param + e), m = *reinterpret_cast<float4 *>(T.exp_avg + e),
+             v = *reinterpret_cast<float4 *>(T.exp_avg_sq + e);
+      const float4 g = *reinterpret_cast<const float4 *>(T.grad + e);
+      adam_one(p.x, g.x, m.x, v.x, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+      adam_one(p.y, g.y, m.y, v.y, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+      adam_one(p.z, g.z, m.z, v.z, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+      adam_one(p.w, g.w, m.w, v.w, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+      *reinterpret_cast<float4 *>(T.param + e) = p;
+      *reinterpret_cast<float4 *>(T.exp_avg + e) = m;
+      *reinterpret_cast<float4 *>(T.exp_avg_sq + e) = v;
+    } else {
+      for (size_t k = e; k < min(e + 4, (size_t)T.numel); k++) {
+        float p = T.param[k], m = T.exp_avg[k], v = T.exp_avg_sq[k];
+        adam_one(p, T.grad[k], m, v, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+        T.param[k] = p; T.exp_avg[k] = m; T.exp_avg_sq[k] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace scorp
+
+using namespace scorp;
+
+extern "C" int scorp_knn_dist2(const float *xyz, int32_t N, float *out, scorp_stream_t stream_) {
+  if (N < 0 || (N > 0 && (!xyz || !out))) { set_error("bad arguments to scorp_knn_dist2"); return SCORP_ERR_INVALID; }
+  if (N == 0) return SCORP_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  {
+    ProfScope prof(kKKnn, stream);
+    knn_dist2_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, xyz, out);
+  }
+  SCORP_KERNEL_CHECK("knn_dist2", 0, stream);
+  return SCORP_OK;
+}
+
+extern "C" int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t n, double beta1, double beta2, double eps,
+                               int32_t step, scorp_stream_t stream_) {
+  if (n < 0 || n > SCORP_ADAM_MAX_TENSORS || (n > 0 && !tensors) || step < 1) {
+    set_error("bad arguments to scorp_adam_step (n=%d, step=%d)", n, step); return SCORP_ERR_INVALID;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  AdamPack pk;
+  pk.n = 0;
+  uint32_t blocks = 0;
+  for (int k = 0; k < n; k++) {
+    if (tensors[k].numel == 0) continue;
+    if (!tensors[k].param || !tensors[k].grad || !tensors[k].exp_avg || !tensors[k].exp_avg_sq) {
+      set_error("scorp_adam_step: NULL pointer in tensor %d", k); return SCORP_ERR_INVALID;
+    }
+    pk.t[pk.n] = tensors[k];
+    pk.first_block[pk.n] = blocks;
+    blocks += (uint32_t)((tensors[k].numel + kAdamPerBlock - 1) / kAdamPerBlock);
+    pk.n++;
+  }
+  pk.first_block[pk.n] = blocks;
+  if (blocks == 0) return SCORP_OK;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  {
+    ProfScope prof(kKAdam, stream);
+    adam_kernel<<<blocks, 256, 0, stream>>>(pk, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                                            (float)bc1, (float)(1.0 / sqrt(bc2)));
+  }
+  SCORP_KERNEL_CHECK("adam", 0, stream);
+  return SCORP_OK;
+}

@@ -99,7 +99,7 @@ struct PairLayout {
 // ---- in-library kernel timing (api.hip) ----
 enum KernelId {
   kKPreprocess = 0, kKCountTiles, kKScanTiles, kKScatterPairs, kKSortTiles, kKBlendForward, kKBlendBackward, kKPreprocessBackward,
-  kKLossForward, kKLossBackward, kKNumKernels
+  kKLossForward, kKLossBackward, kKKnn, kKAdam, kKNumKernels
 };
 extern bool g_prof_on;
 void prof_begin(int kernel_id, hipStream_t stream);

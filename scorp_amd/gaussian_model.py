@@ -180,7 +180,11 @@ class GaussianModel:
                "f_rest": training_args.feature_lr / 20.0, "opacity": training_args.opacity_lr,
                "scaling": training_args.scaling_lr, "rotation": training_args.rotation_lr}
         groups = [{"params": [getattr(self, _ATTR[g])], "lr": lrs[g], "name": g} for g in GROUPS]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        if self.device.type == "cuda":
+            from .fused_adam import FusedAdam      # one HIP launch for all six groups
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        else:                                      # host-logic tests on CPU tensors
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=training_args.position_lr_init * self.spatial_lr_scale,
             lr_final=training_args.position_lr_final * self.spatial_lr_scale,
