@@ -1,0 +1,65 @@
+"""One-process-per-GPU sharding helpers.  The path shards over independent units — views, objects,
+pose hypotheses — so the only collectives are one broadcast of the Gaussians at start and one gather of small results
+at the end; nothing on the per-view critical path.  Backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_indices(n, rank=None, world_size=None):
+    """Unit i -> rank i mod world (round-robin keeps neighbouring, similarly expensive units on different ranks)."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    return list(range(rank, n, world_size))
+
+
+def broadcast_tensors(tensors, src=0):
+    """In-place broadcast of a dict of equally-shaped tensors (the scene: N x 236 B = 236 MB at 1 M Gaussians, SH3)."""
+    _, w = world()
+    if w > 1:
+        for k in sorted(tensors):
+            dist.broadcast(tensors[k], src=src)
+    return tensors
+
+
+def gather_results(ids, values):
+    """All ranks receive every (id, value-row) pair, ordered by id.  `ids`: int64[m]; `values`: float32[m, c]."""
+    _, w = world()
+    ids = torch.as_tensor(ids, dtype=torch.int64, device=values.device)
+    if w > 1:
+        counts = [torch.zeros(1, dtype=torch.int64, device=values.device) for _ in range(w)]
+        dist.all_gather(counts, torch.tensor([ids.numel()], dtype=torch.int64, device=values.device))
+        m = int(max(c.item() for c in counts))
+        pad_i = torch.full((m,), -1, dtype=torch.int64, device=values.device)
+        pad_v = torch.zeros((m, values.shape[1]), dtype=values.dtype, device=values.device)
+        pad_i[: ids.numel()] = ids
+        pad_v[: ids.numel()] = values
+        gi = [torch.empty_like(pad_i) for _ in range(w)]
+        gv = [torch.empty_like(pad_v) for _ in range(w)]
+        dist.all_gather(gi, pad_i)
+        dist.all_gather(gv, pad_v)
+        ids, values = torch.cat(gi), torch.cat(gv)
+        keep = ids >= 0
+        ids, values = ids[keep], values[keep]
+    order = torch.argsort(ids)
+    return ids[order], values[order]
+
+
+def sweep(n_units, score_fn, device="cpu"):
+    """Evaluate score_fn(i) -> float tensor[c] for the units of this rank, gather, and return (ids, scores, argmax id).
+    This is the shape of the 128-rotation alignment sweep: arg-max of an independent per-hypothesis fitness
+    (align_3dgs_clpe_9dof.py:95-111)."""
+    mine = shard_indices(n_units)
+    vals = [score_fn(i).reshape(-1).float() for i in mine]
+    c = vals[0].numel() if vals else 1
+    v = torch.stack(vals) if vals else torch.zeros((0, c), dtype=torch.float32, device=device)
+    ids, scores = gather_results(mine, v.to(device))
+    best = int(ids[torch.argmax(scores[:, 0])]) if ids.numel() else -1
+    return ids, scores, best

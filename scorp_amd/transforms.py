@@ -1,0 +1,86 @@
+"""Rigid / scale transforms of a GaussianModel — the operations the alignment loop applies between renders
+(utils/gaussians.py:12-108: translate, scale, rotate incl. SH rotation).  All on the model's device, no e3nn:
+the real-SH rotation blocks are solved from the model's own SH basis (scorp_amd.sh.eval_sh), so they are consistent
+with the renderer's conventions by construction.
+"""
+import torch
+
+from .sh import eval_sh
+
+
+def quat_multiply(a, b):
+    """Hamilton product of (w,x,y,z) quaternions, broadcastable."""
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], -1)
+
+
+def matrix_to_quat(R):
+    """One proper rotation matrix -> (w,x,y,z), numerically safe branch selection."""
+    R = R.double()
+    t = R.trace()
+    if t > 0:
+        s = torch.sqrt(t + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = torch.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = [(R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s]
+    elif R[1, 1] > R[2, 2]:
+        s = torch.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = [(R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s]
+    else:
+        s = torch.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = [(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s]
+    return torch.stack([torch.as_tensor(v) for v in q]).float()
+
+
+def sh_rotation_blocks(R, max_degree=3):
+    """[D_1 (3x3), D_2 (5x5), D_3 (7x7)] with  c'_l = D_l c_l  for the rotated function f'(d) = f(R^-1 d)."""
+    R = R.detach().double().cpu()
+    g = torch.Generator().manual_seed(0)
+    d = torch.randn(64, 3, generator=g, dtype=torch.float64)
+    d = d / d.norm(dim=1, keepdim=True)
+    K = (max_degree + 1) ** 2
+    eye = torch.eye(K, dtype=torch.float64)
+    # basis values Y_k(d): evaluate with one-hot coefficient vectors
+    Y = lambda dirs: torch.stack([eval_sh(max_degree, eye[k].expand(dirs.shape[0], 1, K), dirs)[:, 0] for k in range(K)], 1)
+    Y0, Y1 = Y(d), Y(d @ R)            # rows: Y(d_i), Y(R^-1 d_i) (d @ R == (R^T d)^T)
+    blocks = []
+    for l in range(1, max_degree + 1):
+        sl = slice(l * l, (l + 1) * (l + 1))
+        M = torch.linalg.lstsq(Y0[:, sl], Y1[:, sl]).solution.T    # Y_l(R^-1 d) = M Y_l(d)
+        blocks.append(M.T.float())                                  # c' = M^T c
+    return blocks
+
+
+@torch.no_grad()
+def gaussians_translate(g, T):
+    g._xyz.data = g._xyz.data + T[None].to(g._xyz)
+
+
+@torch.no_grad()
+def gaussians_scale(g, scale, fix_center=False):
+    scale = scale.to(g._xyz)
+    if fix_center:
+        c = g._xyz.data.mean(0)
+        g._xyz.data = (g._xyz.data - c) * scale[None] + c
+    else:
+        g._xyz.data = g._xyz.data * scale[None]
+    g._scaling.data = torch.log(torch.exp(g._scaling.data) * scale[None])
+
+
+@torch.no_grad()
+def gaussians_rotate(g, R, fix_center=False):
+    R = R.to(g._xyz)
+    c = g._xyz.data.mean(0) if fix_center else torch.zeros(3, device=g._xyz.device)
+    g._xyz.data = (g._xyz.data - c) @ R.T + c
+    q = matrix_to_quat(R).to(g._xyz)
+    rot = g._rotation.data
+    g._rotation.data = quat_multiply(q[None], rot / rot.norm(dim=1, keepdim=True))
+    if g.max_sh_degree > 0:
+        blocks = sh_rotation_blocks(R, g.max_sh_degree)
+        rest = g._features_rest.data
+        for l, D in enumerate(blocks, start=1):
+            sl = slice(l * l - 1, (l + 1) * (l + 1) - 1)            # _features_rest starts at coefficient 1
+            rest[:, sl] = torch.einsum("ij,njc->nic", D.to(rest), rest[:, sl])
