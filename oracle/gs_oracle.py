@@ -128,3 +128,81 @@ class OracleRender:
             self.close()
         except Exception:
             pass
+
+
+class OracleRender2D:
+    """2DGS (surfel) oracle: color[3,H,W], radii[N], allmap[7,H,W]; scales are [N,2]."""
+
+    def __init__(self, dtype, means3D, opacities, view, proj, campos, bg, W, H, tanfovx, tanfovy,
+                 shs=None, sh_degree=0, colors_precomp=None, scales=None, rotations=None, transmat_precomp=None,
+                 scale_modifier=1.0):
+        self.dtype = np.dtype(dtype)
+        self.real = ctypes.c_float if self.dtype == np.float32 else ctypes.c_double
+        self.lib = _lib(self.dtype)
+        self.lib.gs2d_oracle_forward.restype = ctypes.c_void_p
+        self.lib.gs2d_oracle_num_pairs.restype = ctypes.c_int64
+        self.lib.gs2d_oracle_num_pairs.argtypes = [ctypes.c_void_p]
+        self.lib.gs2d_oracle_free.argtypes = [ctypes.c_void_p]
+        c = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a), dtype=self.dtype)
+        self.means3D = c(means3D).reshape(-1, 3)
+        self.N = self.means3D.shape[0]
+        self.opacities = c(opacities).reshape(-1)
+        self.shs, self.colors_precomp = c(shs), c(colors_precomp)
+        self.scales, self.rotations, self.transmat_precomp = c(scales), c(rotations), c(transmat_precomp)
+        assert (self.shs is None) != (self.colors_precomp is None)
+        assert (self.transmat_precomp is None) != (self.scales is None)
+        self.K = 0 if self.shs is None else self.shs.shape[1]
+        self.W, self.H = int(W), int(H)
+        self.view, self.proj = c(view).reshape(16), c(proj).reshape(16)
+        self.campos, self.bg = c(campos).reshape(3), c(bg).reshape(3)
+        self.color = np.zeros((3, self.H, self.W), self.dtype)
+        self.allmap = np.zeros((7, self.H, self.W), self.dtype)
+        self.radii = np.zeros(self.N, np.int32)
+        r = self.real
+        st = self.lib.gs2d_oracle_forward(
+            ctypes.c_int(self.N), ctypes.c_int(self.K), ctypes.c_int(int(sh_degree)), ctypes.c_int(self.W), ctypes.c_int(self.H),
+            r(tanfovx), r(tanfovy), r(scale_modifier), _p(self.bg), _p(self.view), _p(self.proj), _p(self.campos),
+            _p(self.means3D), _p(self.shs), _p(self.colors_precomp), _p(self.opacities), _p(self.scales),
+            _p(self.rotations), _p(self.transmat_precomp), _p(self.color), _p(self.radii), _p(self.allmap))
+        if not st:
+            raise MemoryError("2D oracle forward failed")
+        self.state = ctypes.c_void_p(st)
+        self.num_pairs = int(self.lib.gs2d_oracle_num_pairs(self.state))
+        self.tiles_x, self.tiles_y = (self.W + 15) // 16, (self.H + 15) // 16
+
+    def geom(self):
+        N = self.N
+        T = np.zeros((N, 9), self.dtype); xy = np.zeros((N, 2), self.dtype); depth = np.zeros(N, self.dtype)
+        nrm_o = np.zeros((N, 4), self.dtype); rgb = np.zeros((N, 3), self.dtype); rect = np.zeros((N, 4), np.int32)
+        self.lib.gs2d_oracle_geom(self.state, _p(T), _p(xy), _p(depth), _p(nrm_o), _p(rgb), _p(rect))
+        return dict(T=T, xy=xy, depth=depth, nrm_o=nrm_o, rgb=rgb, rect=rect)
+
+    def tiles(self):
+        ts = np.zeros(self.tiles_x * self.tiles_y + 1, np.int64)
+        pl = np.zeros(max(self.num_pairs, 1), np.int32)
+        self.lib.gs2d_oracle_tiles(self.state, _p(ts), _p(pl))
+        return ts, pl[: self.num_pairs]
+
+    def backward(self, dL_dcolor=None, dL_dallmap=None):
+        c = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a), dtype=self.dtype)
+        dc, da = c(dL_dcolor), c(dL_dallmap)
+        N, K = self.N, self.K
+        g = dict(means3D=np.zeros((N, 3), self.dtype), means2D=np.zeros((N, 3), self.dtype),
+                 shs=np.zeros((N, K, 3), self.dtype) if K else None, colors_precomp=np.zeros((N, 3), self.dtype),
+                 opacities=np.zeros((N, 1), self.dtype), scales=np.zeros((N, 2), self.dtype),
+                 rotations=np.zeros((N, 4), self.dtype), transmat=np.zeros((N, 9), self.dtype))
+        self.lib.gs2d_oracle_backward(self.state, _p(dc), _p(da), _p(g["means3D"]), _p(g["means2D"]), _p(g["shs"]),
+                                      _p(g["colors_precomp"]), _p(g["opacities"]), _p(g["scales"]), _p(g["rotations"]),
+                                      _p(g["transmat"]))
+        return g
+
+    def close(self):
+        if getattr(self, "state", None):
+            self.lib.gs2d_oracle_free(self.state)
+            self.state = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,73 @@
+"""CPU tests of the 2DGS (surfel) oracle: analytic backward vs torch.autograd of the dense formulation (float64)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.gs_oracle import OracleRender2D
+from oracle.torch_dense2d import render_dense_2d
+from scorp_amd.synthetic import activate, make_gaussians, ring_cameras
+
+
+def make_case2d(N, W, H, deg, seed, log_scale=math.log(0.1), radius=4.0, bg=(0.0, 0.0, 0.0), max_deg=3, scale_modifier=1.0,
+                precomp_color=False):
+    raw = make_gaussians(N, max_deg, seed, log_scale_mean=log_scale, log_scale_std=0.6, scale_dims=2)
+    act = activate(raw)
+    cam = ring_cameras(7, W, H, seed, radius=radius)[seed % 7]
+    kw = dict(means3D=act["means3D"], opacities=act["opacities"], W=W, H=H, tanfovx=math.tan(cam.FoVx / 2),
+              tanfovy=math.tan(cam.FoVy / 2), view=cam.world_view_transform.numpy().astype(np.float32),
+              proj=cam.full_proj_transform.numpy().astype(np.float32), campos=cam.camera_center.numpy().astype(np.float32),
+              bg=np.asarray(bg, np.float32), scales=act["scales"], rotations=act["rotations"], scale_modifier=scale_modifier)
+    if precomp_color:
+        kw["colors_precomp"] = np.random.default_rng(seed + 3).uniform(0, 1, (N, 3)).astype(np.float32)
+    else:
+        kw["shs"], kw["sh_degree"] = act["shs"], deg
+    return kw, cam
+
+
+CASES = [dict(N=300, W=48, H=40, deg=3, seed=1, bg=(0.2, 0.5, 0.7)), dict(N=400, W=37, H=50, deg=2, seed=2),
+         dict(N=500, W=40, H=40, deg=1, seed=7, radius=1.5),                       # camera inside: culls + back faces
+         dict(N=300, W=64, H=48, deg=0, seed=4, log_scale=math.log(0.02))]         # tiny surfels: low-pass branch
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle2d_f64_matches_dense_autograd(case):
+    kw, _ = make_case2d(**case)
+    W, H = kw["W"], kw["H"]
+    T = lambda a: torch.tensor(a.astype(np.float64), requires_grad=True)
+    t = {k: T(kw[k]) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    C = lambda a: torch.tensor(np.asarray(a, np.float64))
+    color, radii, allmap = render_dense_2d(t["means3D"], t["opacities"], C(kw["view"]), C(kw["proj"]), C(kw["campos"]),
+                                           C(kw["bg"]), W, H, shs=t["shs"], sh_degree=kw["sh_degree"], scales=t["scales"],
+                                           rotations=t["rotations"], scale_modifier=kw["scale_modifier"])
+    g = torch.Generator().manual_seed(case["seed"])
+    wc = torch.randn(3, H, W, generator=g, dtype=torch.float64)
+    wa = torch.randn(7, H, W, generator=g, dtype=torch.float64)
+    ((color * wc).sum() + (allmap * wa).sum()).backward()
+    o = OracleRender2D(np.float64, **{k: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    assert o.num_pairs > 0
+    np.testing.assert_array_equal(o.radii, radii.numpy())
+    np.testing.assert_allclose(o.color, color.detach().numpy(), atol=1e-12)
+    np.testing.assert_allclose(o.allmap, allmap.detach().numpy(), atol=1e-11)
+    gr = o.backward(wc.numpy(), wa.numpy())
+    for name in ("means3D", "opacities", "shs", "scales", "rotations"):
+        ref = t[name].grad.numpy().reshape(gr[name].shape)
+        assert np.abs(gr[name] - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-12), name
+
+
+def test_oracle2d_f32_and_edges():
+    kw, _ = make_case2d(2000, 128, 96, 3, 11, bg=(0.1, 0.2, 0.3), log_scale=math.log(0.05))
+    o32 = OracleRender2D(np.float32, **kw)
+    o64 = OracleRender2D(np.float64, **{k: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+    assert np.abs(o32.color - o64.color).mean() < 1e-5
+    assert np.abs(o32.allmap[1] - o64.allmap[1]).mean() < 1e-5
+    # alpha channel = 1 - T; normals are unit-length weighted sums
+    assert o32.allmap[1].min() >= 0 and o32.allmap[1].max() <= 1 + 1e-6
+    assert np.all(np.linalg.norm(o32.allmap[2:5], axis=0) <= o32.allmap[1] + 1e-4)
+    # nothing visible
+    kw["means3D"] = kw["means3D"] * 0.01 + 50.0
+    o = OracleRender2D(np.float32, **kw)
+    assert o.num_pairs == 0 and (o.radii == 0).all() and (o.allmap == 0).all()
+    g = o.backward(np.ones((3, 96, 128), np.float32), np.ones((7, 96, 128), np.float32))
+    assert all(np.all(v == 0) for v in g.values() if v is not None)
