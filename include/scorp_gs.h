@@ -135,6 +135,31 @@ int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint64_t capaci
                            int32_t image_width, int32_t image_height, uint32_t *tile_start, uint32_t *point_list,
                            scorp_stream_t stream);
 
+/* ---- 2D Gaussian splatting (surfels): replaces diff_surfel_rasterization (gs2dgs/gaussian_renderer/__init__.py:111-120) ----
+ * Same ScorpGs3dInputs / ScorpGs3dGrads structs with two reinterpretations: `scales` is [N,2]
+ * (gs2dgs/scene/gaussian_model.py:49) and `cov3D_precomp` is the precomputed [N,9] splat->pixel transform
+ * (gs2dgs/gaussian_renderer/__init__.py:78-89).  Outputs: color[3,H,W], radii[N], allmap[7,H,W] with channels
+ * 0 expected depth (un-normalised), 1 alpha, 2-4 view-space normal, 5 median depth, 6 depth distortion (:131-148).
+ * The means2D gradient is the densification statistic the 2DGS model accumulates (gaussian_model.py:495).
+ * Pair counting / overflow checks are shared: scorp_gs3d_num_pairs / scorp_gs3d_check_overflow work on this state. */
+size_t scorp_gs2d_state_bytes(int32_t num_gaussians, int32_t image_width, int32_t image_height);
+size_t scorp_gs2d_backward_scratch_bytes(int32_t num_gaussians);
+int scorp_gs2d_preprocess(const ScorpGs3dInputs *in, int32_t *out_radii, void *state, size_t state_bytes,
+                          scorp_stream_t stream);
+int scorp_gs2d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
+                      float *out_allmap, scorp_stream_t stream);
+int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
+                        const float *dL_dcolor, const float *dL_dallmap, const ScorpGs3dGrads *grads, void *scratch,
+                        size_t scratch_bytes, scorp_stream_t stream);
+/* T[N,9], xy[N,2], depth[N], normal_opacity[N,4], rgb[N,3], rect[N,4]; any may be NULL (stage-level parity tests). */
+int scorp_gs2d_debug_geom(const void *state, int32_t num_gaussians, int32_t image_width, int32_t image_height, float *T,
+                          float *xy, float *depth, float *normal_opacity, float *rgb, int32_t *rect,
+                          scorp_stream_t stream);
+
+int scorp_gs2d_debug_tiles(const void *state, const void *pairs, uint64_t capacity, int32_t num_gaussians,
+                           int32_t image_width, int32_t image_height, uint32_t *tile_start, uint32_t *point_list,
+                           scorp_stream_t stream);
+
 /* ---- fused photometric loss (rows a8/a9 of the hot path) ----
  * loss = (1-lambda) * mean|x-y| + lambda * (1 - mean SSIM(x,y)), x = img*mask, y = gt*mask (mask [H,W] or NULL):
  * train_3dgs.py:106-107, post_refine_gs.py:103-111 over gs3dgs/utils/loss_utils.py:17-73 (11x11 Gaussian window,

@@ -41,6 +41,8 @@ EXPORTS = [
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
     "scorp_knn_dist2", "scorp_adam_step",
+    "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
+    "scorp_gs2d_backward", "scorp_gs2d_debug_geom", "scorp_gs2d_debug_tiles",
     "scorp_prof_enable", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
 ]
 
@@ -77,6 +79,15 @@ def lib():
     L.scorp_loss_workspace_bytes.argtypes = [i32, i32, i32]
     L.scorp_loss_l1_ssim_forward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, sz, i32, vp]
     L.scorp_loss_l1_ssim_backward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, vp, vp]
+    L.scorp_gs2d_state_bytes.restype = sz
+    L.scorp_gs2d_state_bytes.argtypes = [i32, i32, i32]
+    L.scorp_gs2d_backward_scratch_bytes.restype = sz
+    L.scorp_gs2d_backward_scratch_bytes.argtypes = [i32]
+    L.scorp_gs2d_preprocess.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, sz, vp]
+    L.scorp_gs2d_render.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp]
+    L.scorp_gs2d_backward.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, ctypes.POINTER(ScorpGs3dGrads), vp, sz, vp]
+    L.scorp_gs2d_debug_geom.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.scorp_gs2d_debug_tiles.argtypes = [vp, vp, u64, i32, i32, i32, vp, vp, vp]
     L.scorp_knn_dist2.argtypes = [vp, i32, vp, vp]
     L.scorp_adam_step.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i32, vp]
     L.scorp_prof_enable.argtypes = [ctypes.c_int]

@@ -23,7 +23,8 @@ namespace scorp {
 bool g_prof_on = false;
 namespace {
 const char *kKernelNames[kKNumKernels] = {"preprocess", "count_tiles", "scan_tiles", "scatter_pairs", "sort_tiles", "blend_forward",
-                                          "blend_backward", "preprocess_backward", "ssim_l1_forward", "ssim_l1_backward", "knn_dist2", "adam"};
+                                          "blend_backward", "preprocess_backward", "ssim_l1_forward", "ssim_l1_backward", "knn_dist2", "adam", "preprocess_2d", "blend_forward_2d",
+                                          "blend_backward_2d", "preprocess_backward_2d"};
 struct Pending { hipEvent_t start, stop; int id; };
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_pool;

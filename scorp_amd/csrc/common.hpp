@@ -36,11 +36,13 @@ static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
 struct alignas(16) BinRec {
   uint16_t x0, y0, x1, y1;  // tile rectangle, max exclusive
   uint32_t depth_bits;      // fp32 bits of view-space z (> 0, so unsigned order == float order)
-  int32_t radius;           // bits 0..27: pixel radius (0 = culled); bits 28..30: SH colour clamp mask (r,g,b)
+  int32_t radius;           // bits 0..26: pixel radius (0 = culled); bit 27: surfel faces away (2DGS normal flipped);
+                            // bits 28..30: SH colour clamp mask (r,g,b)
 };
 static_assert(sizeof(BinRec) == 16, "BinRec must be 16 bytes");
 constexpr int kClampShift = 28;
-constexpr int32_t kRadiusMask = 0x0FFFFFFF;
+constexpr int32_t kRadiusMask = 0x07FFFFFF;
+constexpr int kFlipBit = 27;
 
 struct StateHeader {
   uint32_t num_pairs;  // D of the last preprocess
@@ -65,19 +67,19 @@ struct StateLayout {
   size_t header, rec, bin, tile_count, tile_start, final_T, n_contrib, block_hist, total;
   int tiles_x, tiles_y, tiles, nb;
   bool lds_binning;
-  StateLayout(int N, int W, int H) {
+  StateLayout(int N, int W, int H, bool mode2d = false) {
     tiles_x = (W + kTile - 1) / kTile;
     tiles_y = (H + kTile - 1) / kTile;
     tiles = tiles_x * tiles_y;
     size_t n = N > 0 ? (size_t)N : 1, hw = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
     size_t off = 0;
     header = off; off = align_up(off + sizeof(StateHeader), 256);
-    rec = off; off = align_up(off + n * sizeof(SplatRec), 256);
+    rec = off; off = align_up(off + n * (mode2d ? (size_t)80 : sizeof(SplatRec)), 256);
     bin = off; off = align_up(off + n * sizeof(BinRec), 256);
     tile_count = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
     tile_start = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
-    final_T = off; off = align_up(off + hw * 4, 256);
-    n_contrib = off; off = align_up(off + hw * 4, 256);
+    final_T = off; off = align_up(off + hw * 4 * (mode2d ? 3 : 1), 256);     // 2DGS also keeps M1, M2 per pixel
+    n_contrib = off; off = align_up(off + hw * 4 * (mode2d ? 2 : 1), 256);   // ... and the median contributor
     nb = bin_blocks(N);
     lds_binning = tiles <= kMaxLdsTiles;
     block_hist = off; off = align_up(off + (lds_binning ? (size_t)nb * tiles * 4 : 0), 256);
@@ -99,7 +101,8 @@ struct PairLayout {
 // ---- in-library kernel timing (api.hip) ----
 enum KernelId {
   kKPreprocess = 0, kKCountTiles, kKScanTiles, kKScatterPairs, kKSortTiles, kKBlendForward, kKBlendBackward, kKPreprocessBackward,
-  kKLossForward, kKLossBackward, kKKnn, kKAdam, kKNumKernels
+  kKLossForward, kKLossBackward, kKKnn, kKAdam, kKPreprocess2d, kKBlendForward2d, kKBlendBackward2d,
+  kKPreprocessBackward2d, kKNumKernels
 };
 extern bool g_prof_on;
 void prof_begin(int kernel_id, hipStream_t stream);
@@ -115,6 +118,11 @@ void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec
                        uint32_t *tile_count, hipStream_t stream);
 void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L, const BinRec *bin, const float *acc,
                                 const ScorpGs3dGrads *grads, hipStream_t stream);
+
+// ---- binning shared by the 3DGS and 2DGS paths (gs3d_forward.hip) ----
+int bin_count_and_scan(const StateLayout &L, char *state_base, int N, int debug, hipStream_t stream);
+int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *state_base, char *pairs_base, int N,
+                         uint32_t capacity, int debug, hipStream_t stream);
 
 // ---- host error plumbing ----
 void set_error(const char *fmt, ...);

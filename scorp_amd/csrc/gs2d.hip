@@ -1,0 +1,718 @@
+// gs2d.hip — 2D Gaussian splatting (surfel) path for gfx950: forward and backward.
+//
+// Replaces `diff_surfel_rasterization` as called at gs2dgs/gaussian_renderer/__init__.py:111-120 (outputs
+// color[3,H,W], radii[N], allmap[7,H,W]; channel order :131-148).  Arithmetic follows oracle/gs2d_oracle.c: each
+// surfel is a 3x3 matrix T (rows Tu,Tv,Tw) mapping its local (u,v,1) to (x*w, y*w, w) in pixels; a pixel intersects
+// the surfel plane in uv space, alpha = o * exp(-0.5 * min(u^2+v^2, 2*|pixel - centre|^2)).
+// Binning / per-tile depth sort are the 3DGS ones (common.hpp); the blend kernels use the same tiling (4 wave64 x
+// 8x8 pixels, LDS batches, per-wave ballot cull — here by the bounding box of the alpha >= 1/255 region).
+#include <stdlib.h>
+
+#include "pergaussian.hpp"
+
+namespace scorp {
+namespace {
+
+constexpr float kFarZ = 100.0f;
+constexpr float kCutoff = 3.0f;
+constexpr float kFilterSize = 0.707106f;
+constexpr float kFilterInvSq = 2.0f;
+constexpr float kExtentFloor = 0.0001f;
+constexpr int kAcc2Stride = 20;  // gT[9], gxy[2], gnormal[3], gopacity, grgb[3], pad[2]
+constexpr int kBatch2 = 128;
+
+struct alignas(16) Surfel {  // 80 bytes, gathered as five 16-byte loads
+  float4 r0;  // Tu.x Tu.y Tu.z Tv.x
+  float4 r1;  // Tv.y Tv.z Tw.x Tw.y
+  float4 r2;  // Tw.z cx cy opacity
+  float4 r3;  // n.x n.y n.z r
+  float4 r4;  // g b hx hy   (hx, hy: half extents of the alpha >= 1/255 region around (cx, cy))
+};
+static_assert(sizeof(Surfel) == 80, "Surfel must be 80 bytes");
+
+struct Pg2Args {
+  int N, K, W, H, tiles_x, tiles_y, raw, count_with_atomics;
+  float scale_mod;
+  const float *view, *proj, *campos;
+  const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *transmat;
+};
+
+__device__ __forceinline__ void pixel_rows(const float *pm, int W, int H, float Q[3][4]) {
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const float p0 = pm[c * 4 + 0], p1 = pm[c * 4 + 1], p3 = pm[c * 4 + 3];
+    Q[0][c] = 0.5f * W * p0 + 0.5f * (W - 1) * p3;
+    Q[1][c] = 0.5f * H * p1 + 0.5f * (H - 1) * p3;
+    Q[2][c] = p3;
+  }
+}
+
+__device__ __forceinline__ void quat_R(float4 q, float *R) {
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - r * z);     R[2] = 2 * (x * z + r * y);
+  R[3] = 2 * (x * y + r * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - r * x);
+  R[6] = 2 * (x * z - r * y);     R[7] = 2 * (y * z + r * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int DEG, bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bin, int32_t *__restrict__ radii,
+                    uint32_t *__restrict__ tile_count) {
+#pragma clang fp contract(off)
+  __shared__ float s_sh[256 * kShStride];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool active = i < a.N;
+  float vm[16], pm[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
+  BinRec br;
+  br.x0 = br.y0 = br.x1 = br.y1 = 0; br.depth_bits = 0; br.radius = 0;
+  bool vis = false;
+  float T[9], nv[3] = {0, 0, 1}, p[3] = {0, 0, 0}, cx = 0, cy = 0, op = 0, hx = 0, hy = 0, depth = 0, mult = 1;
+  int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  if (active) {
+    p[0] = a.means3D[3 * (size_t)i]; p[1] = a.means3D[3 * (size_t)i + 1]; p[2] = a.means3D[3 * (size_t)i + 2];
+    const float pvx = vm[0] * p[0] + vm[4] * p[1] + vm[8] * p[2] + vm[12];
+    const float pvy = vm[1] * p[0] + vm[5] * p[1] + vm[9] * p[2] + vm[13];
+    depth = __builtin_fmaf(vm[10], p[2], __builtin_fmaf(vm[6], p[1], __builtin_fmaf(vm[2], p[0], vm[14])));
+    if (depth > kNearZ) {
+      if (a.transmat) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) T[q] = a.transmat[9 * (size_t)i + q];
+      } else {
+        float Q[3][4], R[9], invn;
+        pixel_rows(pm, a.W, a.H, Q);
+        quat_R(act_quat(reinterpret_cast<const float4 *>(a.rotations)[i], a.raw, &invn), R);
+        const float sx = a.scale_mod * act_scale(a.scales[2 * (size_t)i], a.raw),
+                    sy = a.scale_mod * act_scale(a.scales[2 * (size_t)i + 1], a.raw);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          T[r * 3 + 0] = sx * (Q[r][0] * R[0] + Q[r][1] * R[3] + Q[r][2] * R[6]);
+          T[r * 3 + 1] = sy * (Q[r][0] * R[1] + Q[r][1] * R[4] + Q[r][2] * R[7]);
+          T[r * 3 + 2] = Q[r][0] * p[0] + Q[r][1] * p[1] + Q[r][2] * p[2] + Q[r][3];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) nv[r] = vm[0 * 4 + r] * R[2] + vm[1 * 4 + r] * R[5] + vm[2 * 4 + r] * R[8];
+      }
+      const float cosv = -(pvx * nv[0] + pvy * nv[1] + depth * nv[2]);
+      const float *Tu = T, *Tv = T + 3, *Tw = T + 6;
+      const float c2 = kCutoff * kCutoff;
+      const float dd = c2 * Tw[0] * Tw[0] + c2 * Tw[1] * Tw[1] + -1.0f * Tw[2] * Tw[2];
+      if (cosv != 0.0f && dd != 0.0f) {
+        mult = cosv > 0.0f ? 1.0f : -1.0f;
+        const float f0 = c2 / dd, f1 = c2 / dd, f2 = -1.0f / dd;
+        cx = f0 * Tu[0] * Tw[0] + f1 * Tu[1] * Tw[1] + f2 * Tu[2] * Tw[2];
+        cy = f0 * Tv[0] * Tw[0] + f1 * Tv[1] * Tw[1] + f2 * Tv[2] * Tw[2];
+        const float tx = f0 * Tu[0] * Tu[0] + f1 * Tu[1] * Tu[1] + f2 * Tu[2] * Tu[2];
+        const float ty = f0 * Tv[0] * Tv[0] + f1 * Tv[1] * Tv[1] + f2 * Tv[2] * Tv[2];
+        const float ex = sqrtf(fmaxf(kExtentFloor, cx * cx - tx)), ey = sqrtf(fmaxf(kExtentFloor, cy * cy - ty));
+        radius = (int)ceilf(fmaxf(fmaxf(ex, ey), kCutoff * kFilterSize));
+        x0 = min(a.tiles_x, max(0, (int)((cx - radius) / kTile)));
+        y0 = min(a.tiles_y, max(0, (int)((cy - radius) / kTile)));
+        x1 = min(a.tiles_x, max(0, (int)((cx + radius + kTile - 1) / kTile)));
+        y1 = min(a.tiles_y, max(0, (int)((cy + radius + kTile - 1) / kTile)));
+        if ((x1 - x0) * (y1 - y0) > 0) {
+          vis = true;
+          op = act_opacity(a.opacities[i], a.raw);
+          // Bounding box (around cx, cy) of {alpha >= 1/255} = {min(rho3d, rho2d) <= kk}, kk = 2 ln(255 o): the
+          // projected uv-disc of radius sqrt(kk) (same closed form as the 3-sigma box) united with the low-pass disc.
+          const float kk = fmaxf(2.0f * logf(fmaxf(255.0f * op, 1.0f)), 1e-3f);
+          const float ddk = kk * Tw[0] * Tw[0] + kk * Tw[1] * Tw[1] - Tw[2] * Tw[2];
+          hx = hy = 1e30f;  // unbounded projection (disc crosses the camera plane): never cull
+          if (ddk < 0.0f) {
+            const float g0 = kk / ddk, g2 = -1.0f / ddk;
+            const float cxk = g0 * Tu[0] * Tw[0] + g0 * Tu[1] * Tw[1] + g2 * Tu[2] * Tw[2];
+            const float cyk = g0 * Tv[0] * Tw[0] + g0 * Tv[1] * Tw[1] + g2 * Tv[2] * Tw[2];
+            const float txk = g0 * Tu[0] * Tu[0] + g0 * Tu[1] * Tu[1] + g2 * Tu[2] * Tu[2];
+            const float tyk = g0 * Tv[0] * Tv[0] + g0 * Tv[1] * Tv[1] + g2 * Tv[2] * Tv[2];
+            const float lp = sqrtf(0.5f * kk);
+            hx = 1.01f * fmaxf(fabsf(cxk - cx) + sqrtf(fmaxf(kExtentFloor, cxk * cxk - txk)), lp) + 0.5f;
+            hy = 1.01f * fmaxf(fabsf(cyk - cy) + sqrtf(fmaxf(kExtentFloor, cyk * cyk - tyk)), lp) + 0.5f;
+          }
+        }
+      }
+    }
+  }
+  float rgb[3] = {0.0f, 0.0f, 0.0f};
+  int clamp_bits = 0;
+  if (a.shs) {
+    if (__syncthreads_or(vis ? 1 : 0)) {
+      constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
+      const size_t i0 = (size_t)blockIdx.x * 256;
+      stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, min(256, a.N - (int)i0));
+      __syncthreads();
+      if (vis) {
+        const float dx = p[0] - a.campos[0], dy = p[1] - a.campos[1], dz = p[2] - a.campos[2];
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        sh_row_to_rgb<DEG>(s_sh + threadIdx.x * kShStride, dx * inv, dy * inv, dz * inv, rgb);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          if (rgb[q] < 0.0f) clamp_bits |= 1 << q;
+          rgb[q] = fmaxf(rgb[q], 0.0f);
+        }
+      }
+    }
+  } else if (vis) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) rgb[q] = a.colors_precomp[3 * (size_t)i + q];
+  }
+  if (!active) return;
+  int radius_out = 0;
+  if (vis) {
+    float4 *dst = reinterpret_cast<float4 *>(rec + i);
+    dst[0] = make_float4(T[0], T[1], T[2], T[3]);
+    dst[1] = make_float4(T[4], T[5], T[6], T[7]);
+    dst[2] = make_float4(T[8], cx, cy, op);
+    dst[3] = make_float4(mult * nv[0], mult * nv[1], mult * nv[2], rgb[0]);
+    dst[4] = make_float4(rgb[1], rgb[2], hx, hy);
+    br.x0 = (uint16_t)x0; br.y0 = (uint16_t)y0; br.x1 = (uint16_t)x1; br.y1 = (uint16_t)y1;
+    br.depth_bits = __float_as_uint(depth);
+    br.radius = radius | (clamp_bits << kClampShift) | ((mult < 0.0f ? 1 : 0) << kFlipBit);
+    radius_out = radius;
+    if (a.count_with_atomics)
+      for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * a.tiles_x + x], 1u);
+  }
+  reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
+  radii[i] = radius_out;
+}
+
+// one ray-surfel evaluation, shared by forward and backward
+struct Hit2 { float k[3], l[3], pz, s0, s1, dx, dy, depth, G, alpha; bool use3d; };
+__device__ __forceinline__ bool eval_hit2(const float4 r0, const float4 r1, const float4 r2, float pxf, float pyf, Hit2 &h) {
+  const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
+#pragma unroll
+  for (int q = 0; q < 3; q++) { h.k[q] = pxf * Tw[q] - Tu[q]; h.l[q] = pyf * Tw[q] - Tv[q]; }
+  const float p0 = h.k[1] * h.l[2] - h.k[2] * h.l[1];
+  const float p1 = h.k[2] * h.l[0] - h.k[0] * h.l[2];
+  h.pz = h.k[0] * h.l[1] - h.k[1] * h.l[0];
+  if (h.pz == 0.0f) return false;
+  h.s0 = p0 / h.pz; h.s1 = p1 / h.pz;
+  const float rho3d = h.s0 * h.s0 + h.s1 * h.s1;
+  h.dx = r2.y - pxf; h.dy = r2.z - pyf;
+  const float rho2d = kFilterInvSq * (h.dx * h.dx + h.dy * h.dy);
+  h.use3d = rho3d <= rho2d;
+  const float rho = fminf(rho3d, rho2d);
+  h.depth = h.use3d ? (h.s0 * Tw[0] + h.s1 * Tw[1]) + Tw[2] : Tw[2];
+  if (h.depth < kNearZ) return false;
+  const float power = -0.5f * rho;
+  if (power > 0.0f) return false;
+  h.G = __expf(power);
+  h.alpha = fminf(kAlphaMax, r2.w * h.G);
+  return h.alpha >= kAlphaMin;
+}
+
+__device__ __forceinline__ bool box_hit(const float4 r2, const float4 r4, float bx0, float bx1, float by0, float by1) {
+  return r2.y + r4.z >= bx0 && r2.y - r4.z <= bx1 && r2.z + r4.w >= by0 && r2.z - r4.w <= by1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+blend2d_forward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                       const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x,
+                       const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ allmap,
+                       float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
+  __shared__ float4 s_r[5][kBatch2];
+  const int tile = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bx = (tile % tiles_x) * kTile + (wave & 1) * 8, by = (tile / tiles_x) * kTile + (wave >> 1) * 8;
+  const int px = bx + (lane & 7), py = by + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const float fn = kFarZ / (kFarZ - kNearZ);
+  float T = 1.0f, C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
+  uint32_t last = 0, med_c = 0;
+  bool done = !inside;
+  for (uint32_t base = beg; base < end; base += kBatch2) {
+    if (__syncthreads_and(done)) break;
+    const int cnt = (int)min((uint32_t)kBatch2, end - base);
+    if ((int)threadIdx.x < cnt) {
+      const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[base + threadIdx.x]);
+#pragma unroll
+      for (int q = 0; q < 5; q++) s_r[q][threadIdx.x] = src[q];
+    }
+    __syncthreads();
+    for (int q = 0; q < cnt; q += 64) {
+      const int j = q + lane;
+      const bool hit = j < cnt && box_hit(s_r[2][j], s_r[4][j], bx0, bx1, by0, by1);
+      uint64_t mask = __ballot(hit);
+      while (mask) {
+        const int jj = q + __builtin_ctzll(mask);
+        mask &= mask - 1;
+        if (done) continue;
+        const float4 r2 = s_r[2][jj];
+        Hit2 h;
+        if (!eval_hit2(s_r[0][jj], s_r[1][jj], r2, pxf, pyf, h)) continue;
+        const float test_T = T * (1.0f - h.alpha);
+        if (test_T < kTMin) { done = true; continue; }
+        const float4 r3 = s_r[3][jj], r4 = s_r[4][jj];
+        const float w = h.alpha * T;
+        const float A = 1.0f - T;
+        const float m = fn * (1.0f - kNearZ / h.depth);
+        dist += (m * m * A + M2 - 2.0f * m * M1) * w;
+        Dp += h.depth * w; M1 += m * w; M2 += m * m * w;
+        const uint32_t pos1 = (base - beg) + (uint32_t)jj + 1u;
+        if (T > 0.5f) { med = h.depth; med_c = pos1; }
+        N0 += r3.x * w; N1 += r3.y * w; N2 += r3.z * w;
+        C0 += r3.w * w; C1 += r4.x * w; C2 += r4.y * w;
+        T = test_T;
+        last = pos1;
+      }
+    }
+  }
+  if (inside) {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
+    n_contrib[pix] = last; n_contrib[HW + pix] = med_c;
+    out_color[pix] = C0 + T * bg[0]; out_color[HW + pix] = C1 + T * bg[1]; out_color[2 * HW + pix] = C2 + T * bg[2];
+    allmap[pix] = Dp; allmap[HW + pix] = 1.0f - T;
+    allmap[2 * HW + pix] = N0; allmap[3 * HW + pix] = N1; allmap[4 * HW + pix] = N2;
+    allmap[5 * HW + pix] = med; allmap[6 * HW + pix] = dist;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+blend2d_backward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                        const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x,
+                        const float *__restrict__ bg, const float *__restrict__ final_T,
+                        const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
+                        const float *__restrict__ dL_dallmap, float *__restrict__ acc) {
+  __shared__ float4 s_r[5][kBatch2];
+  __shared__ uint32_t s_id[kBatch2];
+  __shared__ uint32_t s_max;
+  const int tile = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bx = (tile % tiles_x) * kTile + (wave & 1) * 8, by = (tile / tiles_x) * kTile + (wave >> 1) * 8;
+  const int px = bx + (lane & 7), py = by + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  if (end == beg) return;
+  const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+  const float T_final = inside ? final_T[pix] : 0.0f;
+  const uint32_t last = inside ? n_contrib[pix] : 0u;
+  float final_D = 0, final_D2 = 0, dpix0 = 0, dpix1 = 0, dpix2 = 0, ddep = 0, dacc = 0, dn0 = 0, dn1 = 0, dn2 = 0,
+        dmed = 0, dreg = 0;
+  uint32_t med_c = 0;
+  if (last > 0) {  // pixels nothing was blended into never read their upstream gradient (it may be NaN)
+    final_D = final_T[HW + pix]; final_D2 = final_T[2 * HW + pix];
+    med_c = n_contrib[HW + pix];
+    dpix0 = dL_dcolor[pix]; dpix1 = dL_dcolor[HW + pix]; dpix2 = dL_dcolor[2 * HW + pix];
+    if (dL_dallmap) {
+      ddep = dL_dallmap[pix]; dacc = dL_dallmap[HW + pix];
+      dn0 = dL_dallmap[2 * HW + pix]; dn1 = dL_dallmap[3 * HW + pix]; dn2 = dL_dallmap[4 * HW + pix];
+      dmed = dL_dallmap[5 * HW + pix]; dreg = dL_dallmap[6 * HW + pix];
+    }
+  }
+  const float final_A = 1.0f - T_final;
+  const float bg_dot = bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2;
+  const float fn = kFarZ / (kFarZ - kNearZ);
+  if (threadIdx.x == 0) s_max = 0;
+  __syncthreads();
+  atomicMax(&s_max, last);
+  __syncthreads();
+  const uint32_t todo = s_max;
+  float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f, last_dL_dT = 0.0f;
+  for (uint32_t done_n = 0; done_n < todo; done_n += kBatch2) {
+    __syncthreads();
+    const uint32_t top = todo - 1 - done_n;
+    const int cnt = (int)min((uint32_t)kBatch2, todo - done_n);
+    if ((int)threadIdx.x < cnt) {
+      const uint32_t id = point_list[beg + top - threadIdx.x];
+      const float4 *src = reinterpret_cast<const float4 *>(rec + id);
+#pragma unroll
+      for (int q = 0; q < 5; q++) s_r[q][threadIdx.x] = src[q];
+      s_id[threadIdx.x] = id;
+    }
+    __syncthreads();
+    for (int q = 0; q < cnt; q += 64) {
+      const int j = q + lane;
+      const bool hit = j < cnt && box_hit(s_r[2][j], s_r[4][j], bx0, bx1, by0, by1);
+      uint64_t mask = __ballot(hit);
+      while (mask) {
+        const int jj = q + __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t pos1 = top - (uint32_t)jj + 1u;
+        const float4 r0 = s_r[0][jj], r1 = s_r[1][jj], r2 = s_r[2][jj];
+        Hit2 h;
+        const bool valid = eval_hit2(r0, r1, r2, pxf, pyf, h) && pos1 <= last;
+        if (__ballot(valid) == 0) continue;
+        float g[18];
+#pragma unroll
+        for (int q2 = 0; q2 < 18; q2++) g[q2] = 0.0f;
+        if (valid) {
+          const float4 r3 = s_r[3][jj], r4 = s_r[4][jj];
+          const float Tw0 = r1.z, Tw1 = r1.w;
+          const float rinv = __builtin_amdgcn_rcpf(1.0f - h.alpha);
+          T *= rinv;
+          const float w = h.alpha * T;
+          // the five "blended behind" recurrences (colour, depth, alpha, normal) only ever appear dotted with this
+          // pixel's upstream gradient, so one scalar recurrence carries them all (see gs3d_backward.hip)
+          R = last_alpha * (s_last - R) + R;
+          const float sc = r3.w * dpix0 + r4.x * dpix1 + r4.y * dpix2 + h.depth * ddep + dacc + r3.x * dn0 + r3.y * dn1 + r3.z * dn2;
+          float dL_dal = sc - R;
+          s_last = sc;
+          const float m_d = fn * (1.0f - kNearZ / h.depth);
+          const float dmd_dd = (kFarZ * kNearZ) / ((kFarZ - kNearZ) * h.depth * h.depth);
+          float dL_dz = (pos1 == med_c) ? dmed : 0.0f;
+          const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.0f * m_d * final_D) * dreg;
+          dL_dal += dL_dweight - last_dL_dT;
+          last_dL_dT = dL_dweight * h.alpha + (1.0f - h.alpha) * last_dL_dT;
+          dL_dz += 2.0f * w * (m_d * final_A - final_D) * dreg * dmd_dd;
+          dL_dal *= T;
+          last_alpha = h.alpha;
+          dL_dal -= T_final * rinv * bg_dot;
+          const float dL_dG = r2.w * dL_dal;
+          dL_dz += w * ddep;
+          if (h.use3d) {
+            const float ds0 = dL_dG * -h.G * h.s0 + dL_dz * Tw0, ds1 = dL_dG * -h.G * h.s1 + dL_dz * Tw1;
+            const float q0 = ds0 / h.pz, q1 = ds1 / h.pz;
+            const float dp0 = q0, dp1 = q1, dp2 = -(q0 * h.s0 + q1 * h.s1);
+            const float dk0 = h.l[1] * dp2 - h.l[2] * dp1, dk1 = h.l[2] * dp0 - h.l[0] * dp2, dk2 = h.l[0] * dp1 - h.l[1] * dp0;
+            const float dl0 = dp1 * h.k[2] - dp2 * h.k[1], dl1 = dp2 * h.k[0] - dp0 * h.k[2], dl2 = dp0 * h.k[1] - dp1 * h.k[0];
+            g[0] = -dk0; g[1] = -dk1; g[2] = -dk2;
+            g[3] = -dl0; g[4] = -dl1; g[5] = -dl2;
+            g[6] = pxf * dk0 + pyf * dl0 + dL_dz * h.s0;
+            g[7] = pxf * dk1 + pyf * dl1 + dL_dz * h.s1;
+            g[8] = pxf * dk2 + pyf * dl2 + dL_dz;
+          } else {
+            g[9] = dL_dG * (-h.G * kFilterInvSq * h.dx);
+            g[10] = dL_dG * (-h.G * kFilterInvSq * h.dy);
+            g[8] = dL_dz;
+          }
+          g[11] = w * dn0; g[12] = w * dn1; g[13] = w * dn2;
+          g[14] = h.G * dL_dal;
+          g[15] = w * dpix0; g[16] = w * dpix1; g[17] = w * dpix2;
+        }
+        float v = 0.0f;
+#pragma unroll
+        for (int q2 = 0; q2 < 18; q2++) {
+          const float s = wave_sum(g[q2]);
+          v = lane == q2 ? s : v;
+        }
+        if (lane < 18) atomicAdd(acc + (size_t)s_id[jj] * kAcc2Stride + lane, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int DEG, bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const BinRec *__restrict__ bin,
+                             const float *__restrict__ acc, ScorpGs3dGrads g) {
+  __shared__ float s_sh[256 * kShStride];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool active = i < a.N;
+  const size_t i0 = (size_t)blockIdx.x * 256;
+  const int nrows = min(256, a.N - (int)i0);
+  constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
+  const int32_t rad_bits = active ? bin[i].radius : 0;
+  const bool visible = (rad_bits & kRadiusMask) != 0;
+  const bool want_sh_grad = a.shs != nullptr && g.shs != nullptr;
+  bool staged = false;
+  if (a.shs) {
+    if (__syncthreads_or(visible ? 1 : 0)) {
+      stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows);
+      staged = true;
+    }
+    __syncthreads();
+  }
+  float vm[16], pm[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
+  float gm[3] = {0, 0, 0}, gs[2] = {0, 0}, gq[4] = {0, 0, 0, 0}, gT[9], gm2[2] = {0, 0}, grgb[3] = {0, 0, 0}, g_op = 0;
+#pragma unroll
+  for (int q = 0; q < 9; q++) gT[q] = 0.0f;
+  float *row = s_sh + threadIdx.x * kShStride;
+  if (visible) {
+    const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAcc2Stride);
+    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+    gT[0] = a0.x; gT[1] = a0.y; gT[2] = a0.z; gT[3] = a0.w; gT[4] = a1.x; gT[5] = a1.y; gT[6] = a1.z; gT[7] = a1.w; gT[8] = a2.x;
+    const float gx = a2.y, gy = a2.z;
+    const float gn[3] = {a2.w, a3.x, a3.y};
+    g_op = a3.z;
+    grgb[0] = a3.w; grgb[1] = a4.x; grgb[2] = a4.y;
+    const float4 *rp = reinterpret_cast<const float4 *>(rec + i);
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+    const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
+    const float depth = __uint_as_float(bin[i].depth_bits);
+    gm2[0] = gT[2] * depth * 0.5f * a.W;   // densification statistic (gs2dgs/scene/gaussian_model.py:495 consumes it)
+    gm2[1] = gT[5] * depth * 0.5f * a.H;
+    if (gx != 0.0f || gy != 0.0f) {        // the low-pass centre is the centre of the 3-sigma box, a function of T
+      const float c2 = kCutoff * kCutoff;
+      const float t[3] = {c2, c2, -1.0f};
+      const float dd = t[0] * Tw[0] * Tw[0] + t[1] * Tw[1] * Tw[1] + t[2] * Tw[2] * Tw[2];
+      float dLdd = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const float f = t[q] / dd;
+        gT[q] += gx * f * Tw[q];
+        gT[3 + q] += gy * f * Tw[q];
+        gT[6 + q] += gx * f * Tu[q] + gy * f * Tv[q];
+        dLdd += (gx * Tu[q] * Tw[q] + gy * Tv[q] * Tw[q]) * f;
+      }
+      dLdd *= -1.0f / dd;
+#pragma unroll
+      for (int q = 0; q < 3; q++) gT[6 + q] += dLdd * 2.0f * t[q] * Tw[q];
+    }
+    if (a.raw & 1) {
+      const float o = act_opacity(a.opacities[i], a.raw);
+      g_op *= o * (1.0f - o);
+    }
+    const float p0 = a.means3D[3 * (size_t)i], p1 = a.means3D[3 * (size_t)i + 1], p2 = a.means3D[3 * (size_t)i + 2];
+    if (!a.transmat) {
+      float Q[3][4], R[9], inv_qn;
+      pixel_rows(pm, a.W, a.H, Q);
+      const float4 qn = act_quat(reinterpret_cast<const float4 *>(a.rotations)[i], a.raw, &inv_qn);
+      quat_R(qn, R);
+      const float sa0 = act_scale(a.scales[2 * (size_t)i], a.raw), sa1 = act_scale(a.scales[2 * (size_t)i + 1], a.raw);
+      const float sx = a.scale_mod * sa0, sy = a.scale_mod * sa1;
+      float gh[3][3];
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) gh[j][c] = gT[0 * 3 + j] * Q[0][c] + gT[1 * 3 + j] * Q[1][c] + gT[2 * 3 + j] * Q[2][c];
+#pragma unroll
+      for (int c = 0; c < 3; c++) gm[c] = gh[2][c];
+      const float mult = ((rad_bits >> kFlipBit) & 1) ? -1.0f : 1.0f;
+      float gtn[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) gtn[c] = mult * (vm[c * 4 + 0] * gn[0] + vm[c * 4 + 1] * gn[1] + vm[c * 4 + 2] * gn[2]);
+      float gR[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++) { gR[r * 3 + 0] = gh[0][r] * sx; gR[r * 3 + 1] = gh[1][r] * sy; gR[r * 3 + 2] = gtn[r]; }
+      gs[0] = a.scale_mod * (gh[0][0] * R[0] + gh[0][1] * R[3] + gh[0][2] * R[6]);
+      gs[1] = a.scale_mod * (gh[1][0] * R[1] + gh[1][1] * R[4] + gh[1][2] * R[7]);
+      if (a.raw & 2) { gs[0] *= sa0; gs[1] *= sa1; }
+      const float r_ = qn.x, x = qn.y, y = qn.z, z = qn.w;
+      gq[0] = 2 * (-z * gR[1] + y * gR[2] + z * gR[3] - x * gR[5] - y * gR[6] + x * gR[7]);
+      gq[1] = 2 * (y * gR[1] + z * gR[2] + y * gR[3] - 2 * x * gR[4] - r_ * gR[5] + z * gR[6] + r_ * gR[7] - 2 * x * gR[8]);
+      gq[2] = 2 * (-2 * y * gR[0] + x * gR[1] + r_ * gR[2] + x * gR[3] + z * gR[5] - r_ * gR[6] + z * gR[7] - 2 * y * gR[8]);
+      gq[3] = 2 * (-2 * z * gR[0] - r_ * gR[1] + x * gR[2] + r_ * gR[3] - 2 * z * gR[4] + y * gR[5] + x * gR[6] + y * gR[7]);
+      if (a.raw & 4) {
+        const float dotq = r_ * gq[0] + x * gq[1] + y * gq[2] + z * gq[3];
+        gq[0] = (gq[0] - r_ * dotq) * inv_qn; gq[1] = (gq[1] - x * dotq) * inv_qn;
+        gq[2] = (gq[2] - y * dotq) * inv_qn; gq[3] = (gq[3] - z * dotq) * inv_qn;
+      }
+    }
+    if (a.shs) {
+      const float d0 = p0 - a.campos[0], d1 = p1 - a.campos[1], d2_ = p2 - a.campos[2];
+      const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2_ * d2_);
+      const float x = d0 * inv, y = d1 * inv, z = d2_ * inv;
+      float gdir[3] = {0, 0, 0}, gr3[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) gr3[ch] = ((rad_bits >> (kClampShift + ch)) & 1) ? 0.0f : grgb[ch];
+      sh_row_backward<DEG>(row, x, y, z, gr3, want_sh_grad, gdir);
+      const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
+      gm[0] += (gdir[0] - x * dot) * inv; gm[1] += (gdir[1] - y * dot) * inv; gm[2] += (gdir[2] - z * dot) * inv;
+    }
+  } else if (want_sh_grad && active) {
+#pragma unroll
+    for (int c = 0; c < 48; c++) row[c] = 0.0f;
+  }
+  if (active) {
+    if (g.means3D) { g.means3D[3 * (size_t)i] = gm[0]; g.means3D[3 * (size_t)i + 1] = gm[1]; g.means3D[3 * (size_t)i + 2] = gm[2]; }
+    if (g.means2D) { g.means2D[3 * (size_t)i] = gm2[0]; g.means2D[3 * (size_t)i + 1] = gm2[1]; g.means2D[3 * (size_t)i + 2] = 0.0f; }
+    if (g.colors_precomp) { g.colors_precomp[3 * (size_t)i] = grgb[0]; g.colors_precomp[3 * (size_t)i + 1] = grgb[1]; g.colors_precomp[3 * (size_t)i + 2] = grgb[2]; }
+    if (g.opacities) g.opacities[i] = g_op;
+    if (g.scales) { g.scales[2 * (size_t)i] = gs[0]; g.scales[2 * (size_t)i + 1] = gs[1]; }
+    if (g.rotations) reinterpret_cast<float4 *>(g.rotations)[i] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+    if (g.cov3D_precomp) {
+#pragma unroll
+      for (int q = 0; q < 9; q++) g.cov3D_precomp[9 * (size_t)i + q] = gT[q];
+    }
+  }
+  if (want_sh_grad) {
+    if (!staged && active) {
+#pragma unroll
+      for (int c = 0; c < 48; c++) row[c] = 0.0f;
+    }
+    __syncthreads();
+    unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
+  }
+}
+
+Pg2Args make_args2(const ScorpGs3dInputs *in, const StateLayout &L) {
+  Pg2Args a;
+  a.N = in->num_gaussians; a.K = in->sh_coeffs; a.W = in->image_width; a.H = in->image_height;
+  a.tiles_x = L.tiles_x; a.tiles_y = L.tiles_y; a.raw = in->raw_params; a.count_with_atomics = L.lds_binning ? 0 : 1;
+  a.scale_mod = in->scale_modifier;
+  a.view = in->viewmatrix; a.proj = in->projmatrix; a.campos = in->campos;
+  a.means3D = in->means3D; a.shs = in->shs; a.shs_rest = in->shs_rest; a.colors_precomp = in->colors_precomp;
+  a.opacities = in->opacities; a.scales = in->scales; a.rotations = in->rotations; a.transmat = in->cov3D_precomp;
+  return a;
+}
+
+int validate2(const ScorpGs3dInputs *in) {
+  if (!in) { set_error("inputs is NULL"); return SCORP_ERR_INVALID; }
+  if (in->num_gaussians < 0 || in->image_width <= 0 || in->image_height <= 0) { set_error("bad sizes"); return SCORP_ERR_INVALID; }
+  if (in->num_gaussians > 0) {
+    if (!in->means3D || !in->opacities) { set_error("means3D / opacities is NULL"); return SCORP_ERR_INVALID; }
+    if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) { set_error("provide exactly one of shs / colors_precomp"); return SCORP_ERR_INVALID; }
+    const bool sr = in->scales != nullptr && in->rotations != nullptr;
+    if (sr == (in->cov3D_precomp != nullptr)) { set_error("provide exactly one of scales+rotations / precomputed transform"); return SCORP_ERR_INVALID; }
+    if (in->shs && (in->sh_degree < 0 || in->sh_degree > 3 || in->sh_coeffs < (in->sh_degree + 1) * (in->sh_degree + 1))) {
+      set_error("bad sh_degree / sh_coeffs"); return SCORP_ERR_INVALID;
+    }
+  }
+  if (!in->bg || !in->viewmatrix || !in->projmatrix || !in->campos) { set_error("bg / matrices / campos is NULL"); return SCORP_ERR_INVALID; }
+  return SCORP_OK;
+}
+
+}  // namespace
+}  // namespace scorp
+
+using namespace scorp;
+
+extern "C" size_t scorp_gs2d_state_bytes(int32_t N, int32_t W, int32_t H) { return StateLayout(N, W, H, true).total; }
+extern "C" size_t scorp_gs2d_backward_scratch_bytes(int32_t N) {
+  return align_up((size_t)(N > 0 ? N : 1) * kAcc2Stride * sizeof(float), 256);
+}
+
+extern "C" int scorp_gs2d_preprocess(const ScorpGs3dInputs *in, int32_t *out_radii, void *state, size_t state_bytes,
+                                     scorp_stream_t stream_) {
+  if (int e = validate2(in)) return e;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = in->num_gaussians;
+  const StateLayout L(N, in->image_width, in->image_height, true);
+  if (!state || state_bytes < L.total || ((uintptr_t)state & 255)) { set_error("state buffer NULL, misaligned or too small"); return SCORP_ERR_INVALID; }
+  if (N > 0 && !out_radii) { set_error("out_radii is NULL"); return SCORP_ERR_INVALID; }
+  char *base = (char *)state;
+  uint32_t *tile_count = (uint32_t *)(base + L.tile_count);
+  if (!L.lds_binning) SCORP_HIP_CHECK(hipMemsetAsync(tile_count, 0, ((size_t)L.tiles + 1) * 4, stream));
+  if (N > 0) {
+    ProfScope prof(kKPreprocess2d, stream);
+    const Pg2Args a = make_args2(in, L);
+    const dim3 grid((N + 255) / 256), block(256);
+    const int deg = in->shs ? in->sh_degree : 0;
+    Surfel *rec = (Surfel *)(base + L.rec);
+    BinRec *bin = (BinRec *)(base + L.bin);
+#define SCORP_L2(D, S) preprocess2d_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, out_radii, tile_count)
+    if (in->shs_rest) { switch (deg) { case 0: SCORP_L2(0, true); break; case 1: SCORP_L2(1, true); break; case 2: SCORP_L2(2, true); break; default: SCORP_L2(3, true); } }
+    else { switch (deg) { case 0: SCORP_L2(0, false); break; case 1: SCORP_L2(1, false); break; case 2: SCORP_L2(2, false); break; default: SCORP_L2(3, false); } }
+#undef SCORP_L2
+    SCORP_KERNEL_CHECK("preprocess_2d", in->debug, stream);
+  }
+  return bin_count_and_scan(L, base, N, in->debug, stream);
+}
+
+extern "C" int scorp_gs2d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
+                                 float *out_color, float *out_allmap, scorp_stream_t stream_) {
+  if (int e = validate2(in)) return e;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
+  const StateLayout L(N, W, H, true);
+  const PairLayout P(capacity);
+  if (!state || ((uintptr_t)state & 255) || !pairs || ((uintptr_t)pairs & 255)) { set_error("state / pairs NULL or misaligned"); return SCORP_ERR_INVALID; }
+  if (capacity > 0xFFFFFFFFull) { set_error("capacity above 2^32-1 pairs"); return SCORP_ERR_INVALID; }
+  if (!out_color || !out_allmap) { set_error("output image pointer is NULL"); return SCORP_ERR_INVALID; }
+  char *base = (char *)state, *pb = (char *)pairs;
+  if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
+  {
+    ProfScope prof(kKBlendForward2d, stream);
+    blend2d_forward_kernel<<<L.tiles, 256, 0, stream>>>(
+        (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
+        (uint32_t)capacity, W, H, L.tiles_x, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
+        (uint32_t *)(base + L.n_contrib));
+  }
+  SCORP_KERNEL_CHECK("blend_forward_2d", in->debug, stream);
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
+                                   const float *dL_dcolor, const float *dL_dallmap, const ScorpGs3dGrads *grads,
+                                   void *scratch, size_t scratch_bytes, scorp_stream_t stream_) {
+  if (!in || !state || !pairs || !grads || !scratch || !dL_dcolor) { set_error("NULL argument to scorp_gs2d_backward"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
+  if (N <= 0) return SCORP_OK;
+  const StateLayout L(N, W, H, true);
+  const PairLayout P(capacity);
+  if (scratch_bytes < scorp_gs2d_backward_scratch_bytes(N) || ((uintptr_t)scratch & 15)) { set_error("2D backward scratch too small or misaligned"); return SCORP_ERR_INVALID; }
+  const char *base = (const char *)state, *pb = (const char *)pairs;
+  float *acc = (float *)scratch;
+  SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAcc2Stride * sizeof(float), stream));
+  {
+    ProfScope prof(kKBlendBackward2d, stream);
+    blend2d_backward_kernel<<<L.tiles, 256, 0, stream>>>(
+        (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
+        (uint32_t)capacity, W, H, L.tiles_x, in->bg, (const float *)(base + L.final_T),
+        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc);
+  }
+  SCORP_KERNEL_CHECK("blend_backward_2d", in->debug, stream);
+  {
+    ProfScope prof(kKPreprocessBackward2d, stream);
+    const Pg2Args a = make_args2(in, L);
+    const dim3 grid((N + 255) / 256), block(256);
+    const int deg = in->shs ? in->sh_degree : 0;
+    const ScorpGs3dGrads g = *grads;
+    const Surfel *rec = (const Surfel *)(base + L.rec);
+    const BinRec *bin = (const BinRec *)(base + L.bin);
+#define SCORP_B2(D, S) preprocess2d_backward_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, acc, g)
+    if (in->shs_rest) { switch (deg) { case 0: SCORP_B2(0, true); break; case 1: SCORP_B2(1, true); break; case 2: SCORP_B2(2, true); break; default: SCORP_B2(3, true); } }
+    else { switch (deg) { case 0: SCORP_B2(0, false); break; case 1: SCORP_B2(1, false); break; case 2: SCORP_B2(2, false); break; default: SCORP_B2(3, false); } }
+#undef SCORP_B2
+  }
+  SCORP_KERNEL_CHECK("preprocess_backward_2d", in->debug, stream);
+  return SCORP_OK;
+}
+
+// xy[N,2], depth[N], T[N,9], normal_opacity[N,4], rgb[N,3], rect[N,4]; any may be NULL (stage-level parity tests)
+extern "C" int scorp_gs2d_debug_geom(const void *state, int32_t N, int32_t W, int32_t H, float *T, float *xy, float *depth,
+                                     float *normal_opacity, float *rgb, int32_t *rect, scorp_stream_t stream_) {
+  if (!state) { set_error("state is NULL"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const StateLayout L(N, W, H, true);
+  if (N <= 0) return SCORP_OK;
+  Surfel *hrec = (Surfel *)malloc((size_t)N * sizeof(Surfel));
+  BinRec *hbin = (BinRec *)malloc((size_t)N * sizeof(BinRec));
+  if (!hrec || !hbin) { free(hrec); free(hbin); set_error("host allocation failed"); return SCORP_ERR_INVALID; }
+  hipError_t e = hipMemcpyAsync(hrec, (const char *)state + L.rec, (size_t)N * sizeof(Surfel), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(hbin, (const char *)state + L.bin, (size_t)N * sizeof(BinRec), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) { free(hrec); free(hbin); set_error("debug_geom copy failed: %s", hipGetErrorString(e)); return SCORP_ERR_HIP; }
+  for (int i = 0; i < N; i++) {
+    const bool vis = (hbin[i].radius & kRadiusMask) != 0;
+    const Surfel z = {};
+    const Surfel &s = vis ? hrec[i] : z;
+    const float t9[9] = {s.r0.x, s.r0.y, s.r0.z, s.r0.w, s.r1.x, s.r1.y, s.r1.z, s.r1.w, s.r2.x};
+    if (T) memcpy(T + 9 * (size_t)i, t9, sizeof(t9));
+    if (xy) { xy[2 * i] = s.r2.y; xy[2 * i + 1] = s.r2.z; }
+    if (depth) { uint32_t b = vis ? hbin[i].depth_bits : 0u; memcpy(depth + i, &b, 4); }
+    if (normal_opacity) { normal_opacity[4 * i] = s.r3.x; normal_opacity[4 * i + 1] = s.r3.y; normal_opacity[4 * i + 2] = s.r3.z; normal_opacity[4 * i + 3] = s.r2.w; }
+    if (rgb) { rgb[3 * i] = s.r3.w; rgb[3 * i + 1] = s.r4.x; rgb[3 * i + 2] = s.r4.y; }
+    if (rect) { rect[4 * i] = vis ? hbin[i].x0 : 0; rect[4 * i + 1] = vis ? hbin[i].y0 : 0; rect[4 * i + 2] = vis ? hbin[i].x1 : 0; rect[4 * i + 3] = vis ? hbin[i].y1 : 0; }
+  }
+  free(hrec); free(hbin);
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs2d_debug_tiles(const void *state, const void *pairs, uint64_t capacity, int32_t N, int32_t W,
+                                      int32_t H, uint32_t *tile_start, uint32_t *point_list, scorp_stream_t stream_) {
+  if (!state || !pairs) { set_error("state / pairs is NULL"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const StateLayout L(N, W, H, true);
+  const PairLayout P(capacity);
+  StateHeader h;
+  SCORP_HIP_CHECK(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, stream));
+  SCORP_HIP_CHECK(hipStreamSynchronize(stream));
+  if (tile_start)
+    SCORP_HIP_CHECK(hipMemcpyAsync(tile_start, (const char *)state + L.tile_start, ((size_t)L.tiles + 1) * 4, hipMemcpyDeviceToHost, stream));
+  const size_t n = h.num_pairs < capacity ? h.num_pairs : (size_t)capacity;
+  if (point_list && n)
+    SCORP_HIP_CHECK(hipMemcpyAsync(point_list, (const char *)pairs + P.list, n * 4, hipMemcpyDeviceToHost, stream));
+  SCORP_HIP_CHECK(hipStreamSynchronize(stream));
+  return SCORP_OK;
+}

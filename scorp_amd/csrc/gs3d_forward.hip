@@ -328,6 +328,57 @@ int validate(const ScorpGs3dInputs *in) {
 }  // namespace
 }  // namespace scorp
 
+namespace scorp {
+int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipStream_t stream) {
+  uint32_t *tile_count = (uint32_t *)(base + L.tile_count);
+  if (L.lds_binning) {
+    const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
+    uint32_t *block_hist = (uint32_t *)(base + L.block_hist);
+    {
+      ProfScope prof(kKCountTiles, stream);
+      count_tiles_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(N, per_block, (const BinRec *)(base + L.bin),
+                                                                        L.tiles, L.tiles_x, block_hist);
+      scan_block_hist_kernel<<<(L.tiles + 63) / 64, 1024, 0, stream>>>(L.nb, L.tiles, block_hist, tile_count);
+    }
+    SCORP_KERNEL_CHECK("count_tiles", debug, stream);
+  }
+  {
+    ProfScope prof(kKScanTiles, stream);
+    scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, (uint32_t *)(base + L.tile_start), L.tiles,
+                                              (StateHeader *)(base + L.header));
+  }
+  SCORP_KERNEL_CHECK("scan_tiles", debug, stream);
+  return SCORP_OK;
+}
+
+int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, char *pb, int N, uint32_t capacity,
+                         int debug, hipStream_t stream) {
+  uint32_t *tile_count = (uint32_t *)(base + L.tile_count), *tile_start = (uint32_t *)(base + L.tile_start);
+  uint64_t *keys = (uint64_t *)(pb + P.keys);
+  uint32_t *point_list = (uint32_t *)(pb + P.list);
+  StateHeader *header = (StateHeader *)(base + L.header);
+  {
+    ProfScope prof(kKScatterPairs, stream);
+    if (L.lds_binning) {
+      const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
+      scatter_pairs_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(
+          N, per_block, (const BinRec *)(base + L.bin), L.tiles, L.tiles_x, (const uint32_t *)(base + L.block_hist),
+          tile_start, keys, capacity, header);
+    } else {
+      scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), tile_count,
+                                                                        tile_start, L.tiles_x, keys, capacity, header);
+    }
+  }
+  SCORP_KERNEL_CHECK("scatter_pairs", debug, stream);
+  {
+    ProfScope prof(kKSortTiles, stream);
+    sort_tiles_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity, kSortLds);
+  }
+  SCORP_KERNEL_CHECK("sort_tiles", debug, stream);
+  return SCORP_OK;
+}
+}  // namespace scorp
+
 using namespace scorp;
 
 extern "C" size_t scorp_gs3d_state_bytes(int32_t N, int32_t W, int32_t H) { return StateLayout(N, W, H).total; }
@@ -352,23 +403,7 @@ extern "C" int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_rad
     launch_preprocess(in, L, (SplatRec *)(base + L.rec), (BinRec *)(base + L.bin), out_radii, tile_count, stream);
     SCORP_KERNEL_CHECK("preprocess", in->debug, stream);
   }
-  if (L.lds_binning) {
-    const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
-    uint32_t *block_hist = (uint32_t *)(base + L.block_hist);
-    {
-      ProfScope prof(kKCountTiles, stream);
-      count_tiles_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(N, per_block, (const BinRec *)(base + L.bin),
-                                                                        L.tiles, L.tiles_x, block_hist);
-      scan_block_hist_kernel<<<(L.tiles + 63) / 64, 1024, 0, stream>>>(L.nb, L.tiles, block_hist, tile_count);
-    }
-    SCORP_KERNEL_CHECK("count_tiles", in->debug, stream);
-  }
-  {
-    ProfScope prof(kKScanTiles, stream);
-    scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, (uint32_t *)(base + L.tile_start), L.tiles,
-                                              (StateHeader *)(base + L.header));
-  }
-  SCORP_KERNEL_CHECK("scan_tiles", in->debug, stream);
+  if (int e = bin_count_and_scan(L, base, N, in->debug, stream)) return e;
   return SCORP_OK;
 }
 
@@ -413,25 +448,7 @@ extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *p
   uint64_t *keys = (uint64_t *)(pb + P.keys);
   uint32_t *point_list = (uint32_t *)(pb + P.list);
   StateHeader *header = (StateHeader *)(base + L.header);
-  {
-    ProfScope prof(kKScatterPairs, stream);
-    if (L.lds_binning) {
-      const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
-      scatter_pairs_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(
-          N, per_block, (const BinRec *)(base + L.bin), L.tiles, L.tiles_x, (const uint32_t *)(base + L.block_hist),
-          tile_start, keys, (uint32_t)capacity, header);
-    } else {
-      scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), tile_count,
-                                                                        tile_start, L.tiles_x, keys, (uint32_t)capacity,
-                                                                        header);
-    }
-  }
-  SCORP_KERNEL_CHECK("scatter_pairs", in->debug, stream);
-  {
-    ProfScope prof(kKSortTiles, stream);
-    sort_tiles_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, (uint32_t)capacity, kSortLds);
-  }
-  SCORP_KERNEL_CHECK("sort_tiles", in->debug, stream);
+  if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
   {
     ProfScope prof(kKBlendForward, stream);
     blend_forward_kernel<true><<<L.tiles, 256, 0, stream>>>(

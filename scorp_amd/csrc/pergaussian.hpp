@@ -1,0 +1,206 @@
+// pergaussian.hpp — device helpers shared by the per-Gaussian kernels of the 3DGS and 2DGS paths:
+// SH constants and evaluation from an LDS-staged row, coalesced staging of SH rows through LDS (see
+// gs3d_pergaussian.hip for the rationale), and the activations of the "raw parameter" convention.
+#pragma once
+#include "common.hpp"
+
+namespace scorp {
+namespace {
+
+constexpr int kShStride = 49;
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+static __device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+static __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+// ---- coalesced staging of the SH rows of one block (rows i0 .. i0+nrows) into LDS, columns [0, NFL) ----
+template <int NFL, bool SPLIT>
+__device__ __forceinline__ void stage_sh_rows(float *__restrict__ lds, const float *__restrict__ shs,
+                                              const float *__restrict__ shs_rest, int K, size_t i0, int nrows) {
+  const int tid = threadIdx.x;
+  if constexpr (!SPLIT) {
+    const int K3 = K * 3;
+    if constexpr (NFL % 4 == 0) {
+      if ((K & 3) == 0) {
+        constexpr int Q = NFL / 4;
+        for (int e = tid; e < nrows * Q; e += 256) {
+          const int r = e / Q, q = e % Q;
+          const float4 v = *reinterpret_cast<const float4 *>(shs + (i0 + r) * K3 + 4 * q);
+          float *d = lds + r * kShStride + 4 * q;
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        return;
+      }
+    }
+    for (int e = tid; e < nrows * NFL; e += 256) {
+      const int r = e / NFL, c = e % NFL;
+      lds[r * kShStride + c] = shs[(i0 + r) * K3 + c];
+    }
+  } else {
+    for (int e = tid; e < nrows * 3; e += 256) {
+      const int r = e / 3, c = e % 3;
+      lds[r * kShStride + c] = shs[(i0 + r) * 3 + c];
+    }
+    if constexpr (NFL > 3) {
+      constexpr int NR = NFL - 3;
+      const int R3 = (K - 1) * 3;
+      if (NR == 45 && R3 == 45 && nrows == 256) {  // whole rows of a full block: one contiguous 16-byte-aligned stream
+        const float4 *src = reinterpret_cast<const float4 *>(shs_rest + i0 * 45);
+        for (int e4 = tid; e4 < 256 * 45 / 4; e4 += 256) {
+          const float4 v = src[e4];
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int f = 4 * e4 + j;
+            lds[(f / 45) * kShStride + 3 + f % 45] = vv[j];
+          }
+        }
+      } else {
+        for (int e = tid; e < nrows * NR; e += 256) {
+          const int r = e / NR, c = e % NR;
+          lds[r * kShStride + 3 + c] = shs_rest[(i0 + r) * R3 + c];
+        }
+      }
+    }
+  }
+}
+
+// ---- the reverse: stream the (gradient) rows back out; columns >= 48 of very wide rows are zero-filled ----
+template <bool SPLIT>
+__device__ __forceinline__ void unstage_sh_rows(const float *__restrict__ lds, float *__restrict__ g_shs,
+                                                float *__restrict__ g_rest, int K, size_t i0, int nrows) {
+  const int tid = threadIdx.x;
+  if constexpr (!SPLIT) {
+    const int K3 = K * 3;
+    if (K == 16) {
+      for (int e = tid; e < nrows * 12; e += 256) {
+        const int r = e / 12, q = e % 12;
+        const float *s = lds + r * kShStride + 4 * q;
+        *reinterpret_cast<float4 *>(g_shs + (i0 + r) * 48 + 4 * q) = make_float4(s[0], s[1], s[2], s[3]);
+      }
+    } else {
+      for (int e = tid; e < nrows * K3; e += 256) {
+        const int r = e / K3, c = e % K3;
+        g_shs[(i0 + r) * K3 + c] = c < 48 ? lds[r * kShStride + c] : 0.0f;
+      }
+    }
+  } else {
+    for (int e = tid; e < nrows * 3; e += 256) {
+      const int r = e / 3, c = e % 3;
+      g_shs[(i0 + r) * 3 + c] = lds[r * kShStride + c];
+    }
+    const int R3 = (K - 1) * 3;
+    if (R3 == 45 && nrows == 256) {
+      float4 *dst = reinterpret_cast<float4 *>(g_rest + i0 * 45);
+      for (int e4 = tid; e4 < 256 * 45 / 4; e4 += 256) {
+        float vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int f = 4 * e4 + j;
+          vv[j] = lds[(f / 45) * kShStride + 3 + f % 45];
+        }
+        dst[e4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
+    } else if (R3 > 0) {
+      for (int e = tid; e < nrows * R3; e += 256) {
+        const int r = e / R3, c = e % R3;
+        g_rest[(i0 + r) * R3 + c] = c < 45 ? lds[r * kShStride + 3 + c] : 0.0f;
+      }
+    }
+  }
+}
+
+// SH -> RGB + 0.5 from a staged row (gs3dgs/utils/sh_utils.py:57-112 restated for [K,3] rows)
+template <int DEG>
+__device__ __forceinline__ void sh_row_to_rgb(const float *__restrict__ sh, float x, float y, float z, float *rgb) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float r = SH_C0 * sh[c];
+    if constexpr (DEG > 0) {
+      r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+      if constexpr (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        r = r + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] + SH_C2[2] * (2 * zz - xx - yy) * sh[18 + c] +
+            SH_C2[3] * xz * sh[21 + c] + SH_C2[4] * (xx - yy) * sh[24 + c];
+        if constexpr (DEG > 2) {
+          r = r + SH_C3[0] * y * (3 * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
+              SH_C3[2] * y * (4 * zz - xx - yy) * sh[33 + c] + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[36 + c] +
+              SH_C3[4] * x * (4 * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
+              SH_C3[6] * x * (xx - 3 * yy) * sh[45 + c];
+        }
+      }
+    }
+    rgb[c] = r + 0.5f;
+  }
+}
+
+
+// Backward of sh_row_to_rgb for one staged row: gr[ch] = dL/d(colour ch) after the clamp mask.  Accumulates
+// dL/d(unit direction) into gdir and, if write_grad, overwrites the row IN PLACE with dL/d(coefficients)
+// (each channel's coefficients are consumed before they are overwritten).
+template <int DEG>
+__device__ __forceinline__ void sh_row_backward(float *__restrict__ row, float x, float y, float z, const float *gr3,
+                                                bool write_grad, float *gdir) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        float basis[16];
+        basis[0] = SH_C0;
+        if constexpr (DEG > 0) { basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x; }
+        if constexpr (DEG > 1) {
+          basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz; basis[6] = SH_C2[2] * (2 * zz - xx - yy);
+          basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
+        }
+        if constexpr (DEG > 2) {
+          basis[9] = SH_C3[0] * y * (3 * xx - yy); basis[10] = SH_C3[1] * xy * z;
+          basis[11] = SH_C3[2] * y * (4 * zz - xx - yy); basis[12] = SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy);
+          basis[13] = SH_C3[4] * x * (4 * zz - xx - yy); basis[14] = SH_C3[5] * z * (xx - yy);
+          basis[15] = SH_C3[6] * x * (xx - 3 * yy);
+        }
+  #pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          const float gr = gr3[ch];
+          float rx = 0, ry = 0, rz = 0;
+          if constexpr (DEG > 0) {
+            const float s1_ = row[3 + ch], s2_ = row[6 + ch], s3_ = row[9 + ch];
+            rx = -SH_C1 * s3_; ry = -SH_C1 * s1_; rz = SH_C1 * s2_;
+          }
+          if constexpr (DEG > 1) {
+            const float s4 = row[12 + ch], s5 = row[15 + ch], s6 = row[18 + ch], s7 = row[21 + ch], s8 = row[24 + ch];
+            rx += SH_C2[0] * y * s4 + SH_C2[2] * 2 * -x * s6 + SH_C2[3] * z * s7 + SH_C2[4] * 2 * x * s8;
+            ry += SH_C2[0] * x * s4 + SH_C2[1] * z * s5 + SH_C2[2] * 2 * -y * s6 + SH_C2[4] * 2 * -y * s8;
+            rz += SH_C2[1] * y * s5 + SH_C2[2] * 4 * z * s6 + SH_C2[3] * x * s7;
+          }
+          if constexpr (DEG > 2) {
+            const float s9 = row[27 + ch], s10 = row[30 + ch], s11 = row[33 + ch], s12 = row[36 + ch], s13 = row[39 + ch],
+                        s14 = row[42 + ch], s15 = row[45 + ch];
+            rx += SH_C3[0] * s9 * 6 * xy + SH_C3[1] * s10 * yz + SH_C3[2] * s11 * -2 * xy + SH_C3[3] * s12 * -6 * xz +
+                  SH_C3[4] * s13 * (-3 * xx + 4 * zz - yy) + SH_C3[5] * s14 * 2 * xz + SH_C3[6] * s15 * 3 * (xx - yy);
+            ry += SH_C3[0] * s9 * 3 * (xx - yy) + SH_C3[1] * s10 * xz + SH_C3[2] * s11 * (-3 * yy + 4 * zz - xx) +
+                  SH_C3[3] * s12 * -6 * yz + SH_C3[4] * s13 * -2 * xy + SH_C3[5] * s14 * -2 * yz + SH_C3[6] * s15 * -6 * xy;
+            rz += SH_C3[1] * s10 * xy + SH_C3[2] * s11 * 8 * yz + SH_C3[3] * s12 * 3 * (2 * zz - xx - yy) +
+                  SH_C3[4] * s13 * 8 * xz + SH_C3[5] * s14 * (xx - yy);
+          }
+          gdir[0] += rx * gr; gdir[1] += ry * gr; gdir[2] += rz * gr;
+          // the coefficients of this channel are consumed: overwrite them in place with their gradients
+          if (write_grad) {
+  #pragma unroll
+            for (int k = 0; k < 16; k++) row[3 * k + ch] = k < (DEG + 1) * (DEG + 1) ? basis[k] * gr : 0.0f;
+          }
+        }
+}
+
+// activations of the raw-parameter convention (gaussian_model.py:37-45: sigmoid, exp, F.normalize)
+__device__ __forceinline__ float act_opacity(float v, int raw) { return (raw & 1) ? 1.0f / (1.0f + expf(-v)) : v; }
+__device__ __forceinline__ float act_scale(float v, int raw) { return (raw & 2) ? expf(v) : v; }
+__device__ __forceinline__ float4 act_quat(float4 q, int raw, float *inv_norm) {
+  if (!(raw & 4)) { *inv_norm = 1.0f; return q; }
+  const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  const float inv = 1.0f / fmaxf(n, 1e-12f);
+  *inv_norm = inv;
+  return make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+}
+
+}  // namespace
+}  // namespace scorp

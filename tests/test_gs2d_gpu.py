@@ -1,0 +1,143 @@
+"""GPU parity tests of the 2DGS (surfel) path against the CPU oracle, through the diff_surfel_rasterization shim."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_oracle2d_cpu import make_case2d
+
+pytestmark = pytest.mark.gpu
+IMG_L1_TOL = 1e-4
+GRAD_REL_TOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from scorp_amd import _C
+    _C.lib()
+    return torch.device("cuda:0")
+
+
+def hip_render2d(kw, dev, requires_grad=True):
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    T = lambda a, rg=False: None if a is None else torch.tensor(a, device=dev, requires_grad=rg and requires_grad)
+    N = kw["means3D"].shape[0]
+    t = dict(means3D=T(kw["means3D"], True), opacities=T(kw["opacities"].reshape(N, 1), True), shs=T(kw.get("shs"), True),
+             colors_precomp=T(kw.get("colors_precomp"), True), scales=T(kw.get("scales"), True),
+             rotations=T(kw.get("rotations"), True))
+    means2D = torch.zeros(N, 3, device=dev, requires_grad=requires_grad)
+    s = GaussianRasterizationSettings(
+        image_height=kw["H"], image_width=kw["W"], tanfovx=kw["tanfovx"], tanfovy=kw["tanfovy"], bg=T(kw["bg"]),
+        scale_modifier=kw.get("scale_modifier", 1.0), viewmatrix=T(kw["view"]), projmatrix=T(kw["proj"]),
+        sh_degree=kw.get("sh_degree", 0), campos=T(kw["campos"]), prefiltered=False, debug=False)
+    out = GaussianRasterizer(raster_settings=s)(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"],
+                                                colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"],
+                                                cov3D_precomp=None)
+    t["means2D"] = means2D
+    return out, t
+
+
+def assert_radii_match(got, ref):
+    """Bit-exact, except that a surfel grazing the camera plane has an extent of 1e4+ px whose ceil() may flip on the
+    last ulp of a cancelling difference (cx^2 - sum f Tu^2); its tile rectangle is clamped to the image either way."""
+    bad = got != ref
+    assert ((got > 0) == (ref > 0)).all()
+    if bad.any():
+        assert bad.mean() < 1e-3 and (np.abs(got - ref)[bad] <= 1).all() and (ref[bad] > 4096).all()
+
+
+CASES = {
+    "sh3_bg": dict(N=3000, W=160, H=120, deg=3, seed=1, bg=(0.2, 0.5, 0.7)),
+    "sh2_ragged": dict(N=4000, W=137, H=91, deg=2, seed=2, log_scale=math.log(0.06)),
+    "sh0_maxdeg0": dict(N=2000, W=128, H=72, deg=0, seed=9, max_deg=0),
+    "precomp_color": dict(N=3000, W=128, H=66, deg=0, seed=3, precomp_color=True),
+    "inside_cloud": dict(N=5000, W=80, H=80, deg=3, seed=7, radius=1.5),
+    "tiny_surfels": dict(N=20000, W=256, H=192, deg=1, seed=5, log_scale=math.log(0.006)),   # low-pass branch
+    "scale_mod": dict(N=2000, W=96, H=96, deg=1, seed=8, scale_modifier=1.4),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_backward_parity_2d(name, dev):
+    from oracle.gs_oracle import OracleRender2D
+    kw, _ = make_case2d(**CASES[name])
+    o = OracleRender2D(np.float32, **kw)
+    assert o.num_pairs > 0
+    out, t = hip_render2d(kw, dev)
+    color, radii, allmap = out
+    assert_radii_match(radii.cpu().numpy(), o.radii)
+    c, am = color.detach().cpu().numpy(), allmap.detach().cpu().numpy()
+    assert np.abs(c - o.color).mean() < IMG_L1_TOL and np.abs(c - o.color).max() < 2e-2
+    for ch in range(7):
+        scale = max(np.abs(o.allmap[ch]).max(), 1.0)
+        assert np.abs(am[ch] - o.allmap[ch]).mean() / scale < IMG_L1_TOL, f"allmap channel {ch}"
+    rng = np.random.default_rng(CASES[name]["seed"] + 99)
+    wc = rng.normal(0, 1, c.shape).astype(np.float32)
+    wa = rng.normal(0, 1, am.shape).astype(np.float32)
+    wa[5] *= 0.1                                    # median depth: a discontinuous selection, keep its weight modest
+    ((color * torch.tensor(wc, device=dev)).sum() + (allmap * torch.tensor(wa, device=dev)).sum()).backward()
+    g = o.backward(wc, wa)
+
+    def close(nm, got, ref):
+        got = got.detach().cpu().numpy().reshape(ref.shape)
+        scale = max(np.abs(ref).max(), 1e-20)
+        err = np.abs(got - ref).max() / scale
+        assert err < GRAD_REL_TOL, f"grad {nm}: {err:.3e} of {scale:.3e}"
+    close("means3D", t["means3D"].grad, g["means3D"])
+    close("means2D", t["means2D"].grad, g["means2D"])
+    close("opacities", t["opacities"].grad, g["opacities"])
+    close("scales", t["scales"].grad, g["scales"])
+    close("rotations", t["rotations"].grad, g["rotations"])
+    if t["shs"] is not None:
+        close("shs", t["shs"].grad, g["shs"])
+    else:
+        close("colors", t["colors_precomp"].grad, g["colors_precomp"])
+
+
+def test_stage_parity_2d(dev):
+    """Surfel transforms, centres, normals match the oracle to rounding; radii, rectangles, pair count and the
+    per-tile sorted lists match exactly."""
+    from oracle.gs_oracle import OracleRender2D
+    from scorp_amd import _C, rasterizer3d as R
+    kw, _ = make_case2d(**CASES["sh3_bg"])
+    o = OracleRender2D(np.float32, **kw)
+    L = _C.lib()
+    T = lambda a: None if a is None else torch.tensor(a, device=dev)
+    N, W, H = kw["means3D"].shape[0], kw["W"], kw["H"]
+    s = R.GaussianRasterizationSettings(H, W, kw["tanfovx"], kw["tanfovy"], T(kw["bg"]), 1.0, T(kw["view"]), T(kw["proj"]),
+                                        kw["sh_degree"], T(kw["campos"]), False, True)
+    ten = {k: T(kw.get(k)) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    keep = []
+    args = R._inputs_struct(s, ten["means3D"], ten["shs"], None, ten["opacities"], ten["scales"], ten["rotations"], None, keep)
+    sb = L.scorp_gs2d_state_bytes(N, W, H)
+    state = torch.empty(sb, dtype=torch.uint8, device=dev)
+    radii = torch.empty(N, dtype=torch.int32, device=dev)
+    _C.check(L.scorp_gs2d_preprocess(ctypes.byref(args), R._ptr(radii), R._ptr(state), sb, R._stream()), "pre")
+    n = ctypes.c_uint64()
+    _C.check(L.scorp_gs3d_num_pairs(R._ptr(state), R._stream(), ctypes.byref(n)), "num")
+    assert n.value == o.num_pairs
+    pairs = torch.empty(L.scorp_gs3d_pairs_bytes(max(n.value, 1)), dtype=torch.uint8, device=dev)
+    color = torch.empty(3, H, W, device=dev); allmap = torch.empty(7, H, W, device=dev)
+    _C.check(L.scorp_gs2d_render(ctypes.byref(args), R._ptr(state), R._ptr(pairs), max(n.value, 1), R._ptr(color), R._ptr(allmap), R._stream()), "render")
+    Tm = np.zeros((N, 9), np.float32); xy = np.zeros((N, 2), np.float32); depth = np.zeros(N, np.float32)
+    no = np.zeros((N, 4), np.float32); rgb = np.zeros((N, 3), np.float32); rect = np.zeros((N, 4), np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _C.check(L.scorp_gs2d_debug_geom(state.data_ptr(), N, W, H, p(Tm), p(xy), p(depth), p(no), p(rgb), p(rect), R._stream()), "geom")
+    g = o.geom()
+    assert_radii_match(radii.cpu().numpy(), o.radii)
+    np.testing.assert_array_equal(rect, g["rect"])
+    np.testing.assert_array_equal(depth, g["depth"])
+    vis = o.radii > 0                                 # the oracle keeps T of surfels it culls later; compare visible ones
+    np.testing.assert_allclose(Tm[vis], g["T"][vis], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(xy, g["xy"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(no, g["nrm_o"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rgb, g["rgb"], rtol=1e-5, atol=2e-6)
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    ts = np.zeros(tiles + 1, np.uint32); pl = np.zeros(max(n.value, 1), np.uint32)
+    _C.check(L.scorp_gs2d_debug_tiles(state.data_ptr(), pairs.data_ptr(), max(n.value, 1), N, W, H, p(ts), p(pl), R._stream()), "tiles")
+    ots, opl = o.tiles()
+    np.testing.assert_array_equal(ts.astype(np.int64), ots)
+    np.testing.assert_array_equal(pl[: n.value].astype(np.int32), opl)
