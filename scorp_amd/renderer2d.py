@@ -1,0 +1,149 @@
+"""`render()` of the 2DGS path — host-side mirror of gs2dgs/gaussian_renderer/__init__.py:24-170 — and the surfel
+flavour of `GaussianModel` (gs2dgs/scene/gaussian_model.py: 2-D scales :49,136, random initial rotations :137,
+4x4 splat2world `get_covariance` :27-33, densification statistic over all three components :495).
+
+Result dict keys as the reference returns them: render, viewspace_points, visibility_filter, radii, render_alpha,
+render_normal (rotated to world space), render_dist, render_depth (= surf_depth), surf_normal.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .gaussian_model import GaussianModel, build_rotation, inverse_sigmoid
+from .rasterizer2d import GaussianRasterizer, rasterize_surfels_raw
+from .rasterizer3d import GaussianRasterizationSettings
+from .sh import RGB2SH, eval_sh
+
+
+def depths_to_points(view, depthmap):
+    """gs2dgs/utils/point_utils.py:9-24, on the depth map's device."""
+    dev = depthmap.device
+    c2w = (view.world_view_transform.T).inverse()
+    W, H = view.resolution
+    ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], device=dev).float().T
+    projection_matrix = c2w.T @ view.full_proj_transform
+    intrins = (projection_matrix @ ndc2pix)[:3, :3].T
+    grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).float(), torch.arange(H, device=dev).float(), indexing="xy")
+    points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
+    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3]
+    return depthmap.reshape(-1, 1) * rays_d + rays_o
+
+
+def depth_to_normal(view, depth):
+    """Pseudo surface normal from a depth map (point_utils.py:26-37)."""
+    points = depths_to_points(view, depth).reshape(*depth.shape[1:], 3)
+    output = torch.zeros_like(points)
+    dx = points[2:, 1:-1] - points[:-2, 1:-1]
+    dy = points[1:-1, 2:] - points[1:-1, :-2]
+    output[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
+    return output
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx, tanfovy = math.tan(viewpoint_camera.FoVx * 0.5), math.tan(viewpoint_camera.FoVy * 0.5)
+    w, h = viewpoint_camera.resolution
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(h), image_width=int(w), tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+
+    fused = (override_color is None and getattr(pipe, "fused_activations", False) and hasattr(pc, "raw_leaves")
+             and not getattr(pipe, "compute_cov3D_python", False))
+    if fused:
+        f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw = pc.raw_leaves()
+        rendered_image, radii, allmap = rasterize_surfels_raw(xyz, screenspace_points, f_dc, f_rest, opacity_raw,
+                                                              scaling_raw, rotation_raw, raster_settings)
+    else:
+        scales = rotations = cov3D_precomp = None
+        if getattr(pipe, "compute_cov3D_python", False):
+            splat2world = pc.get_covariance(scaling_modifier)
+            W, H = viewpoint_camera.resolution
+            near, far = viewpoint_camera.znear, viewpoint_camera.zfar
+            ndc2pix = torch.tensor([[W / 2, 0, 0, (W - 1) / 2], [0, H / 2, 0, (H - 1) / 2], [0, 0, far - near, near],
+                                    [0, 0, 0, 1]], device=xyz.device).float().T
+            world2pix = viewpoint_camera.full_proj_transform @ ndc2pix
+            cov3D_precomp = (splat2world[:, [0, 1, 3]] @ world2pix[:, [0, 1, 3]]).permute(0, 2, 1).reshape(-1, 9)
+        else:
+            scales, rotations = pc.get_scaling, pc.get_rotation
+        shs = colors_precomp = None
+        if override_color is None:
+            shs = pc.get_features            # the reference forces convert_SHs_python = False (:96)
+        else:
+            colors_precomp = override_color
+        rendered_image, radii, allmap = GaussianRasterizer(raster_settings=raster_settings)(
+            means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp, opacities=pc.get_opacity,
+            scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+
+    rets = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+    render_alpha = allmap[1:2]
+    render_normal = allmap[2:5]
+    render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
+    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
+    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
+    render_dist = allmap[6:7]
+    depth_ratio = getattr(pipe, "depth_ratio", 1.0)
+    surf_depth = render_depth_expected * (1 - depth_ratio) + depth_ratio * render_depth_median
+    surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
+    surf_normal = surf_normal * render_alpha.detach()
+    rets.update({"render_alpha": render_alpha, "render_normal": render_normal, "render_dist": render_dist,
+                 "render_depth": surf_depth, "surf_normal": surf_normal})
+    return rets
+
+
+class GaussianModel2D(GaussianModel):
+    """Surfel parameters: _scaling is [N,2]; everything else as the 3DGS container."""
+
+    @classmethod
+    def from_raw(cls, raw, sh_degree, device="cuda"):
+        assert raw["scaling"].shape[1] == 2, "surfels have two scales"
+        return super().from_raw(raw, sh_degree, device)
+
+    def get_covariance(self, scaling_modifier=1):
+        """4x4 splat2world, transposed storage (gs2dgs/scene/gaussian_model.py:27-33)."""
+        s = torch.cat([self.get_scaling * scaling_modifier, torch.ones_like(self.get_scaling[:, :1])], dim=-1)
+        RS = (build_rotation(self._rotation) * s[:, None, :]).permute(0, 2, 1)
+        trans = torch.zeros((self._xyz.shape[0], 4, 4), dtype=torch.float, device=self._xyz.device)
+        trans[:, :3, :3] = RS
+        trans[:, 3, :3] = self._xyz
+        trans[:, 3, 3] = 1
+        return trans
+
+    def create_from_pcd(self, pcd, spatial_lr_scale: float):
+        from simple_knn._C import distCUDA2
+        self.spatial_lr_scale = spatial_lr_scale
+        pts = torch.tensor(np.asarray(pcd.points)).float().to(self.device)
+        col = RGB2SH(torch.tensor(np.asarray(pcd.colors)).float().to(self.device))
+        K = (self.max_sh_degree + 1) ** 2
+        feats = torch.zeros((col.shape[0], 3, K), device=self.device)
+        feats[:, :3, 0] = col
+        dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 2)
+        rots = torch.rand((pts.shape[0], 4), device=self.device)
+        opac = inverse_sigmoid(0.1 * torch.ones((pts.shape[0], 1), device=self.device))
+        P = lambda t: nn.Parameter(t.contiguous().requires_grad_(True))
+        self._xyz, self._scaling, self._rotation, self._opacity = P(pts), P(scales), P(rots), P(opac)
+        self._features_dc = P(feats[:, :, 0:1].transpose(1, 2))
+        self._features_rest = P(feats[:, :, 1:].transpose(1, 2))
+        self.max_radii2D = torch.zeros(pts.shape[0], device=self.device)
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter], dim=-1, keepdim=True)
+        self.denom[update_filter] += 1
+
+
+def surfel_regularizers(render_pkg, lambda_normal, lambda_dist):
+    """Normal-consistency and depth-distortion terms of train_2dgs.py:142-150."""
+    rend_normal, surf_normal, rend_dist = render_pkg["render_normal"], render_pkg["surf_normal"], render_pkg["render_dist"]
+    normal_loss = lambda_normal * (1 - (rend_normal * surf_normal).sum(dim=0))[None].mean()
+    dist_loss = lambda_dist * rend_dist.mean()
+    return normal_loss, dist_loss

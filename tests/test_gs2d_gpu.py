@@ -141,3 +141,62 @@ def test_stage_parity_2d(dev):
     ots, opl = o.tiles()
     np.testing.assert_array_equal(ts.astype(np.int64), ots)
     np.testing.assert_array_equal(pl[: n.value].astype(np.int32), opl)
+
+
+def test_render2d_dict_fused_vs_reference_convention_and_training_step(dev):
+    """scorp_amd.renderer2d.render: the reference's nine keys; raw-leaf (fused) path == activated path incl. gradients;
+    precomputed-transform branch (compute_cov3D_python) == in-kernel transform; one regularised training step runs."""
+    from scorp_amd.fused_loss import fused_l1_ssim_loss
+    from scorp_amd.gaussian_model import OptimizationParams
+    from scorp_amd.renderer2d import GaussianModel2D, render, surfel_regularizers
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+
+    class Pipe:
+        convert_SHs_python = False
+        compute_cov3D_python = False
+        debug = False
+        depth_ratio = 1.0
+        fused_activations = False
+
+    raw = make_gaussians(5000 + 19, 3, 41, log_scale_mean=math.log(0.05), scale_dims=2)
+    cam = ring_cameras(3, 150, 110, 5, device=dev)[2]
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    wc = torch.randn(3, 110, 150, device=dev, generator=g)
+    res = []
+    for fused in (False, True):
+        pc = GaussianModel2D.from_raw(raw, 3, device=dev)
+        pc.active_sh_degree = 2
+        Pipe.fused_activations = fused
+        r = render(cam, pc, Pipe(), bg)
+        nl, dl = surfel_regularizers(r, 0.05, 100.0)
+        ((r["render"] * wc).sum() + r["render_alpha"].sum() + nl + dl).backward()
+        res.append((r, pc))
+    (r0, p0), (r1, p1) = res
+    assert set(r0) == {"render", "viewspace_points", "visibility_filter", "radii", "render_alpha", "render_normal",
+                       "render_dist", "render_depth", "surf_normal"}
+    assert r0["render_normal"].shape == (3, 110, 150) and r0["surf_normal"].shape == (3, 110, 150)
+    assert torch.equal(r0["radii"], r1["radii"])
+    assert (r0["render"] - r1["render"]).abs().max() < 2e-5
+    for name in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        a, b = getattr(p0, name).grad, getattr(p1, name).grad
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        assert (a - b).abs().max() <= 3e-3 * a.abs().max() + 1e-12, name
+    # precomputed transform branch
+    Pipe.fused_activations = False
+    Pipe.compute_cov3D_python = True
+    with torch.no_grad():
+        r2 = render(cam, p0, Pipe(), bg)
+    assert (r2["render"] - r0["render"]).abs().mean() < 1e-5
+    Pipe.compute_cov3D_python = False
+    # one optimisation step end to end
+    Pipe.fused_activations = True
+    p1.training_setup(OptimizationParams())
+    p1.optimizer.zero_grad(set_to_none=True)
+    r = render(cam, p1, Pipe(), bg)
+    nl, dl = surfel_regularizers(r, 0.05, 100.0)
+    loss = fused_l1_ssim_loss(r["render"], torch.rand(3, 110, 150, device=dev), 0.2) + nl + dl
+    loss.backward()
+    p1.add_densification_stats(r["viewspace_points"], r["visibility_filter"])
+    p1.optimizer.step()
+    assert torch.isfinite(p1._xyz).all() and torch.isfinite(p1._scaling).all() and p1._scaling.shape[1] == 2
