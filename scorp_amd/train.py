@@ -1,0 +1,115 @@
+"""The build's counterparts of the reference's optimisation loops, on synthetic or caller-supplied views:
+
+  training_iteration(...)  one iteration of train_3dgs.py:56-193 (LR schedule, SH-degree schedule, random background,
+                           render, 0.8*L1 + 0.2*(1-SSIM), backward, densification bookkeeping, Adam step)
+  post_refine(...)         the 800-iteration appearance refinement of post_refine_gs.py:30-203: everything frozen
+                           but the colours, masked L1 + SSIM
+
+Dataset I/O, tensorboard and checkpoint plumbing of the scripts are out of scope; the loops take
+cameras and ground-truth tensors that are already resident on the GPU.
+"""
+import random
+
+import torch
+
+from .fused_loss import fused_l1_ssim_loss
+from .loss import psnr
+from .renderer import render
+
+
+class PipelineParams:
+    """Defaults of gs3dgs/arguments/__init__.py:67-72 + this build's fused fast path."""
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+    fused_activations = True
+
+
+def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteration, scene_extent=4.0, densify=True,
+                       render_fn=render):
+    """Returns (loss tensor, render package). Mirrors train_3dgs.py:74-193 for one camera."""
+    gaussians.update_learning_rate(iteration)
+    if iteration % 1000 == 0:
+        gaussians.oneupSHdegree()
+    bg = torch.rand(3, device=background.device) if opt.random_background else background
+    pkg = render_fn(cam, gaussians, pipe, bg)
+    loss = fused_l1_ssim_loss(pkg["render"], gt_image, opt.lambda_dssim)
+    loss.backward()
+    with torch.no_grad():
+        if densify and iteration < opt.densify_until_iter:
+            vis, radii = pkg["visibility_filter"], pkg["radii"]
+            gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis].float())
+            gaussians.add_densification_stats(pkg["viewspace_points"], vis)
+            if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+                size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+                gaussians.densify_and_prune(opt.densify_grad_threshold, 0.005, scene_extent, size_threshold)
+            if iteration % opt.opacity_reset_interval == 0:
+                gaussians.reset_opacity()
+        gaussians.optimizer.step()
+        gaussians.optimizer.zero_grad(set_to_none=True)
+    return loss, pkg
+
+
+def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, background=None, seed=0, **kw):
+    """Runs `iterations` training iterations over shuffled cameras; returns the list of per-iteration losses."""
+    pipe = pipe or PipelineParams()
+    dev = gaussians.get_xyz.device
+    background = torch.zeros(3, device=dev) if background is None else background
+    if gaussians.optimizer is None:
+        gaussians.training_setup(opt)
+    rng = random.Random(seed)
+    stack, losses = [], []
+    for it in range(1, (iterations or opt.iterations) + 1):
+        if not stack:
+            stack = list(range(len(cameras)))
+            rng.shuffle(stack)
+        k = stack.pop()
+        loss, _ = training_iteration(gaussians, cameras[k], gt_images[k], opt, pipe, background, it, **kw)
+        losses.append(loss.detach())
+    return [float(l) for l in losses]
+
+
+def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, pipe=None, background=None, seed=0):
+    """post_refine_gs.py: colours only (`_opacity/_rotation/_scaling/_xyz` frozen, :53-56), SH degree 0 (:47),
+    loss on image*mask vs gt*mask (:103-111).  Returns per-iteration losses."""
+    assert gaussians.max_sh_degree == 0, "post-refinement runs on SH-0 objects (post_refine_gs.py:47)"
+    pipe = pipe or PipelineParams()
+    dev = gaussians.get_xyz.device
+    background = torch.zeros(3, device=dev) if background is None else background
+    if gaussians.optimizer is None:
+        gaussians.training_setup(opt)
+    for name in ("_opacity", "_rotation", "_scaling", "_xyz"):
+        gaussians.set_freeze(name, True)
+    rng = random.Random(seed)
+    stack, losses = [], []
+    for it in range(1, iterations + 1):
+        if not stack:
+            stack = list(range(len(cameras)))
+            rng.shuffle(stack)
+        k = stack.pop()
+        pkg = render(cameras[k], gaussians, pipe, background)
+        loss = fused_l1_ssim_loss(pkg["render"], gt_images[k], opt.lambda_dssim, mask=gt_alphas[k])
+        loss.backward()
+        with torch.no_grad():
+            gaussians.optimizer.step()
+            gaussians.optimizer.zero_grad(set_to_none=True)
+        losses.append(loss.detach())
+    return [float(l) for l in losses]
+
+
+@torch.no_grad()
+def evaluate_psnr(gaussians, cameras, gt_images, pipe=None, background=None):
+    pipe = pipe or PipelineParams()
+    background = torch.zeros(3, device=gaussians.get_xyz.device) if background is None else background
+    vals = [psnr(render(c, gaussians, pipe, background)["render"].clamp(0, 1), g).mean() for c, g in zip(cameras, gt_images)]
+    return float(torch.stack(vals).mean())
+
+
+@torch.no_grad()
+def render_views_gt(gaussians, cameras, with_alpha=False, pipe=None, background=None):
+    """Ground truth for synthetic experiments: renders of a reference model (clamped to [0,1])."""
+    pipe = pipe or PipelineParams()
+    background = torch.zeros(3, device=gaussians.get_xyz.device) if background is None else background
+    pk = [render(c, gaussians, pipe, background) for c in cameras]
+    imgs = [p["render"].clamp(0, 1).clone() for p in pk]
+    return (imgs, [p["render_alpha"].clone() for p in pk]) if with_alpha else imgs
