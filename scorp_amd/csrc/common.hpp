@@ -28,7 +28,7 @@ constexpr float kDet2Eps = 0.0000001f;
 struct alignas(16) SplatRec {
   float x, y, A, B;         // pixel-space centre, conic A,B
   float C, o, r, g;         // conic C, opacity, colour r,g
-  float b, depth, rcut, _;  // colour b, view-space z, alpha>=1/255 cutoff radius (px)
+  float b, depth, kcut, _;  // colour b, view-space z, cutoff: alpha >= 1/255 only where A dx^2 + 2B dx dy + C dy^2 <= kcut
 };
 static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
 
@@ -57,6 +57,47 @@ constexpr int kAccStride = 12;  // dx, dy, dA, dB, dC, dopacity, dr, dg, db, dde
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+#ifdef __HIPCC__
+// Exact culling.  A splat contributes to a pixel only if alpha = o * exp(-q/2) >= 1/255, q = A dx^2 + 2B dx dy + C dy^2,
+// i.e. q <= 2 ln(255 o).  This returns min q over the pixel box [bx0,bx1] x [by0,by1]: 0 if the centre is inside,
+// otherwise the smallest of the four edge minima (q is convex, so the box minimum lies on an edge).  A box whose
+// minimum exceeds the splat's `kcut` (2 ln(255 o) plus 1% + 0.02 of slack) cannot receive a single contributing
+// pixel, so dropping the (box, splat) pair changes no output bit.  Lane-parallel: one lane tests one splat.
+__device__ __forceinline__ float conic_min_over_box(float cx, float cy, float A, float B, float C, float bx0, float bx1,
+                                                    float by0, float by1) {
+  const float x0 = bx0 - cx, x1 = bx1 - cx, y0 = by0 - cy, y1 = by1 - cy;
+  if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return 0.0f;
+  const float iC = 1.0f / C, iA = 1.0f / A;
+  float best = 3.4e38f;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const float xe = e ? x1 : x0;
+    const float dy = fminf(fmaxf(-B * xe * iC, y0), y1);
+    best = fminf(best, A * xe * xe + 2.0f * B * xe * dy + C * dy * dy);
+    const float ye = e ? y1 : y0;
+    const float dx = fminf(fmaxf(-B * ye * iA, x0), x1);
+    best = fminf(best, A * dx * dx + 2.0f * B * dx * ye + C * ye * ye);
+  }
+  return best;
+}
+
+// Tile mask convention: bit (ty - y0) * 8 + (tx - x0) for rectangles of at most 8 x 8 tiles; ~0 = whole rectangle.
+constexpr uint64_t kMaskAll = ~0ull;
+template <typename F>
+__device__ __forceinline__ void for_each_tile(int x0, int y0, int x1, int y1, uint64_t mask, int tiles_x, F f) {
+  if (mask == kMaskAll) {
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) f(y * tiles_x + x);
+  } else {
+    while (mask) {
+      const int b = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      f((y0 + (b >> 3)) * tiles_x + x0 + (b & 7));
+    }
+  }
+}
+#endif
+
 // Forward state layout (one caller-owned blob, 256-byte aligned sub-buffers).
 constexpr int kMaxLdsTiles = 16384;   // per-block tile histograms live in LDS up to this many tiles (64 KiB)
 constexpr int kBinBlocksMax = 512;    // blocks of the LDS-histogram binning (each owns a contiguous Gaussian range)
@@ -64,7 +105,7 @@ constexpr int kBinBlocksMax = 512;    // blocks of the LDS-histogram binning (ea
 inline int bin_blocks(int N) { int b = (N + 1023) / 1024; return b < 1 ? 1 : (b > kBinBlocksMax ? kBinBlocksMax : b); }
 
 struct StateLayout {
-  size_t header, rec, bin, tile_count, tile_start, final_T, n_contrib, block_hist, total;
+  size_t header, rec, bin, tile_mask, tile_count, tile_start, final_T, n_contrib, block_hist, total;
   int tiles_x, tiles_y, tiles, nb;
   bool lds_binning;
   StateLayout(int N, int W, int H, bool mode2d = false) {
@@ -76,6 +117,7 @@ struct StateLayout {
     header = off; off = align_up(off + sizeof(StateHeader), 256);
     rec = off; off = align_up(off + n * (mode2d ? (size_t)80 : sizeof(SplatRec)), 256);
     bin = off; off = align_up(off + n * sizeof(BinRec), 256);
+    tile_mask = off; off = align_up(off + n * 8, 256);   // per splat: which tiles of its (<= 8x8) rectangle it can reach
     tile_count = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
     tile_start = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
     final_T = off; off = align_up(off + hw * 4 * (mode2d ? 3 : 1), 256);     // 2DGS also keeps M1, M2 per pixel
@@ -114,8 +156,8 @@ struct ProfScope {  // brackets one kernel launch with an event pair when profil
 };
 
 // ---- per-Gaussian kernels (gs3d_pergaussian.hip) ----
-void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec *rec, BinRec *bin, int32_t *radii,
-                       uint32_t *tile_count, hipStream_t stream);
+void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec *rec, BinRec *bin, uint64_t *tile_mask,
+                       int32_t *radii, uint32_t *tile_count, hipStream_t stream);
 void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L, const BinRec *bin, const float *acc,
                                 const ScorpGs3dGrads *grads, hipStream_t stream);
 

@@ -57,8 +57,8 @@ __device__ __forceinline__ void quat_R(float4 q, float *R) {
 // ---------------------------------------------------------------------------------------------------------
 template <int DEG, bool SPLIT>
 __global__ void __launch_bounds__(256)
-preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bin, int32_t *__restrict__ radii,
-                    uint32_t *__restrict__ tile_count) {
+preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
+                    int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
 #pragma clang fp contract(off)
   __shared__ float s_sh[256 * kShStride];
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -175,6 +175,7 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
         for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * a.tiles_x + x], 1u);
   }
   reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
+  tile_mask[i] = kMaskAll;  // surfels keep their whole rectangle (the blend kernels cull by bounding box)
   radii[i] = radius_out;
 }
 
@@ -599,7 +600,7 @@ extern "C" int scorp_gs2d_preprocess(const ScorpGs3dInputs *in, int32_t *out_rad
     const int deg = in->shs ? in->sh_degree : 0;
     Surfel *rec = (Surfel *)(base + L.rec);
     BinRec *bin = (BinRec *)(base + L.bin);
-#define SCORP_L2(D, S) preprocess2d_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, out_radii, tile_count)
+#define SCORP_L2(D, S) preprocess2d_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, (uint64_t *)(base + L.tile_mask), out_radii, tile_count)
     if (in->shs_rest) { switch (deg) { case 0: SCORP_L2(0, true); break; case 1: SCORP_L2(1, true); break; case 2: SCORP_L2(2, true); break; default: SCORP_L2(3, true); } }
     else { switch (deg) { case 0: SCORP_L2(0, false); break; case 1: SCORP_L2(1, false); break; case 2: SCORP_L2(2, false); break; default: SCORP_L2(3, false); } }
 #undef SCORP_L2

@@ -80,9 +80,7 @@ blend_backward_body(const uint32_t *__restrict__ tile_start, const uint32_t *__r
       bool hit = false;
       if (j < cnt) {
         const float4 a = s_a[j];
-        const float rc = s_c[j].z;
-        const float ddx = fmaxf(fmaxf(bx0 - a.x, a.x - bx1), 0.0f), ddy = fmaxf(fmaxf(by0 - a.y, a.y - by1), 0.0f);
-        hit = ddx * ddx + ddy * ddy <= rc * rc;
+        hit = conic_min_over_box(a.x, a.y, a.z, a.w, s_b[j].x, bx0, bx1, by0, by1) <= s_c[j].z;
       }
       uint64_t mask = __ballot(hit);
       while (mask) {
@@ -183,7 +181,7 @@ blend_backward_mfma_kernel(const uint32_t *__restrict__ tile_start, const uint32
                            const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
                            const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dalpha,
                            float *__restrict__ acc, int ablate) {
-  // s_a = (x, y, A', B'), s_b = (C', opacity, r, g), s_c = (b, depth, rcut, -): conic pre-scaled for exp2
+  // s_a = (x, y, A', B'), s_b = (C', opacity, r, g), s_c = (b, depth, kcut, -): conic pre-scaled for exp2
   __shared__ float4 s_a[kBatch], s_b[kBatch], s_c[kBatch];
   __shared__ uint32_t s_id[kBatch];
   __shared__ float s_acc[kBatch * kAccStride];
@@ -265,10 +263,9 @@ blend_backward_mfma_kernel(const uint32_t *__restrict__ tile_start, const uint32
       const int j = q + lane;
       bool hit = false;
       if (j < cnt) {
-        const float4 a = s_a[j];
-        const float rc = s_c[j].z;
-        const float ddx = fmaxf(fmaxf(bx0 - a.x, a.x - bx1), 0.0f), ddy = fmaxf(fmaxf(by0 - a.y, a.y - by1), 0.0f);
-        hit = ddx * ddx + ddy * ddy <= rc * rc;
+        const float4 a = s_a[j];  // conic is pre-scaled for exp2: undo it for the cull test
+        hit = conic_min_over_box(a.x, a.y, a.z * (-2.0f / kLog2e), a.w * (-1.0f / kLog2e), s_b[j].x * (-2.0f / kLog2e), bx0,
+                                 bx1, by0, by1) <= s_c[j].z;
       }
       const uint64_t m = __ballot(hit);
       if (hit) list[nh + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)j;

@@ -50,7 +50,8 @@ scan_tiles_kernel(const uint32_t *__restrict__ tile_count, uint32_t *__restrict_
 // so it is clean for the next view). Slot order inside a tile is arbitrary; the sort below fixes it.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, uint32_t *__restrict__ tile_count,
+scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
+                     uint32_t *__restrict__ tile_count,
                      const uint32_t *__restrict__ tile_start, int tiles_x, uint64_t *__restrict__ keys,
                      uint32_t capacity, StateHeader *__restrict__ header) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -63,12 +64,10 @@ scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, uint32_t *__restrict
   const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
   if ((br.radius & kRadiusMask) == 0) return;
   const uint64_t key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
-  for (int y = br.y0; y < br.y1; y++)
-    for (int x = br.x0; x < br.x1; x++) {
-      const int t = y * tiles_x + x;
-      const uint32_t slot = tile_start[t] + atomicSub(&tile_count[t], 1u) - 1u;
-      if (slot < capacity) keys[slot] = key;
-    }
+  for_each_tile(br.x0, br.y0, br.x1, br.y1, tile_mask[i], tiles_x, [&](int t) {
+    const uint32_t slot = tile_start[t] + atomicSub(&tile_count[t], 1u) - 1u;
+    if (slot < capacity) keys[slot] = key;
+  });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -82,8 +81,8 @@ scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, uint32_t *__restrict
 // Slot order inside a tile is arbitrary but deterministic; the per-tile depth sort fixes the final order.
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-count_tiles_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, int tiles, int tiles_x,
-                       uint32_t *__restrict__ block_hist) {
+count_tiles_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
+                       int tiles, int tiles_x, uint32_t *__restrict__ block_hist) {
   extern __shared__ uint32_t s_hist[];
   for (int t = threadIdx.x; t < tiles; t += 256) s_hist[t] = 0;
   __syncthreads();
@@ -92,8 +91,7 @@ count_tiles_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, int
     const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
     const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
     if ((br.radius & kRadiusMask) == 0) continue;
-    for (int y = br.y0; y < br.y1; y++)
-      for (int x = br.x0; x < br.x1; x++) atomicAdd(&s_hist[y * tiles_x + x], 1u);
+    for_each_tile(br.x0, br.y0, br.x1, br.y1, tile_mask[i], tiles_x, [&](int t) { atomicAdd(&s_hist[t], 1u); });
   }
   __syncthreads();
   uint32_t *row = block_hist + (size_t)blockIdx.x * tiles;
@@ -127,7 +125,8 @@ scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uin
 }
 
 __global__ void __launch_bounds__(256)
-scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, int tiles, int tiles_x,
+scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
+                         int tiles, int tiles_x,
                          const uint32_t *__restrict__ block_hist, const uint32_t *__restrict__ tile_start,
                          uint64_t *__restrict__ keys, uint32_t capacity, StateHeader *__restrict__ header) {
   extern __shared__ uint32_t s_cur[];
@@ -144,11 +143,10 @@ scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, i
     const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
     if ((br.radius & kRadiusMask) == 0) continue;
     const uint64_t key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
-    for (int y = br.y0; y < br.y1; y++)
-      for (int x = br.x0; x < br.x1; x++) {
-        const uint32_t slot = atomicAdd(&s_cur[y * tiles_x + x], 1u);
-        if (slot < capacity) keys[slot] = key;
-      }
+    for_each_tile(br.x0, br.y0, br.x1, br.y1, tile_mask[i], tiles_x, [&](int t) {
+      const uint32_t slot = atomicAdd(&s_cur[t], 1u);
+      if (slot < capacity) keys[slot] = key;
+    });
   }
 }
 
@@ -214,7 +212,7 @@ sort_tiles_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict_
 // ---------------------------------------------------------------------------------------------------------
 // K5: front-to-back blend. One workgroup (4 wave64) per 16x16 tile; each wave owns an 8x8 pixel block.
 // Splat records are gathered 256 at a time into LDS; each wave first ballots which of them can reach its 8x8
-// block at all (distance to the block > rcut  =>  alpha < 1/255 on every pixel of the block), then walks only
+// block at all (min of the conic over the block > kcut  =>  alpha < 1/255 on every pixel of the block), then walks only
 // those, reading each record from LDS at a wave-uniform address (broadcast, conflict-free).
 // ---------------------------------------------------------------------------------------------------------
 template <bool kCull>
@@ -252,9 +250,7 @@ blend_forward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__
       if (j < cnt) {
         if (kCull) {
           const float4 a = s_a[j];
-          const float rc = s_c[j].z;
-          const float ddx = fmaxf(fmaxf(bx0 - a.x, a.x - bx1), 0.0f), ddy = fmaxf(fmaxf(by0 - a.y, a.y - by1), 0.0f);
-          hit = ddx * ddx + ddy * ddy <= rc * rc;
+          hit = conic_min_over_box(a.x, a.y, a.z, a.w, s_b[j].x, bx0, bx1, by0, by1) <= s_c[j].z;
         } else {
           hit = true;
         }
@@ -337,7 +333,8 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
     {
       ProfScope prof(kKCountTiles, stream);
       count_tiles_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(N, per_block, (const BinRec *)(base + L.bin),
-                                                                        L.tiles, L.tiles_x, block_hist);
+                                                                        (const uint64_t *)(base + L.tile_mask), L.tiles,
+                                                                        L.tiles_x, block_hist);
       scan_block_hist_kernel<<<(L.tiles + 63) / 64, 1024, 0, stream>>>(L.nb, L.tiles, block_hist, tile_count);
     }
     SCORP_KERNEL_CHECK("count_tiles", debug, stream);
@@ -362,11 +359,12 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
     if (L.lds_binning) {
       const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
       scatter_pairs_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(
-          N, per_block, (const BinRec *)(base + L.bin), L.tiles, L.tiles_x, (const uint32_t *)(base + L.block_hist),
-          tile_start, keys, capacity, header);
+          N, per_block, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
+          (const uint32_t *)(base + L.block_hist), tile_start, keys, capacity, header);
     } else {
-      scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), tile_count,
-                                                                        tile_start, L.tiles_x, keys, capacity, header);
+      scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(
+          N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), tile_count, tile_start, L.tiles_x,
+          keys, capacity, header);
     }
   }
   SCORP_KERNEL_CHECK("scatter_pairs", debug, stream);
@@ -400,7 +398,8 @@ extern "C" int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_rad
   if (!L.lds_binning) SCORP_HIP_CHECK(hipMemsetAsync(tile_count, 0, ((size_t)L.tiles + 1) * 4, stream));
   if (N > 0) {
     ProfScope prof(kKPreprocess, stream);
-    launch_preprocess(in, L, (SplatRec *)(base + L.rec), (BinRec *)(base + L.bin), out_radii, tile_count, stream);
+    launch_preprocess(in, L, (SplatRec *)(base + L.rec), (BinRec *)(base + L.bin), (uint64_t *)(base + L.tile_mask), out_radii,
+                      tile_count, stream);
     SCORP_KERNEL_CHECK("preprocess", in->debug, stream);
   }
   if (int e = bin_count_and_scan(L, base, N, in->debug, stream)) return e;

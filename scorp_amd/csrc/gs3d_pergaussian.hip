@@ -31,8 +31,8 @@ struct PgArgs {
 // ---------------------------------------------------------------------------------------------------------
 template <int DEG, bool SPLIT>
 __global__ void __launch_bounds__(256)
-preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin, int32_t *__restrict__ radii,
-                  uint32_t *__restrict__ tile_count) {
+preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
+                  int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
 #pragma clang fp contract(off)
   __shared__ float s_sh[256 * kShStride];
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -44,7 +44,8 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
   br.x0 = br.y0 = br.x1 = br.y1 = 0; br.depth_bits = 0; br.radius = 0;
   int radius_out = 0;
   bool vis = false;
-  float px_ = 0, py_ = 0, pz_ = 0, tz = 0, sx = 0, sy = 0, cA = 0, cB = 0, cC = 0, op = 0, rcut = 0;
+  float px_ = 0, py_ = 0, pz_ = 0, tz = 0, sx = 0, sy = 0, cA = 0, cB = 0, cC = 0, op = 0, kcut = 0;
+  uint64_t mask = 0;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0, radius = 0;
   if (active) {
     px_ = a.means3D[3 * (size_t)i]; py_ = a.means3D[3 * (size_t)i + 1]; pz_ = a.means3D[3 * (size_t)i + 2];
@@ -116,9 +117,18 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
           vis = true;
           cA = cc * det_inv; cB = -cb * det_inv; cC = ca * det_inv;
           op = act_opacity(a.opacities[i], a.raw);
-          // Beyond rcut the splat's alpha is < 1/255 everywhere (|d|^2 / (2 lambda_max) > ln(255 o)), so a pixel
-          // block farther than rcut can skip it without changing a single output bit. 1% + 0.1 px of slack.
-          rcut = 1.01f * sqrtf(2.0f * lam * logf(fmaxf(255.0f * op, 1.0f))) + 0.1f;
+          // alpha >= 1/255 needs q <= 2 ln(255 o): tiles (here) and 8x8 pixel blocks (blend kernels) whose minimum q
+          // is larger are skipped without changing a single output bit (common.hpp: conic_min_over_box).
+          kcut = 1.01f * 2.0f * logf(fmaxf(255.0f * op, 1.0f)) + 0.02f;
+          if (x1 - x0 <= 8 && y1 - y0 <= 8) {
+            for (int ty = y0; ty < y1; ty++)
+              for (int tx = x0; tx < x1; tx++)
+                if (conic_min_over_box(sx, sy, cA, cB, cC, (float)(tx * kTile), (float)(tx * kTile + kTile - 1),
+                                       (float)(ty * kTile), (float)(ty * kTile + kTile - 1)) <= kcut)
+                  mask |= 1ull << ((ty - y0) * 8 + (tx - x0));
+          } else {
+            mask = kMaskAll;
+          }
         }
       }
     }
@@ -151,16 +161,16 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
     float4 *dst = reinterpret_cast<float4 *>(rec + i);
     dst[0] = make_float4(sx, sy, cA, cB);
     dst[1] = make_float4(cC, op, rgb[0], rgb[1]);
-    dst[2] = make_float4(rgb[2], tz, rcut, 0.0f);
+    dst[2] = make_float4(rgb[2], tz, kcut, 0.0f);
     br.x0 = (uint16_t)x0; br.y0 = (uint16_t)y0; br.x1 = (uint16_t)x1; br.y1 = (uint16_t)y1;
     br.depth_bits = __float_as_uint(tz);
     br.radius = radius | (clamp_bits << kClampShift);
     radius_out = radius;
     if (a.count_with_atomics)  // fallback binning for images with more tiles than an LDS histogram holds
-      for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * a.tiles_x + x], 1u);
+      for_each_tile(x0, y0, x1, y1, mask, a.tiles_x, [&](int t) { atomicAdd(&tile_count[t], 1u); });
   }
   reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
+  tile_mask[i] = mask;
   radii[i] = radius_out;
 }
 
@@ -380,13 +390,13 @@ PgArgs make_args(const ScorpGs3dInputs *in, const StateLayout &L) {
 
 }  // namespace
 
-void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec *rec, BinRec *bin, int32_t *radii,
-                       uint32_t *tile_count, hipStream_t stream) {
+void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec *rec, BinRec *bin, uint64_t *tile_mask,
+                       int32_t *radii, uint32_t *tile_count, hipStream_t stream) {
   const PgArgs a = make_args(in, L);
   const dim3 grid((a.N + 255) / 256), block(256);
   const int deg = in->shs ? in->sh_degree : 0;
   const bool split = in->shs_rest != nullptr;
-#define SCORP_LAUNCH_PRE(D, S) preprocess_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, radii, tile_count)
+#define SCORP_LAUNCH_PRE(D, S) preprocess_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, tile_mask, radii, tile_count)
   if (split) {
     switch (deg) { case 0: SCORP_LAUNCH_PRE(0, true); break; case 1: SCORP_LAUNCH_PRE(1, true); break;
                    case 2: SCORP_LAUNCH_PRE(2, true); break; default: SCORP_LAUNCH_PRE(3, true); }
