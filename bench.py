@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--cams", type=int, default=8, help="distinct cameras (with resident GT images) cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 and collectives go through CPU copies (use with --backend gloo)")
     ap.add_argument("--unfused", action="store_true", help="reference call-site convention: torch activations + cat per view")
     args = ap.parse_args()
 
@@ -121,10 +124,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collective payloads live
 
     from scorp_amd import _C
     from scorp_amd.gaussian_model import GaussianModel
@@ -142,9 +150,9 @@ def main():
         shapes = dict(xyz=(N, 3), scaling=(N, 3), rotation=(N, 4), opacity=(N, 1), features_dc=(N, 1, 3), features_rest=(N, K - 1, 3))
         recv = {}
         for k, shp in shapes.items():
-            t = torch.tensor(raw[k], device=dev) if rank == 0 else torch.empty(shp, dtype=torch.float32, device=dev)
+            t = torch.tensor(raw[k], device=cdev) if rank == 0 else torch.empty(shp, dtype=torch.float32, device=cdev)
             dist.broadcast(t, src=0)
-            recv[k] = t
+            recv[k] = t.to(dev)
         model = GaussianModel(deg, device=dev)
         P = lambda t: torch.nn.Parameter(t.contiguous().requires_grad_(True))
         model._xyz, model._features_dc, model._features_rest = P(recv["xyz"]), P(recv["features_dc"]), P(recv["features_rest"])
@@ -203,10 +211,10 @@ def main():
     _C.prof_enable(False)
     PairPolicy.mode = "exact"
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        ll = torch.tensor([float(loss)], device=dev)
+        ll = torch.tensor([float(loss)], device=cdev)
         gathered = [torch.zeros_like(ll) for _ in range(world)]
         dist.all_gather(gathered, ll)     # gather of per-rank results (scalars)
 

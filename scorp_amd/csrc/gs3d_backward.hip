@@ -377,6 +377,209 @@ blend_backward_mfma_kernel(const uint32_t *__restrict__ tile_start, const uint32
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// B1w: the MFMA replay with ONE WAVE PER 8x8 PIXEL BLOCK as the unit of work (64-thread workgroups, no workgroup
+// barriers, no waiting for the slowest wave of a tile).  A wave walks its tile's sorted list back to front 32 entries
+// at a time: each lane gathers one record and runs the exact ellipse-vs-block test on it, the survivors are
+// compacted (ballot + popcount) into a 64-entry ring in the wave's own LDS, and whenever 16 are queued they go
+// through the 1a / 1b / MFMA pipeline of the kernel above.  The 16x16 result is converted from block-frame moments
+// to the ten gradients by lanes 0..15 and added to the per-Gaussian accumulators with float atomics (zero terms are
+// skipped).  Blocks are numbered so that the four waves of a tile land on the same XCD (same L2).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kRing = 64, kChunk = 32;
+
+__global__ void __launch_bounds__(64, 3)
+blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
+                           const float *__restrict__ bg, const float *__restrict__ final_T,
+                           const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
+                           const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dalpha,
+                           float *__restrict__ acc) {
+  __shared__ float4 q_a[kRing], q_b[kRing];   // (x, y, A', B'), (C', opacity, r, g): conic pre-scaled for exp2
+  __shared__ float2 q_c[kRing];               // (b, depth)
+  __shared__ uint32_t q_id[kRing], q_pos[kRing];
+  __shared__ float xv[kGroup * kXStride], xw[kGroup * kXStride];
+  float *dbuf = xw;  // the 16x12 result tile reuses the w matrix once the MFMAs have consumed it
+  const int lane = threadIdx.x;
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
+  if (tile >= tiles) return;
+  const int tx0 = (tile % tiles_x) * kTile, ty0 = (tile / tiles_x) * kTile;
+  const int bx = tx0 + (quad & 1) * 8, by = ty0 + (quad >> 1) * 8;
+  const int px = bx + (lane & 7), py = by + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const float cx = (float)bx + 3.5f, cy = (float)by + 3.5f;  // block-frame origin of the moments
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  if (end == beg) return;
+  const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+  const float T_final = inside ? final_T[pix] : 0.0f;
+  const uint32_t last = inside ? n_contrib[pix] : 0u;
+  float dpix0 = 0.0f, dpix1 = 0.0f, dpix2 = 0.0f, ddep = 0.0f, dalp = 0.0f;
+  if (last > 0) {
+    dpix0 = dL_dcolor[pix]; dpix1 = dL_dcolor[HW + pix]; dpix2 = dL_dcolor[2 * HW + pix];
+    if (dL_ddepth) ddep = dL_ddepth[pix];
+    if (dL_dalpha) dalp = dL_dalpha[pix];
+  }
+  const float tf_bg = T_final * (bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2);
+  uint32_t todo = last;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
+  if (todo == 0) return;
+  const int bn = lane & 15, bk = lane >> 4;
+  float bv[16], bw[16];
+#pragma unroll
+  for (int t = 0; t < 16; t++) {
+    const int q = t + 16 * bk;
+    const int qx = bx + (q & 7), qy = by + (q >> 3);
+    const float xl = (float)qx - cx, yl = (float)qy - cy;
+    float v = 0.0f;
+    v = bn == 0 ? 1.0f : v; v = bn == 1 ? xl : v; v = bn == 2 ? yl : v;
+    v = bn == 3 ? xl * xl : v; v = bn == 4 ? xl * yl : v; v = bn == 5 ? yl * yl : v;
+    bv[t] = v;
+    float w = 0.0f;
+    if (qx < W && qy < H && bn >= 6 && bn <= 9) {
+      const size_t qp = (size_t)qy * W + qx;
+      if (n_contrib[qp] > 0) {
+        if (bn <= 8) w = dL_dcolor[(size_t)(bn - 6) * HW + qp];
+        else w = dL_ddepth ? dL_ddepth[qp] : 0.0f;
+      }
+    }
+    bw[t] = w;
+  }
+  float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
+  const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
+  int head = 0, count = 0;
+
+  auto process_group = [&](int nslots) {
+    {
+      // 1a + 1b in two halves of 8 splats: the straight-line part keeps only 8 (alpha, G*opacity) pairs live
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        float Go[8], al[8];
+#pragma unroll
+        for (int i8 = 0; i8 < 8; i8++) {
+          const int i = h * 8 + i8;
+          const int qi = (head + i) & (kRing - 1);
+          const float4 a = q_a[qi];
+          const float2 co = *reinterpret_cast<const float2 *>(&q_b[qi]);
+          const float dx = a.x - pxf, dy = a.y - pyf;
+          const float p2 = a.z * dx * dx + co.x * dy * dy + a.w * dx * dy;
+          const float G = __builtin_amdgcn_exp2f(p2);
+          const float alpha = fminf(kAlphaMax, co.y * G);
+          const bool ok = i < nslots && q_pos[qi] <= last && p2 <= 0.0f && alpha >= kAlphaMin;
+          al[i8] = ok ? alpha : 0.0f;
+          Go[i8] = ok ? G * co.y : 0.0f;
+        }
+#pragma unroll
+        for (int i8 = 0; i8 < 8; i8++) {
+          const int i = h * 8 + i8;
+          if (i < nslots) {  // wave-uniform: stale ring entries beyond the group must not enter the recurrence
+            const int qi = (head + i) & (kRing - 1);
+            const float2 rg = *reinterpret_cast<const float2 *>(&q_b[qi].z);
+            const float2 bz = q_c[qi];
+            const float alpha = al[i8];
+            const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+            T *= rinv;
+            const float w = alpha * T;
+            R = last_alpha * (s_last - R) + R;
+            const float sc = rg.x * dpix0 + rg.y * dpix1 + bz.x * dpix2 + bz.y * ddep + dalp;
+            const float dL_dal = (sc - R) * T - tf_bg * rinv;
+            s_last = sc;
+            last_alpha = alpha;
+            xv[i * kXStride + lane] = Go[i8] * dL_dal;
+            xw[i * kXStride + lane] = w;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      f32x4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[abase + t], bv[t], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[abase + t + 1], bv[t + 1], d1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[abase + t], bw[t], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[abase + t + 1], bw[t + 1], d1, 0, 0, 0);
+      }
+      const f32x4 d = d0 + d1;
+      if (bn < 10) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) dbuf[(4 * bk + r) * kAccStride + bn] = d[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < nslots) {  // block-frame moments -> the ten screen-space gradients of slot `lane`
+        const int qi = (head + lane) & (kRing - 1);
+        float *m = dbuf + lane * kAccStride;
+        const float4 a = q_a[qi];
+        const float4 b = q_b[qi];
+        const float cA = a.z * (-2.0f / kLog2e), cB = a.w * (-1.0f / kLog2e), cC = b.x * (-2.0f / kLog2e);
+        const float xl = a.x - cx, yl = a.y - cy;
+        const float m0 = m[0], mx = m[1], my = m[2], mxx = m[3], mxy = m[4], myy = m[5];
+        const float svdx = xl * m0 - mx, svdy = yl * m0 - my;
+        const float svdx2 = xl * xl * m0 - 2.0f * xl * mx + mxx;
+        const float svdxdy = xl * yl * m0 - xl * my - yl * mx + mxy;
+        const float svdy2 = yl * yl * m0 - 2.0f * yl * my + myy;
+        m[0] = 0.5f * W * (-cA * svdx - cB * svdy);
+        m[1] = 0.5f * H * (-cC * svdy - cB * svdx);
+        m[2] = -0.5f * svdx2;
+        m[3] = -svdxdy;
+        m[4] = -0.5f * svdy2;
+        m[5] = m0 / b.y;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int f = lane + 64 * k;
+        const int sl = f / 10, col = f - sl * 10;
+        if (sl < nslots) {
+          const float v = dbuf[sl * kAccStride + col];
+          if (v != 0.0f) atomicAdd(acc + (size_t)q_id[(head + sl) & (kRing - 1)] * kAccStride + col, v);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    head = (head + nslots) & (kRing - 1);
+    count -= nslots;
+  };
+
+  for (uint32_t done_n = 0; done_n < todo; done_n += kChunk) {
+    bool hit = false;
+    float4 a, b, c;
+    uint32_t id = 0, pos1 = 0;
+    if (lane < kChunk && done_n + lane < todo) {
+      const uint32_t pos0 = todo - 1 - done_n - lane;
+      pos1 = pos0 + 1;
+      id = point_list[beg + pos0];
+      const float4 *src = reinterpret_cast<const float4 *>(rec + id);
+      a = src[0]; b = src[1]; c = src[2];
+      hit = conic_min_over_box(a.x, a.y, a.z, a.w, b.x, bx0, bx1, by0, by1) <= c.z;
+    }
+    const uint64_t m = __ballot(hit);
+    if (hit) {
+      const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (kRing - 1);
+      q_a[qi] = make_float4(a.x, a.y, -0.5f * kLog2e * a.z, -kLog2e * a.w);
+      q_b[qi] = make_float4(-0.5f * kLog2e * b.x, b.y, b.z, b.w);
+      q_c[qi] = make_float2(c.x, c.y);
+      q_id[qi] = id;
+      q_pos[qi] = pos1;
+    }
+    count += __builtin_popcountll(m);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool last_chunk = done_n + kChunk >= todo;
+    while (count >= kGroup || (last_chunk && count > 0)) process_group(min(count, kGroup));  // single call site
+  }
+}
+
 }  // namespace
 }  // namespace scorp
 
@@ -410,11 +613,20 @@ extern "C" int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state,
   ProfScope prof(kKBlendBackward, stream);
   static const bool batch256 = getenv("SCORP_BWD_BATCH256") != nullptr;
   static const int ablate = getenv("SCORP_BWD_ABLATE") ? atoi(getenv("SCORP_BWD_ABLATE")) : 0;  // timing experiments only
+  static const bool per_tile = getenv("SCORP_BWD_PER_TILE") != nullptr;  // A/B switch: the workgroup-per-tile form
+  if (!use_shuffle && !per_tile) {
+    const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
+    blend_backward_wave_kernel<<<blocks, 64, 0, stream>>>(
+        (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const SplatRec *)(base + L.rec),
+        (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),
+        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc);
+  } else {
   auto kern = use_shuffle ? blend_backward_kernel_abl : (batch256 ? blend_backward_mfma_kernel<256> : blend_backward_mfma_kernel<128>);
   kern<<<L.tiles, 256, 0, stream>>>(
       (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const SplatRec *)(base + L.rec),
       (uint32_t)capacity, W, H, L.tiles_x, in->bg, (const float *)(base + L.final_T),
       (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc, ablate);
+  }
   }
   SCORP_KERNEL_CHECK("blend_backward", in->debug, stream);
   {
