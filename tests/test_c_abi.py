@@ -40,7 +40,7 @@ def test_binding_lists_every_declared_symbol(built_lib):
     assert L.scorp_version() >= 100
     # workspace sizing is pure host arithmetic
     s = L.scorp_gs3d_state_bytes(1_000_000, 1600, 1200)
-    assert 64 * 1_000_000 <= s < 96 * 1_000_000
+    assert 64 * 1_000_000 <= s < 128 * 1_000_000   # records + bin + tile masks + pixel state + block histograms
     assert L.scorp_gs3d_pairs_bytes(1_500_000) >= 12 * 1_500_000
     assert L.scorp_gs3d_backward_scratch_bytes(1000) >= 48 * 1000
 
