@@ -52,7 +52,11 @@ def kernel_algorithmic_bytes(name, N, Nvis, K, HW, D):
         "preprocess_backward": N * (per_g_in + 16) + Nvis * (K * 12 + 48) + N * 248,
         "ssim_l1_forward": HW * 3 * (8 + 12),       # read img+gt, write 3 derivative maps
         "ssim_l1_backward": HW * 3 * (12 + 8 + 4),  # read 3 maps + img+gt, write grad
-    }[name]
+        "preprocess_2d": N * (40 + 16 + 4 + 8) + Nvis * (K * 12 + 80),
+        "blend_forward_2d": D * 4 + Nvis * 80 + HW * (40 + 20),
+        "blend_backward_2d": D * 4 + Nvis * 80 + HW * (40 + 20) + Nvis * 72,
+        "preprocess_backward_2d": N * (40 + 16) + Nvis * (K * 12 + 80 + 80) + N * 244,
+    }.get(name, 0)
 
 
 def cpu_baseline(raw, cam, deg, W, H):
@@ -138,16 +142,22 @@ def main():
     from scorp_amd.gaussian_model import GaussianModel
     from scorp_amd.fused_loss import fused_l1_ssim_loss
     from scorp_amd.rasterizer3d import PairPolicy
-    from scorp_amd.renderer import render
+    from scorp_amd.renderer import render as render3d
     from scorp_amd.synthetic import SCENES, make_gaussians, ring_cameras
+    surfels = args.scene == "S6"                      # BASELINE config #5: the 2DGS surfel path
+    if surfels:
+        from scorp_amd.renderer2d import GaussianModel2D as GaussianModel, render as render2d, surfel_regularizers
+        render = render2d
+    else:
+        render = render3d
     _C.lib()  # fail loudly if the HIP extension is missing
 
     N, W, H, deg, seed, ncam_total = SCENES[args.scene]
     K = (deg + 1) ** 2
     # rank 0 draws the scene; the others receive it over RCCL (the one collective of this workload, outside the timed region)
-    raw = make_gaussians(N, deg, seed) if rank == 0 else None
+    raw = make_gaussians(N, deg, seed, scale_dims=2 if surfels else 3) if rank == 0 else None
     if world > 1:
-        shapes = dict(xyz=(N, 3), scaling=(N, 3), rotation=(N, 4), opacity=(N, 1), features_dc=(N, 1, 3), features_rest=(N, K - 1, 3))
+        shapes = dict(xyz=(N, 3), scaling=(N, 2 if surfels else 3), rotation=(N, 4), opacity=(N, 1), features_dc=(N, 1, 3), features_rest=(N, K - 1, 3))
         recv = {}
         for k, shp in shapes.items():
             t = torch.tensor(raw[k], device=cdev) if rank == 0 else torch.empty(shp, dtype=torch.float32, device=cdev)
@@ -184,6 +194,9 @@ def main():
         cam, gt = my_cams[i % len(my_cams)], gts[i % len(my_cams)]
         out = render(cam, model, pipe, bg)
         loss = fused_l1_ssim_loss(out["render"], gt, 0.2)
+        if surfels:                                   # train_2dgs.py:142-150: normal consistency + depth distortion
+            nl, dl = surfel_regularizers(out, 0.05, 100.0)
+            loss = loss + nl + dl
         loss.backward()
         for p in params:
             p.grad = None
@@ -243,7 +256,7 @@ def main():
                         note="blend kernels are bound by pixel-splat evaluation rate, not HBM; see DESIGN.md")
         B_view = N * 720 + HW * 40 + 28 * D_mean
         line = {
-            "metric": "fwd+bwd views/sec @1M Gaussians 1600x1200 SH3" if args.scene == "S3" else f"fwd+bwd views/sec ({args.scene})",
+            "metric": "fwd+bwd views/sec @1M Gaussians 1600x1200 SH3" if args.scene == "S3" else f"fwd+bwd views/sec ({args.scene}{', 2DGS surfels' if surfels else ''})",
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
