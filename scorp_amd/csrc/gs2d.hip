@@ -396,13 +396,15 @@ blend2d_backward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t 
           g[14] = h.G * dL_dal;
           g[15] = w * dpix0; g[16] = w * dpix1; g[17] = w * dpix2;
         }
+        // 18 sums as 9 paired reductions: lane p (< 9) of the lower half ends up with sum(g[2p]), of the upper half
+        // with sum(g[2p+1]); those 18 lanes add to consecutive floats of the splat's accumulator row
         float v = 0.0f;
 #pragma unroll
-        for (int q2 = 0; q2 < 18; q2++) {
-          const float s = wave_sum(g[q2]);
-          v = lane == q2 ? s : v;
+        for (int p2 = 0; p2 < 9; p2++) {
+          const float s = wave_sum_pair(g[2 * p2], g[2 * p2 + 1]);
+          v = (lane & 31) == p2 ? s : v;
         }
-        if (lane < 18) atomicAdd(acc + (size_t)s_id[jj] * kAcc2Stride + lane, v);
+        if ((lane & 31) < 9) atomicAdd(acc + (size_t)s_id[jj] * kAcc2Stride + 2 * (lane & 31) + (lane >> 5), v);
       }
     }
   }
