@@ -157,32 +157,49 @@ scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, c
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSortLds = 4096;  // 32 KiB of 64-bit keys
 
-template <typename Ptr>
+// Comparator i of a stage is always handled by thread i % 256, i.e. the 128-element block b = i / 64 belongs to wave
+// b % 4 in every stage whose partners are < 128 apart.  Those stages (all of k <= 128 and every j <= 64) therefore
+// need no workgroup barrier: a wave's LDS operations retire in order, a wave-level fence is enough.  Only the few
+// stages that cross 128-element blocks synchronise the workgroup (3 of 45 for a 512-entry list).
+template <bool kWaveLocal, typename Ptr>
 __device__ __forceinline__ void bitonic_sort(Ptr a, uint32_t n, uint32_t P) {
   const uint32_t tid = threadIdx.x;
-  for (uint32_t k = 2; k <= P; k <<= 1) {
-    const uint32_t half = k >> 1;
-    for (uint32_t i = tid; i < (P >> 1); i += 256) {  // flip step: lo <-> mirrored partner inside each k-block
-      const uint32_t lo = (i / half) * k + (i % half);
-      const uint32_t hi = (i / half) * k + (k - 1 - (i % half));
-      if (hi < n) {
-        const uint64_t u = a[lo], v = a[hi];
-        if (u > v) { a[lo] = v; a[hi] = u; }
+  auto sync = [&](bool cross) {
+    if (!kWaveLocal || cross) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  };
+  bool prev_cross = true;  // the loads that filled `a` came from all waves
+  for (uint32_t lk = 1; (1u << lk) <= P; lk++) {
+    const uint32_t k = 1u << lk, half = k >> 1;
+    {
+      const bool cross = k > 128;
+      sync(cross || prev_cross);
+      prev_cross = cross;
+      for (uint32_t i = tid; i < (P >> 1); i += 256) {  // flip step: lo <-> mirrored partner inside each k-block
+        const uint32_t base = (i >> (lk - 1)) << lk, r = i & (half - 1);
+        const uint32_t lo = base + r, hi = base + (k - 1 - r);
+        if (hi < n) {
+          const uint64_t u = a[lo], v = a[hi];
+          if (u > v) { a[lo] = v; a[hi] = u; }
+        }
       }
     }
-    __syncthreads();
-    for (uint32_t j = half >> 1; j >= 1; j >>= 1) {
+    for (int lj = (int)lk - 2; lj >= 0; lj--) {
+      const uint32_t j = 1u << lj;
+      const bool cross = j >= 128;
+      sync(cross || prev_cross);
+      prev_cross = cross;
       for (uint32_t i = tid; i < (P >> 1); i += 256) {
-        const uint32_t lo = 2 * j * (i / j) + (i % j);
+        const uint32_t lo = ((i >> lj) << (lj + 1)) + (i & (j - 1));
         const uint32_t hi = lo + j;
         if (hi < n) {
           const uint64_t u = a[lo], v = a[hi];
           if (u > v) { a[lo] = v; a[hi] = u; }
         }
       }
-      __syncthreads();
     }
   }
+  __syncthreads();
 }
 
 __global__ void __launch_bounds__(256)
@@ -197,14 +214,13 @@ sort_tiles_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict_
   while (P < n) P <<= 1;
   if (n <= (uint32_t)lds_limit) {
     for (uint32_t i = threadIdx.x; i < n; i += 256) s_keys[i] = keys[beg + i];
-    __syncthreads();
-    if (n > 1) bitonic_sort(s_keys, n, P);
+    if (n > 1) bitonic_sort<true>(s_keys, n, P);
+    else __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[beg + i] = (uint32_t)s_keys[i];
   } else {
     // Oversize tile: same network straight on global memory. Global accesses of one workgroup are made visible
     // to its own waves by the barrier (same CU, same L1/L2).
-    __syncthreads();
-    bitonic_sort(keys + beg, n, P);
+    bitonic_sort<false>(keys + beg, n, P);
     for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[beg + i] = (uint32_t)keys[beg + i];
   }
 }
