@@ -8,6 +8,8 @@
 // bucketed by tile with one atomic per pair, and each tile's list (a few hundred entries) is depth-sorted in
 // LDS by the workgroup that owns the tile.  Ties in depth are broken by splat index, which makes the order —
 // and therefore the image — independent of atomic arrival order.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace scorp {
@@ -305,6 +307,108 @@ blend_forward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K5w: the same blend with ONE WAVE PER 8x8 BLOCK as the unit (64-thread workgroups, no workgroup barriers), the
+// forward twin of blend_backward_wave_kernel: the wave walks the tile's list front to back 32 entries at a time, each
+// lane gathers one record and runs the exact conic-vs-block test, survivors are compacted into a per-wave LDS ring,
+// and groups of 8 go through a straight-line alpha phase followed by the branch-free sequential blend (a splat that
+// does not contribute to a pixel enters as alpha = 0, which changes nothing).  Stops as soon as all 64 pixels are
+// saturated.  The four waves of a tile are numbered onto the same XCD.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kFRing = 64, kFChunk = 32, kFGroup = 8;
+constexpr float kLog2eF = 1.4426950408889634f;
+
+__global__ void __launch_bounds__(64)
+blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                          const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
+                          const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
+                          float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
+  __shared__ float4 q_a[kFRing], q_b[kFRing];  // (x, y, A', B'), (C', opacity, r, g): conic pre-scaled for exp2
+  __shared__ float2 q_c[kFRing];               // (b, depth)
+  __shared__ uint32_t q_pos[kFRing];
+  const int lane = threadIdx.x;
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
+  if (tile >= tiles) return;
+  const int bx = (tile % tiles_x) * kTile + (quad & 1) * 8, by = (tile / tiles_x) * kTile + (quad >> 1) * 8;
+  const int px = bx + (lane & 7), py = by + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t n = end - beg;
+  float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f, Wt = 0.0f;
+  uint32_t last = 0;
+  bool done = !inside;
+  int head = 0, count = 0;
+  for (uint32_t base = 0; base < n; base += kFChunk) {
+    if (__ballot(!done) == 0) break;
+    bool hit = false;
+    float4 a, b, c;
+    if (lane < kFChunk && base + lane < n) {
+      const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[beg + base + lane]);
+      a = src[0]; b = src[1]; c = src[2];
+      hit = conic_min_over_box(a.x, a.y, a.z, a.w, b.x, bx0, bx1, by0, by1) <= c.z;
+    }
+    const uint64_t m = __ballot(hit);
+    if (hit) {
+      const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (kFRing - 1);
+      q_a[qi] = make_float4(a.x, a.y, -0.5f * kLog2eF * a.z, -kLog2eF * a.w);
+      q_b[qi] = make_float4(-0.5f * kLog2eF * b.x, b.y, b.z, b.w);
+      q_c[qi] = make_float2(c.x, c.y);
+      q_pos[qi] = base + lane + 1u;
+    }
+    count += __builtin_popcountll(m);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool last_chunk = base + kFChunk >= n;
+    while (count >= kFGroup || (last_chunk && count > 0)) {
+      const int nslots = min(count, kFGroup);
+      float al[kFGroup];
+#pragma unroll
+      for (int i = 0; i < kFGroup; i++) {
+        const int qi = (head + i) & (kFRing - 1);
+        const float4 qa = q_a[qi];
+        const float2 co = *reinterpret_cast<const float2 *>(&q_b[qi]);
+        const float dx = qa.x - pxf, dy = qa.y - pyf;
+        const float p2 = qa.z * dx * dx + co.x * dy * dy + qa.w * dx * dy;
+        const float alpha = fminf(kAlphaMax, co.y * __builtin_amdgcn_exp2f(p2));
+        al[i] = (i < nslots && p2 <= 0.0f && alpha >= kAlphaMin) ? alpha : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < kFGroup; i++) {
+        if (i < nslots) {  // wave-uniform
+          const int qi = (head + i) & (kFRing - 1);
+          const float2 rg = *reinterpret_cast<const float2 *>(&q_b[qi].z);
+          const float2 bz = q_c[qi];
+          const float alpha = al[i];
+          const float test_T = T * (1.0f - alpha);
+          done = done || (alpha > 0.0f && test_T < kTMin);   // the splat that would saturate the pixel is not blended
+          const float ae = done ? 0.0f : alpha;
+          const float w = ae * T;
+          C0 += rg.x * w; C1 += rg.y * w; C2 += bz.x * w;
+          Dp += bz.y * w;
+          Wt += w;
+          T = done ? T : test_T;
+          last = ae > 0.0f ? q_pos[qi] : last;
+        }
+      }
+      head = (head + nslots) & (kFRing - 1);
+      count -= nslots;
+    }
+  }
+  if (inside) {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    final_T[pix] = T;
+    n_contrib[pix] = last;
+    out_color[pix] = C0 + T * bg[0];
+    out_color[HW + pix] = C1 + T * bg[1];
+    out_color[2 * HW + pix] = C2 + T * bg[2];
+    out_depth[pix] = Dp;
+    out_alpha[pix] = Wt;
+  }
+}
+
 int validate(const ScorpGs3dInputs *in) {
   if (!in) { set_error("inputs is NULL"); return SCORP_ERR_INVALID; }
   if (in->num_gaussians < 0 || in->image_width <= 0 || in->image_height <= 0) {
@@ -464,7 +568,14 @@ extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *p
   uint32_t *point_list = (uint32_t *)(pb + P.list);
   StateHeader *header = (StateHeader *)(base + L.header);
   if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
-  {
+  static const bool fwd_per_tile = getenv("SCORP_FWD_PER_TILE") != nullptr;  // A/B switch: workgroup-per-tile form
+  if (!fwd_per_tile) {
+    ProfScope prof(kKBlendForward, stream);
+    const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
+    blend_forward_wave_kernel<<<blocks, 64, 0, stream>>>(
+        tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
+        out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib));
+  } else {
     ProfScope prof(kKBlendForward, stream);
     blend_forward_kernel<true><<<L.tiles, 256, 0, stream>>>(
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, in->bg,
