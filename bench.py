@@ -47,8 +47,8 @@ def kernel_algorithmic_bytes(name, N, Nvis, K, HW, D):
         "scan_tiles": 0,
         "scatter_pairs": N * 16 + D * 8,
         "sort_tiles": D * (8 + 4),
-        "blend_forward": D * 4 + Nvis * 48 + HW * (20 + 8),
-        "blend_backward": D * 4 + Nvis * 48 + HW * (20 + 8) + Nvis * 40,
+        "blend_forward": 4 * D * 4 + Nvis * 48 + HW * (20 + 8),      # each of a tile's 4 waves walks the tile's list
+        "blend_backward": 4 * D * 4 + Nvis * 48 + HW * (20 + 8) + Nvis * 40,
         "preprocess_backward": N * (per_g_in + 16) + Nvis * (K * 12 + 48) + N * 248,
         "ssim_l1_forward": HW * 3 * (8 + 12),       # read img+gt, write 3 derivative maps
         "ssim_l1_backward": HW * 3 * (12 + 8 + 4),  # read 3 maps + img+gt, write grad
@@ -222,6 +222,16 @@ def main():
     dt = time.perf_counter() - t0
     kern = {} if args.no_kernel_events else _C.prof_collect()
     _C.prof_enable(False)
+    # extra (not part of `value`): forward-only render rate, the unit of the alignment sweep / test-view rendering
+    nf = max(args.steps // 2, 1)
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    with torch.no_grad():
+        for i in range(nf):
+            render(my_cams[i % len(my_cams)], model, pipe, bg)
+    PairPolicy.drain()
+    torch.cuda.synchronize()
+    fwd_only = nf / (time.perf_counter() - tf0)
     PairPolicy.mode = "exact"
     if world > 1:
         tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
@@ -269,6 +279,7 @@ def main():
             "view_hbm": {"algorithmic_bytes_per_view": int(B_view), "achieved_GBs": round(value / world * B_view / 1e9, 1),
                          "frac_of_8TBs": round(value / world * B_view / 8e12, 5)},
             "kernels": kernels,
+            "forward_only_views_per_s_per_gpu": round(fwd_only, 1),
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"], _ = cpu_baseline(raw, my_cams[0].to("cpu"), deg, W, H)

@@ -315,7 +315,7 @@ blend_forward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__
 // does not contribute to a pixel enters as alpha = 0, which changes nothing).  Stops as soon as all 64 pixels are
 // saturated.  The four waves of a tile are numbered onto the same XCD.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kFRing = 64, kFChunk = 32, kFGroup = 8;
+constexpr int kFRing = 128, kFChunk = 64, kFGroup = 8;
 constexpr float kLog2eF = 1.4426950408889634f;
 
 __global__ void __launch_bounds__(64)
