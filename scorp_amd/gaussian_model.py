@@ -132,6 +132,34 @@ class GaussianModel:
         self._opacity = nn.Parameter(opac.requires_grad_(True))
         self.max_radii2D = torch.zeros(pts.shape[0], device=self.device)
 
+    # ---- PLY interchange (gaussian_model.py:234-251, 287-410) ----
+    def save_ply(self, path):
+        from .ply import write_ply
+        c = lambda t: t.detach().cpu().numpy()
+        write_ply(path, c(self._xyz), c(self._features_dc), c(self._features_rest), c(self._opacity), c(self._scaling), c(self._rotation))
+
+    def _adopt(self, raw):
+        P = lambda a: nn.Parameter(torch.tensor(a, dtype=torch.float32, device=self.device).contiguous().requires_grad_(True))
+        self._xyz, self._features_dc, self._features_rest = P(raw["xyz"]), P(raw["features_dc"]), P(raw["features_rest"])
+        self._opacity, self._scaling, self._rotation = P(raw["opacity"]), P(raw["scaling"]), P(raw["rotation"])
+        self.active_sh_degree = self.max_sh_degree
+        self.max_radii2D = torch.zeros(self._xyz.shape[0], device=self.device)
+
+    def load_ply(self, path, spatial_lr_scale=None):
+        from .ply import read_gaussian_ply
+        self.spatial_lr_scale = spatial_lr_scale
+        raw = read_gaussian_ply(path)
+        assert raw["features_rest"].shape[1] == (self.max_sh_degree + 1) ** 2 - 1, "PLY SH degree differs from the model's"
+        self._adopt(raw)
+
+    def load_multi_ply(self, paths, spatial_lr_scale=None):
+        """Concatenates several objects into ONE model (post_refine_gs.py:40-50); returns the per-object sizes."""
+        from .ply import read_gaussian_ply
+        self.spatial_lr_scale = spatial_lr_scale
+        raws = [read_gaussian_ply(p, self.max_sh_degree) for p in paths]
+        self._adopt({k: np.concatenate([r[k] for r in raws], axis=0) for k in raws[0]})
+        return [r["xyz"].shape[0] for r in raws]
+
     # ---- activations (the per-view host work of SURVEY §8 row a4) ----
     @property
     def get_scaling(self):

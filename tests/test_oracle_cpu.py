@@ -218,3 +218,36 @@ def test_gaussian_model_cpu_api():
     m2 = GaussianModel(3, device="cpu")
     m2.restore(cap, OptimizationParams())
     assert m2.get_xyz.shape[0] == n1
+
+
+def test_ply_round_trip_and_reference_layout(tmp_path):
+    """save_ply / load_ply / load_multi_ply: header and attribute order of the reference's writer
+    (gaussian_model.py:220-251), channel-major f_dc / f_rest flattening, exact float round trip."""
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.ply import attribute_names, read_ply_vertices
+    from scorp_amd.synthetic import make_gaussians
+    m = GaussianModel.from_raw(make_gaussians(37, 3, 8), 3, device="cpu")
+    p = str(tmp_path / "a" / "point_cloud.ply")
+    m.save_ply(p)
+    head = open(p, "rb").read(200).decode("ascii", "ignore")
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex 37\nproperty float x\n")
+    v = read_ply_vertices(p)
+    assert list(v.dtype.names) == attribute_names(3, 45, 3) and len(v.dtype.names) == 62
+    # f_rest_k is channel-major: index = channel * 15 + coefficient
+    np.testing.assert_array_equal(v["f_rest_16"], m._features_rest.detach().numpy()[:, 1, 1])
+    np.testing.assert_array_equal(v["f_dc_2"], m._features_dc.detach().numpy()[:, 0, 2])
+    np.testing.assert_array_equal(v["nx"], 0)
+    m2 = GaussianModel(3, device="cpu")
+    m2.load_ply(p)
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(getattr(m, n).detach(), getattr(m2, n).detach()), n
+    assert m2.active_sh_degree == 3
+    # two SH-0 objects merged into one model, sizes reported for the later split (post_refine_gs.py:197-202)
+    a = GaussianModel.from_raw(make_gaussians(10, 0, 1), 0, device="cpu")
+    b = GaussianModel.from_raw(make_gaussians(7, 0, 2), 0, device="cpu")
+    pa, pb = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
+    a.save_ply(pa); b.save_ply(pb)
+    mm = GaussianModel(0, device="cpu")
+    assert mm.load_multi_ply([pa, pb]) == [10, 7]
+    assert mm.get_xyz.shape == (17, 3) and mm._features_rest.shape == (17, 0, 3)
+    assert torch.equal(mm._xyz[10:].detach(), b._xyz.detach())
