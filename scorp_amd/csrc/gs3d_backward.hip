@@ -389,6 +389,7 @@ blend_backward_mfma_kernel(const uint32_t *__restrict__ tile_start, const uint32
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kRing = 64, kChunk = 32;
 
+template <bool kHasDA>  // false: no upstream gradient on the depth / alpha images (the photometric-loss-only step)
 __global__ void __launch_bounds__(64, 3)
 blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                            const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
@@ -420,8 +421,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   float dpix0 = 0.0f, dpix1 = 0.0f, dpix2 = 0.0f, ddep = 0.0f, dalp = 0.0f;
   if (last > 0) {
     dpix0 = dL_dcolor[pix]; dpix1 = dL_dcolor[HW + pix]; dpix2 = dL_dcolor[2 * HW + pix];
-    if (dL_ddepth) ddep = dL_ddepth[pix];
-    if (dL_dalpha) dalp = dL_dalpha[pix];
+    if (kHasDA && dL_ddepth) ddep = dL_ddepth[pix];
+    if (kHasDA && dL_dalpha) dalp = dL_dalpha[pix];
   }
   const float tf_bg = T_final * (bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2);
   uint32_t todo = last;
@@ -444,7 +445,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       const size_t qp = (size_t)qy * W + qx;
       if (n_contrib[qp] > 0) {
         if (bn <= 8) w = dL_dcolor[(size_t)(bn - 6) * HW + qp];
-        else w = dL_ddepth ? dL_ddepth[qp] : 0.0f;
+        else w = (kHasDA && dL_ddepth) ? dL_ddepth[qp] : 0.0f;
       }
     }
     bw[t] = w;
@@ -485,7 +486,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
             T *= rinv;
             const float w = alpha * T;
             R = last_alpha * (s_last - R) + R;
-            const float sc = rg.x * dpix0 + rg.y * dpix1 + bz.x * dpix2 + bz.y * ddep + dalp;
+            const float sc = kHasDA ? rg.x * dpix0 + rg.y * dpix1 + bz.x * dpix2 + bz.y * ddep + dalp
+                                    : rg.x * dpix0 + rg.y * dpix1 + bz.x * dpix2;
             const float dL_dal = (sc - R) * T - tf_bg * rinv;
             s_last = sc;
             last_alpha = alpha;
@@ -616,7 +618,8 @@ extern "C" int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state,
   static const bool per_tile = getenv("SCORP_BWD_PER_TILE") != nullptr;  // A/B switch: the workgroup-per-tile form
   if (!use_shuffle && !per_tile) {
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
-    blend_backward_wave_kernel<<<blocks, 64, 0, stream>>>(
+    auto wk = (dL_ddepth || dL_dalpha) ? blend_backward_wave_kernel<true> : blend_backward_wave_kernel<false>;
+    wk<<<blocks, 64, 0, stream>>>(
         (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const SplatRec *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),
         (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc);

@@ -154,6 +154,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         grads = _C.ScorpGs3dGrads()
         grads.means3D, grads.means2D, grads.shs, grads.colors_precomp = _ptr(g_means3D), _ptr(g_means2D), _ptr(g_sh), _ptr(g_col)
         grads.opacities, grads.scales, grads.rotations, grads.cov3D_precomp = _ptr(g_op), _ptr(g_sc), _ptr(g_rot), _ptr(g_cov)
+        if grad_color is None:
+            grad_color = torch.zeros((3, int(s.image_height), int(s.image_width)), dtype=torch.float32, device=dev)
         gc = _prep(grad_color, "grad_color")
         gd = _prep(grad_depth, "grad_depth") if grad_depth is not None else None
         ga = _prep(grad_alpha, "grad_alpha") if grad_alpha is not None else None
@@ -195,6 +197,7 @@ def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opaciti
     _C.check(L.scorp_gs3d_render(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(depth),
                                  _ptr(alpha), stream), "scorp_gs3d_render")
     ctx.settings, ctx.capacity = settings, capacity
+    ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward: the kernels skip those terms
     return color, radii, depth, alpha, state, pairs, keep
 
 
@@ -234,6 +237,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         grads = _C.ScorpGs3dGrads()
         grads.means3D, grads.means2D, grads.shs, grads.shs_rest = _ptr(g_means3D), _ptr(g_means2D), _ptr(g_dc), _ptr(g_rest)
         grads.opacities, grads.scales, grads.rotations = _ptr(g_op), _ptr(g_sc), _ptr(g_rot)
+        if grad_color is None:
+            grad_color = torch.zeros((3, int(s.image_height), int(s.image_width)), dtype=torch.float32, device=dev)
         gc = _prep(grad_color, "grad_color")
         gd = _prep(grad_depth, "grad_depth") if grad_depth is not None else None
         ga = _prep(grad_alpha, "grad_alpha") if grad_alpha is not None else None
