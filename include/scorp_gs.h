@@ -200,6 +200,9 @@ int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t num_tensors, double 
 /* Off by default. scorp_prof_enable(1) clears the accumulators and starts recording; collect() synchronises the
  * recorded events and returns, per kernel id, the summed duration in ms and the number of launches. */
 int scorp_prof_enable(int on);
+/* Restrict the bracketing to the kernels whose bit (1 << kernel_id) is set (default: all) — an event pair costs a few
+ * microseconds of stream time, so a throughput run brackets only the kernel it reports. */
+int scorp_prof_select(uint64_t kernel_mask);
 int scorp_prof_num_kernels(void);
 const char *scorp_prof_kernel_name(int kernel_id);
 int scorp_prof_collect(double *total_ms, uint64_t *launches);

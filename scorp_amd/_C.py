@@ -43,7 +43,7 @@ EXPORTS = [
     "scorp_knn_dist2", "scorp_adam_step",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
     "scorp_gs2d_backward", "scorp_gs2d_debug_geom", "scorp_gs2d_debug_tiles",
-    "scorp_prof_enable", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
+    "scorp_prof_enable", "scorp_prof_select", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
 ]
 
 _lib = None
@@ -91,6 +91,7 @@ def lib():
     L.scorp_knn_dist2.argtypes = [vp, i32, vp, vp]
     L.scorp_adam_step.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i32, vp]
     L.scorp_prof_enable.argtypes = [ctypes.c_int]
+    L.scorp_prof_select.argtypes = [u64]
     L.scorp_prof_kernel_name.restype = ctypes.c_char_p
     L.scorp_prof_kernel_name.argtypes = [ctypes.c_int]
     L.scorp_prof_collect.argtypes = [vp, vp]
@@ -98,8 +99,15 @@ def lib():
     return L
 
 
-def prof_enable(on=True):
-    check(lib().scorp_prof_enable(1 if on else 0), "scorp_prof_enable")
+def prof_enable(on=True, only=None):
+    """Start / stop hipEvent bracketing of the library's kernels; `only` = iterable of kernel names to bracket."""
+    L = lib()
+    mask = (1 << 64) - 1
+    if only is not None:
+        names = [L.scorp_prof_kernel_name(k).decode() for k in range(L.scorp_prof_num_kernels())]
+        mask = sum(1 << names.index(n) for n in only)
+    check(L.scorp_prof_select(mask), "scorp_prof_select")
+    check(L.scorp_prof_enable(1 if on else 0), "scorp_prof_enable")
 
 
 def prof_collect():

@@ -21,6 +21,7 @@ void set_error(const char *fmt, ...) {
 // ---- kernel timing ----
 namespace scorp {
 bool g_prof_on = false;
+uint64_t g_prof_mask = ~0ull;
 namespace {
 const char *kKernelNames[kKNumKernels] = {"preprocess", "count_tiles", "scan_tiles", "scatter_pairs", "sort_tiles", "blend_forward",
                                           "blend_backward", "preprocess_backward", "ssim_l1_forward", "ssim_l1_backward", "knn_dist2", "adam", "preprocess_2d", "blend_forward_2d",
@@ -40,12 +41,14 @@ hipEvent_t get_event() {
 }
 }  // namespace
 void prof_begin(int id, hipStream_t stream) {
+  if (!((g_prof_mask >> id) & 1)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   hipEvent_t e = get_event();
   (void)hipEventRecord(e, stream);
   g_open[id] = e;
 }
 void prof_end(int id, hipStream_t stream) {
+  if (!((g_prof_mask >> id) & 1)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   hipEvent_t e = get_event();
   (void)hipEventRecord(e, stream);
@@ -60,6 +63,11 @@ extern "C" int scorp_prof_enable(int on) {
   scorp::g_pending.clear();
   for (int k = 0; k < scorp::kKNumKernels; k++) { scorp::g_ms[k] = 0; scorp::g_count[k] = 0; }
   scorp::g_prof_on = on != 0;
+  return SCORP_OK;
+}
+extern "C" int scorp_prof_select(uint64_t kernel_mask) {
+  std::lock_guard<std::mutex> lk(scorp::g_mu);
+  scorp::g_prof_mask = kernel_mask;
   return SCORP_OK;
 }
 extern "C" int scorp_prof_num_kernels(void) { return scorp::kKNumKernels; }

@@ -162,6 +162,7 @@ enum KernelId {
   kKPreprocessBackward2d, kKNumKernels
 };
 extern bool g_prof_on;
+extern uint64_t g_prof_mask;
 void prof_begin(int kernel_id, hipStream_t stream);
 void prof_end(int kernel_id, hipStream_t stream);
 struct ProfScope {  // brackets one kernel launch with an event pair when profiling is enabled
