@@ -57,6 +57,9 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m scorp_amd.build` "
             "(needs /opt/rocm/bin/hipcc). scorp_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime already in the process when this library
+    # is loaded, or the kernels register with a second runtime that has no device ("no ROCm-capable device").
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, u64, i32, sz = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
     L.scorp_version.restype = ctypes.c_int
