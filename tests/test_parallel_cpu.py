@@ -37,6 +37,14 @@ def _worker(rank, world, port, q):
         # a rank with nothing to do (more ranks than units)
         ids, scores, best = P.sweep(1, lambda i: torch.tensor([1.0]))
         assert ids.tolist() == [0] and best == 0
+        # data-parallel gradient averaging in flat buckets; a rank with a missing gradient contributes zeros
+        pa = torch.nn.Parameter(torch.zeros(5, 3))
+        pb = torch.nn.Parameter(torch.zeros(7))
+        pa.grad = torch.full((5, 3), float(rank + 1))
+        pb.grad = torch.arange(7.0) * (rank + 1) if rank == 0 else None
+        P.average_gradients([pa, pb], bucket_bytes=32)
+        assert torch.allclose(pa.grad, torch.full((5, 3), 1.5))
+        assert torch.allclose(pb.grad, torch.arange(7.0) * 0.5)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
