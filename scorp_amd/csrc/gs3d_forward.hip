@@ -204,17 +204,21 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, uint32_t n, uint32_t P) {
   __syncthreads();
 }
 
+// Two launches share the tiles by list length so that the common case keeps a small LDS footprint (8 KiB -> 8
+// workgroups per CU instead of 5): kCap = 1024 handles lists of up to 1024 entries, kCap = 4096 the longer ones
+// (in LDS up to 4096 entries, with the same network on global memory beyond).
+template <int kCap, int kMinExclusive>
 __global__ void __launch_bounds__(256)
 sort_tiles_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict__ keys,
                   uint32_t *__restrict__ point_list, uint32_t capacity, int lds_limit) {
-  __shared__ uint64_t s_keys[kSortLds];
+  __shared__ uint64_t s_keys[kCap];
   const int tile = blockIdx.x;
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t n = end - beg;
-  if (n == 0) return;
+  if (n == 0 || n <= (uint32_t)kMinExclusive || (kMinExclusive == 0 && n > (uint32_t)kCap)) return;
   uint32_t P = 1;
   while (P < n) P <<= 1;
-  if (n <= (uint32_t)lds_limit) {
+  if (n <= (uint32_t)min(lds_limit, kCap)) {
     for (uint32_t i = threadIdx.x; i < n; i += 256) s_keys[i] = keys[beg + i];
     if (n > 1) bitonic_sort<true>(s_keys, n, P);
     else __syncthreads();
@@ -490,7 +494,8 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
   SCORP_KERNEL_CHECK("scatter_pairs", debug, stream);
   {
     ProfScope prof(kKSortTiles, stream);
-    sort_tiles_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity, kSortLds);
+    sort_tiles_kernel<1024, 0><<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity, kSortLds);
+    sort_tiles_kernel<kSortLds, 1024><<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity, kSortLds);
   }
   SCORP_KERNEL_CHECK("sort_tiles", debug, stream);
   return SCORP_OK;
