@@ -140,12 +140,15 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
     if (__syncthreads_or(vis ? 1 : 0)) {
       constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
       const size_t i0 = (size_t)blockIdx.x * 256;
-      stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, min(256, a.N - (int)i0));
+      const int nrows_f = min(256, a.N - (int)i0);
+      const bool lin = SPLIT && NFL == 48 && a.K == 16 && nrows_f == 256;
+      if (lin) stage_sh_linear(s_sh, a.shs, a.shs_rest, i0);
+      else stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows_f);
       __syncthreads();
       if (vis) {
         const float dx = p[0] - a.campos[0], dy = p[1] - a.campos[1], dz = p[2] - a.campos[2];
         const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-        sh_row_to_rgb<DEG>(s_sh + threadIdx.x * kShStride, dx * inv, dy * inv, dz * inv, rgb);
+        sh_row_to_rgb<DEG>(sh_row(s_sh, threadIdx.x, lin), dx * inv, dy * inv, dz * inv, rgb);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           if (rgb[q] < 0.0f) clamp_bits |= 1 << q;
@@ -425,9 +428,11 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
   const bool visible = (rad_bits & kRadiusMask) != 0;
   const bool want_sh_grad = a.shs != nullptr && g.shs != nullptr;
   bool staged = false;
+  const bool lin = SPLIT && NFL == 48 && a.K == 16 && nrows == 256;
   if (a.shs) {
     if (__syncthreads_or(visible ? 1 : 0)) {
-      stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows);
+      if (lin) stage_sh_linear(s_sh, a.shs, a.shs_rest, i0);
+      else stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows);
       staged = true;
     }
     __syncthreads();
@@ -438,7 +443,7 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
   float gm[3] = {0, 0, 0}, gs[2] = {0, 0}, gq[4] = {0, 0, 0, 0}, gT[9], gm2[2] = {0, 0}, grgb[3] = {0, 0, 0}, g_op = 0;
 #pragma unroll
   for (int q = 0; q < 9; q++) gT[q] = 0.0f;
-  float *row = s_sh + threadIdx.x * kShStride;
+  const ShRow row = sh_row(s_sh, threadIdx.x, lin);
   if (visible) {
     const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAcc2Stride);
     const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
@@ -522,8 +527,7 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
       gm[0] += (gdir[0] - x * dot) * inv; gm[1] += (gdir[1] - y * dot) * inv; gm[2] += (gdir[2] - z * dot) * inv;
     }
   } else if (want_sh_grad && active) {
-#pragma unroll
-    for (int c = 0; c < 48; c++) row[c] = 0.0f;
+    sh_row_zero(row);
   }
   if (active) {
     if (g.means3D) { g.means3D[3 * (size_t)i] = gm[0]; g.means3D[3 * (size_t)i + 1] = gm[1]; g.means3D[3 * (size_t)i + 2] = gm[2]; }
@@ -538,12 +542,10 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
     }
   }
   if (want_sh_grad) {
-    if (!staged && active) {
-#pragma unroll
-      for (int c = 0; c < 48; c++) row[c] = 0.0f;
-    }
+    if (!staged && active) sh_row_zero(row);
     __syncthreads();
-    unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
+    if (lin) unstage_sh_linear(s_sh, g.shs, g.shs_rest, i0);
+    else unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
   }
 }
 

@@ -139,12 +139,15 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
     if (__syncthreads_or(vis ? 1 : 0)) {  // a block with nothing visible never touches its SH rows
       constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
       const size_t i0 = (size_t)blockIdx.x * 256;
-      stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, min(256, a.N - (int)i0));
+      const int nrows_f = min(256, a.N - (int)i0);
+      const bool lin = SPLIT && NFL == 48 && a.K == 16 && nrows_f == 256;
+      if (lin) stage_sh_linear(s_sh, a.shs, a.shs_rest, i0);
+      else stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows_f);
       __syncthreads();
       if (vis) {
         const float dx = px_ - a.campos[0], dy = py_ - a.campos[1], dz = pz_ - a.campos[2];
         const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-        sh_row_to_rgb<DEG>(s_sh + threadIdx.x * kShStride, dx * inv, dy * inv, dz * inv, rgb);
+        sh_row_to_rgb<DEG>(sh_row(s_sh, threadIdx.x, lin), dx * inv, dy * inv, dz * inv, rgb);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
           if (rgb[q] < 0.0f) clamp_bits |= 1 << q;  // remembered for the backward (zero gradient where clamped)
@@ -189,9 +192,11 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
   const bool visible = (rad_bits & kRadiusMask) != 0;
   const bool want_sh_grad = a.shs != nullptr && g.shs != nullptr;
   bool staged = false;
+  const bool lin = SPLIT && NFL == 48 && a.K == 16 && nrows == 256;
   if (a.shs) {
     if (__syncthreads_or(visible ? 1 : 0)) {
-      stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows);
+      if (lin) stage_sh_linear(s_sh, a.shs, a.shs_rest, i0);
+      else stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows);
       staged = true;
     }
     __syncthreads();
@@ -204,7 +209,7 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
 #pragma unroll
   for (int q = 0; q < kAccStride; q++) a_[q] = 0.0f;
   float g_op = 0.0f;
-  float *row = s_sh + threadIdx.x * kShStride;
+  const ShRow row = sh_row(s_sh, threadIdx.x, lin);
   if (visible) {
     const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAccStride);
     const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
@@ -352,8 +357,7 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
       }
     }
   } else if (want_sh_grad && active) {
-#pragma unroll
-    for (int c = 0; c < 48; c++) row[c] = 0.0f;
+    sh_row_zero(row);
   }
   if (active) {
     if (g.means3D) { g.means3D[3 * (size_t)i] = gm[0]; g.means3D[3 * (size_t)i + 1] = gm[1]; g.means3D[3 * (size_t)i + 2] = gm[2]; }
@@ -368,12 +372,10 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
     }
   }
   if (want_sh_grad) {
-    if (!staged && active) {  // nothing visible in this block: rows were never staged, they are all zero
-#pragma unroll
-      for (int c = 0; c < 48; c++) row[c] = 0.0f;
-    }
+    if (!staged && active) sh_row_zero(row);  // nothing visible in this block: rows were never staged
     __syncthreads();
-    unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
+    if (lin) unstage_sh_linear(s_sh, g.shs, g.shs_rest, i0);
+    else unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
   }
 }
 

@@ -113,12 +113,47 @@ __device__ __forceinline__ void unstage_sh_rows(const float *__restrict__ lds, f
   }
 }
 
+// A staged SH row as two bases so that the same code serves both LDS layouts:
+//   padded  : one row of 48 floats at stride 49                      -> p0 = pr = row
+//   linear  : dc rows (3 floats) and rest rows (45 floats) staged as plain copies of the global arrays; both strides are
+//             odd, so one-thread-per-row walks stay bank-conflict free  -> p0 = dc row, pr = rest row - 3
+struct ShRow { float *p0; float *pr; };
+constexpr int kShLinearRest = 256 * 3;  // float offset of the rest rows in the linear layout
+__device__ __forceinline__ ShRow sh_row(float *lds, int t, bool linear) {
+  ShRow r;
+  if (linear) { r.p0 = lds + 3 * t; r.pr = lds + kShLinearRest + 45 * t - 3; }
+  else { r.p0 = lds + t * kShStride; r.pr = r.p0; }
+  return r;
+}
+__device__ __forceinline__ void sh_row_zero(ShRow r) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) r.p0[c] = 0.0f;
+#pragma unroll
+  for (int c = 3; c < 48; c++) r.pr[c] = 0.0f;
+}
+// Linear staging of a FULL block (256 rows) of the split layout with K = 16: two plain 16-byte streams, no index math.
+__device__ __forceinline__ void stage_sh_linear(float *__restrict__ lds, const float *__restrict__ dc,
+                                                const float *__restrict__ rest, size_t i0) {
+  const float4 *d4 = reinterpret_cast<const float4 *>(dc + i0 * 3), *r4 = reinterpret_cast<const float4 *>(rest + i0 * 45);
+  float4 *l4 = reinterpret_cast<float4 *>(lds), *lr4 = reinterpret_cast<float4 *>(lds + kShLinearRest);
+  for (int e = threadIdx.x; e < 256 * 3 / 4; e += 256) l4[e] = d4[e];
+  for (int e = threadIdx.x; e < 256 * 45 / 4; e += 256) lr4[e] = r4[e];
+}
+__device__ __forceinline__ void unstage_sh_linear(const float *__restrict__ lds, float *__restrict__ g_dc,
+                                                  float *__restrict__ g_rest, size_t i0) {
+  float4 *d4 = reinterpret_cast<float4 *>(g_dc + i0 * 3), *r4 = reinterpret_cast<float4 *>(g_rest + i0 * 45);
+  const float4 *l4 = reinterpret_cast<const float4 *>(lds), *lr4 = reinterpret_cast<const float4 *>(lds + kShLinearRest);
+  for (int e = threadIdx.x; e < 256 * 3 / 4; e += 256) d4[e] = l4[e];
+  for (int e = threadIdx.x; e < 256 * 45 / 4; e += 256) r4[e] = lr4[e];
+}
+
 // SH -> RGB + 0.5 from a staged row (gs3dgs/utils/sh_utils.py:57-112 restated for [K,3] rows)
 template <int DEG>
-__device__ __forceinline__ void sh_row_to_rgb(const float *__restrict__ sh, float x, float y, float z, float *rgb) {
+__device__ __forceinline__ void sh_row_to_rgb(ShRow row, float x, float y, float z, float *rgb) {
+  const float *sh0 = row.p0, *sh = row.pr;  // sh0[c]: degree-0 coefficient; sh[3k + c]: coefficient k >= 1
 #pragma unroll
   for (int c = 0; c < 3; c++) {
-    float r = SH_C0 * sh[c];
+    float r = SH_C0 * sh0[c];
     if constexpr (DEG > 0) {
       r = r - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
       if constexpr (DEG > 1) {
@@ -142,8 +177,9 @@ __device__ __forceinline__ void sh_row_to_rgb(const float *__restrict__ sh, floa
 // dL/d(unit direction) into gdir and, if write_grad, overwrites the row IN PLACE with dL/d(coefficients)
 // (each channel's coefficients are consumed before they are overwritten).
 template <int DEG>
-__device__ __forceinline__ void sh_row_backward(float *__restrict__ row, float x, float y, float z, const float *gr3,
+__device__ __forceinline__ void sh_row_backward(ShRow srow, float x, float y, float z, const float *gr3,
                                                 bool write_grad, float *gdir) {
+        float *row = srow.pr;
         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
         float basis[16];
         basis[0] = SH_C0;
@@ -186,7 +222,8 @@ __device__ __forceinline__ void sh_row_backward(float *__restrict__ row, float x
           // the coefficients of this channel are consumed: overwrite them in place with their gradients
           if (write_grad) {
   #pragma unroll
-            for (int k = 0; k < 16; k++) row[3 * k + ch] = k < (DEG + 1) * (DEG + 1) ? basis[k] * gr : 0.0f;
+            for (int k = 1; k < 16; k++) row[3 * k + ch] = k < (DEG + 1) * (DEG + 1) ? basis[k] * gr : 0.0f;
+            srow.p0[ch] = basis[0] * gr;
           }
         }
 }
