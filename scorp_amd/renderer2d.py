@@ -17,18 +17,33 @@ from .rasterizer3d import GaussianRasterizationSettings
 from .sh import RGB2SH, eval_sh
 
 
-def depths_to_points(view, depthmap):
-    """gs2dgs/utils/point_utils.py:9-24, on the depth map's device."""
-    dev = depthmap.device
-    c2w = (view.world_view_transform.T).inverse()
+def _camera_rays(view, dev):
+    """Per-pixel ray directions / origin of gs2dgs/utils/point_utils.py:9-22.  They depend only on the camera and its
+    current resolution, so they are built once per (camera, resolution) and cached on the camera object — the
+    reference rebuilds them (two 4x4 inversions, a host->device copy, a meshgrid) on every render."""
     W, H = view.resolution
+    key = (W, H, str(dev), view.world_view_transform.data_ptr(), view.full_proj_transform.data_ptr())
+    cache = getattr(view, "_scorp_rays", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    c2w = (view.world_view_transform.T).inverse()
     ndc2pix = torch.tensor([[W / 2, 0, 0, W / 2], [0, H / 2, 0, H / 2], [0, 0, 0, 1]], device=dev).float().T
     projection_matrix = c2w.T @ view.full_proj_transform
     intrins = (projection_matrix @ ndc2pix)[:3, :3].T
     grid_x, grid_y = torch.meshgrid(torch.arange(W, device=dev).float(), torch.arange(H, device=dev).float(), indexing="xy")
     points = torch.stack([grid_x, grid_y, torch.ones_like(grid_x)], dim=-1).reshape(-1, 3)
-    rays_d = points @ intrins.inverse().T @ c2w[:3, :3].T
-    rays_o = c2w[:3, 3]
+    rays_d = (points @ intrins.inverse().T @ c2w[:3, :3].T).contiguous()
+    rays_o = c2w[:3, 3].contiguous()
+    try:
+        view._scorp_rays = (key, rays_d, rays_o)
+    except Exception:
+        pass
+    return rays_d, rays_o
+
+
+def depths_to_points(view, depthmap):
+    """gs2dgs/utils/point_utils.py:9-24, on the depth map's device."""
+    rays_d, rays_o = _camera_rays(view, depthmap.device)
     return depthmap.reshape(-1, 1) * rays_d + rays_o
 
 
