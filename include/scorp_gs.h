@@ -160,6 +160,25 @@ int scorp_gs2d_debug_tiles(const void *state, const void *pairs, uint64_t capaci
                            int32_t image_width, int32_t image_height, uint32_t *tile_start, uint32_t *point_list,
                            scorp_stream_t stream);
 
+/* ---- per-pixel tail of the 2DGS render(): gs2dgs/gaussian_renderer/__init__.py:131-160 over
+ * gs2dgs/utils/point_utils.py:9-40 (depths_to_points, depth_to_normal) ----
+ * allmap[7,H,W] -> render_alpha[1,H,W], render_normal[3,H,W] (rotated to world space by viewmatrix[:3,:3]),
+ * render_dist[1,H,W], surf_depth[1,H,W] = expected*(1-depth_ratio) + depth_ratio*median (both nan_to_num(.,0,0)),
+ * surf_normal[3,H,W] = normalize(cross(dP/dy, dP/dx)) * alpha with P = surf_depth*rays_d + rays_o, zero on the
+ * one-pixel border.  viewmatrix: the camera's world_view_transform (16 floats, as passed to the rasterizer);
+ * rays_d[H*W,3] / rays_o[3]: the camera's per-pixel ray table (point_utils.py:9-22).  All pointers are device
+ * pointers.  The backward takes the five upstream gradients (any may be NULL = zero) and writes g_allmap[7,H,W];
+ * surf_depth is the forward's output.  Where PyTorch's chain yields 0/0 = NaN (empty pixels) it writes 0. */
+int scorp_gs2d_maps_forward(int32_t image_width, int32_t image_height, const float *allmap, const float *viewmatrix,
+                            const float *rays_d, const float *rays_o, float depth_ratio, float *render_alpha,
+                            float *render_normal, float *render_dist, float *surf_depth, float *surf_normal,
+                            scorp_stream_t stream);
+int scorp_gs2d_maps_backward(int32_t image_width, int32_t image_height, const float *allmap, const float *viewmatrix,
+                             const float *rays_d, const float *rays_o, float depth_ratio, const float *surf_depth,
+                             const float *g_render_alpha, const float *g_render_normal, const float *g_render_dist,
+                             const float *g_surf_depth, const float *g_surf_normal, float *g_allmap,
+                             scorp_stream_t stream);
+
 /* ---- fused photometric loss (rows a8/a9 of the hot path) ----
  * loss = (1-lambda) * mean|x-y| + lambda * (1 - mean SSIM(x,y)), x = img*mask, y = gt*mask (mask [H,W] or NULL):
  * train_3dgs.py:106-107, post_refine_gs.py:103-111 over gs3dgs/utils/loss_utils.py:17-73 (11x11 Gaussian window,

@@ -25,7 +25,7 @@ uint64_t g_prof_mask = ~0ull;
 namespace {
 const char *kKernelNames[kKNumKernels] = {"preprocess", "count_tiles", "scan_tiles", "scatter_pairs", "sort_tiles", "blend_forward",
                                           "blend_backward", "preprocess_backward", "ssim_l1_forward", "ssim_l1_backward", "knn_dist2", "adam", "preprocess_2d", "blend_forward_2d",
-                                          "blend_backward_2d", "preprocess_backward_2d"};
+                                          "blend_backward_2d", "preprocess_backward_2d", "surfel_maps_forward", "surfel_maps_backward"};
 struct Pending { hipEvent_t start, stop; int id; };
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_pool;

@@ -159,7 +159,7 @@ struct PairLayout {
 enum KernelId {
   kKPreprocess = 0, kKCountTiles, kKScanTiles, kKScatterPairs, kKSortTiles, kKBlendForward, kKBlendBackward, kKPreprocessBackward,
   kKLossForward, kKLossBackward, kKKnn, kKAdam, kKPreprocess2d, kKBlendForward2d, kKBlendBackward2d,
-  kKPreprocessBackward2d, kKNumKernels
+  kKPreprocessBackward2d, kKMapsForward2d, kKMapsBackward2d, kKNumKernels
 };
 extern bool g_prof_on;
 extern uint64_t g_prof_mask;

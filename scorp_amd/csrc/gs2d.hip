@@ -414,6 +414,315 @@ blend2d_backward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Wave-per-8x8-block forms (the defaults): 64-thread workgroups, no workgroup barriers, the four blocks of a tile
+// numbered onto the same XCD — the 2DGS twins of blend_forward_wave_kernel / blend_backward_wave_kernel.
+// ---------------------------------------------------------------------------------------------------------
+struct Eval2 { float s0, s1, pz, dx, dy, depth, G, alpha; float k[3], l[3]; bool use3d; };
+// Same decisions in forward and backward: every product-sum is written as an explicit fma and contraction is off, so
+// the two kernels cannot round the ray-surfel intersection differently.
+__device__ __forceinline__ bool eval_surfel(const float4 r0, const float4 r1, const float4 r2, float pxf, float pyf, Eval2 &h) {
+#pragma clang fp contract(off)
+  const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
+#pragma unroll
+  for (int q = 0; q < 3; q++) { h.k[q] = __builtin_fmaf(pxf, Tw[q], -Tu[q]); h.l[q] = __builtin_fmaf(pyf, Tw[q], -Tv[q]); }
+  const float p0 = __builtin_fmaf(h.k[1], h.l[2], -(h.k[2] * h.l[1]));
+  const float p1 = __builtin_fmaf(h.k[2], h.l[0], -(h.k[0] * h.l[2]));
+  h.pz = __builtin_fmaf(h.k[0], h.l[1], -(h.k[1] * h.l[0]));
+  const float rz = __builtin_amdgcn_rcpf(h.pz);
+  h.s0 = p0 * rz; h.s1 = p1 * rz;
+  const float rho3d = __builtin_fmaf(h.s0, h.s0, h.s1 * h.s1);
+  h.dx = r2.y - pxf; h.dy = r2.z - pyf;
+  const float rho2d = kFilterInvSq * __builtin_fmaf(h.dx, h.dx, h.dy * h.dy);
+  h.use3d = rho3d <= rho2d;
+  const float rho = fminf(rho3d, rho2d);
+  h.depth = h.use3d ? __builtin_fmaf(h.s0, Tw[0], __builtin_fmaf(h.s1, Tw[1], Tw[2])) : Tw[2];
+  h.G = __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * rho);
+  h.alpha = fminf(kAlphaMax, r2.w * h.G);
+  // pz == 0 gives inf/NaN in rho (comparisons false); rho >= 0 otherwise, so the reference's `power > 0` never fires
+  return h.pz != 0.0f && h.depth >= kNearZ && h.alpha >= kAlphaMin && rho >= 0.0f;
+}
+
+constexpr int k2FRing = 128, k2FChunk = 64, k2FGroup = 8;
+
+__global__ void __launch_bounds__(64)
+blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                            const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
+                            const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ allmap,
+                            float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
+  __shared__ float4 q0[k2FRing], q1[k2FRing], q2[k2FRing], q3[k2FRing];
+  __shared__ float2 q4[k2FRing];
+  __shared__ uint32_t q_pos[k2FRing];
+  const int lane = threadIdx.x;
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
+  if (tile >= tiles) return;
+  const int bx = (tile % tiles_x) * kTile + (quad & 1) * 8, by = (tile / tiles_x) * kTile + (quad >> 1) * 8;
+  const int px = bx + (lane & 7), py = by + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t n = end - beg;
+  const float fn = kFarZ / (kFarZ - kNearZ);
+  float T = 1.0f, C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
+  uint32_t last = 0, med_c = 0;
+  bool done = !inside;
+  int head = 0, count = 0;
+  for (uint32_t base = 0; base < n; base += k2FChunk) {
+    if (__ballot(!done) == 0) break;
+    bool hit = false;
+    float4 r0, r1, r2, r3, r4;
+    if (base + lane < n) {
+      const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[beg + base + lane]);
+      r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3]; r4 = src[4];
+      hit = box_hit(r2, r4, bx0, bx1, by0, by1);
+    }
+    const uint64_t m = __ballot(hit);
+    if (hit) {
+      const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (k2FRing - 1);
+      q0[qi] = r0; q1[qi] = r1; q2[qi] = r2; q3[qi] = r3; q4[qi] = make_float2(r4.x, r4.y);
+      q_pos[qi] = base + lane + 1u;
+    }
+    count += __builtin_popcountll(m);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool last_chunk = base + k2FChunk >= n;
+    while (count >= k2FGroup || (last_chunk && count > 0)) {
+      const int nslots = min(count, k2FGroup);
+      float al[k2FGroup], dz[k2FGroup], mm[k2FGroup];
+#pragma unroll
+      for (int i = 0; i < k2FGroup; i++) {
+        const int qi = (head + i) & (k2FRing - 1);
+        Eval2 h;
+        const bool ok = eval_surfel(q0[qi], q1[qi], q2[qi], pxf, pyf, h) && i < nslots;
+        al[i] = ok ? h.alpha : 0.0f;
+        dz[i] = ok ? h.depth : 1.0f;
+        mm[i] = fn * (1.0f - kNearZ * __builtin_amdgcn_rcpf(dz[i]));
+      }
+#pragma unroll
+      for (int i = 0; i < k2FGroup; i++) {
+        if (i < nslots) {  // wave-uniform
+          const int qi = (head + i) & (k2FRing - 1);
+          const float4 nr = q3[qi];
+          const float2 gb = q4[qi];
+          const float alpha = al[i];
+          const float test_T = T * (1.0f - alpha);
+          done = done || (alpha > 0.0f && test_T < kTMin);
+          const float ae = done ? 0.0f : alpha;
+          const float w = ae * T;
+          const float A = 1.0f - T, mz = mm[i];
+          dist += (mz * mz * A + M2 - 2.0f * mz * M1) * w;
+          Dp += dz[i] * w; M1 += mz * w; M2 += mz * mz * w;
+          const uint32_t pos1 = q_pos[qi];
+          const bool contributes = ae > 0.0f;
+          if (contributes && T > 0.5f) { med = dz[i]; med_c = pos1; }
+          N0 += nr.x * w; N1 += nr.y * w; N2 += nr.z * w;
+          C0 += nr.w * w; C1 += gb.x * w; C2 += gb.y * w;
+          T = done ? T : test_T;
+          last = contributes ? pos1 : last;
+        }
+      }
+      head = (head + nslots) & (k2FRing - 1);
+      count -= nslots;
+    }
+  }
+  if (inside) {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
+    n_contrib[pix] = last; n_contrib[HW + pix] = med_c;
+    out_color[pix] = C0 + T * bg[0]; out_color[HW + pix] = C1 + T * bg[1]; out_color[2 * HW + pix] = C2 + T * bg[2];
+    allmap[pix] = Dp; allmap[HW + pix] = 1.0f - T;
+    allmap[2 * HW + pix] = N0; allmap[3 * HW + pix] = N1; allmap[4 * HW + pix] = N2;
+    allmap[5 * HW + pix] = med; allmap[6 * HW + pix] = dist;
+  }
+}
+
+// Eighteen wave-wide sums as one butterfly: each level halves the number of live values by pairing them (the lane
+// keeps one of the pair and receives the partner's copy of it), so the whole reduction costs ~43 instructions instead
+// of 18 x 6.  Levels 32 and 16 are v_permlane{32,16}_swap + add; in-row levels 8 and 4 are two DPP adds (the partner
+// lanes are whole banks, so bank_mask picks which value a lane keeps), levels 2 and 1 a select pair + a DPP add.  Value q's total ends in lane acc_writer_lane(q); reduce18_slot() gives each lane the q it holds (or -1).
+__device__ __forceinline__ float fold32(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold16(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float fold_row(float a, float b, bool upper) {
+  const float keep = upper ? b : a, send = upper ? a : b;
+  return keep + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(send), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float fold8_banked(float a, float b) {   // lanes 0-7 of a row: a[l] + a[l^8]; lanes 8-15: b
+  float t = dpp_add<0x128>(a);
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(t) : "v"(b));
+  return t;
+}
+__device__ __forceinline__ float fold4_banked(float a, float b) {   // lanes with bit 2 clear: a[l] + a[7-l]; set: b
+  float t = dpp_add<0x141>(a);
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(t) : "v"(b));
+  return t;
+}
+__device__ __forceinline__ int reduce18_slot(int lane) {
+  const int h = lane >> 5, r = (lane >> 4) & 1, b8 = (lane >> 3) & 1, b4 = (lane >> 2) & 1, b2 = (lane >> 1) & 1, b1 = lane & 1;
+  if (b1) return -1;
+  if (!b2) return 8 * b4 + 4 * b8 + 2 * r + h;
+  return (r == 0 && b8 == 0 && b4 == 0) ? 16 + h : -1;
+}
+__device__ __forceinline__ float reduce18(const float *g, int lane) {
+  float w[9], x[5], y[3];
+#pragma unroll
+  for (int j = 0; j < 9; j++) w[j] = fold32(g[2 * j], g[2 * j + 1]);
+#pragma unroll
+  for (int j = 0; j < 4; j++) x[j] = fold16(w[2 * j], w[2 * j + 1]);
+  x[4] = fold16(w[8], 0.0f);
+  const bool u2 = (lane & 2) != 0;
+  y[0] = fold8_banked(x[0], x[1]);
+  y[1] = fold8_banked(x[2], x[3]);
+  y[2] = dpp_add<0x128>(x[4]);
+  // in-row partners must stay inside the lane group that holds the same value: xor 8 = row_ror:8, then
+  // row_half_mirror (l <-> 7 - l), then quad_perm [2,3,0,1] and [1,0,3,2]
+  const float z0 = fold4_banked(y[0], y[1]);
+  const float z1 = dpp_add<0x141>(y[2]);
+  const float u = fold_row<0x4E>(z0, z1, u2);
+  return dpp_add<0xB1>(u);
+}
+
+constexpr int k2BChunk = 64;
+
+template <bool kHasMap>
+__global__ void __launch_bounds__(64, 3)
+blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                             const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
+                             const float *__restrict__ bg, const float *__restrict__ final_T,
+                             const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
+                             const float *__restrict__ dL_dallmap, float *__restrict__ acc) {
+  __shared__ float4 q0[k2BChunk], q1[k2BChunk], q2[k2BChunk], q3[k2BChunk];
+  __shared__ float2 q4[k2BChunk];
+  __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];
+  const int lane = threadIdx.x;
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
+  if (tile >= tiles) return;
+  const int bx = (tile % tiles_x) * kTile + (quad & 1) * 8, by = (tile / tiles_x) * kTile + (quad >> 1) * 8;
+  const int px = bx + (lane & 7), py = by + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  if (end == beg) return;
+  const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+  const float T_final = inside ? final_T[pix] : 0.0f;
+  const uint32_t last = inside ? n_contrib[pix] : 0u;
+  float final_D = 0, final_D2 = 0, dpix0 = 0, dpix1 = 0, dpix2 = 0, ddep = 0, dacc = 0, dn0 = 0, dn1 = 0, dn2 = 0,
+        dmed = 0, dreg = 0;
+  uint32_t med_c = 0;
+  if (last > 0) {  // pixels nothing was blended into never read their upstream gradient (it may be NaN)
+    dpix0 = dL_dcolor[pix]; dpix1 = dL_dcolor[HW + pix]; dpix2 = dL_dcolor[2 * HW + pix];
+    if (kHasMap) {
+      final_D = final_T[HW + pix]; final_D2 = final_T[2 * HW + pix];
+      med_c = n_contrib[HW + pix];
+      ddep = dL_dallmap[pix]; dacc = dL_dallmap[HW + pix];
+      dn0 = dL_dallmap[2 * HW + pix]; dn1 = dL_dallmap[3 * HW + pix]; dn2 = dL_dallmap[4 * HW + pix];
+      dmed = dL_dallmap[5 * HW + pix]; dreg = dL_dallmap[6 * HW + pix];
+    }
+  }
+  const float final_A = 1.0f - T_final;
+  const float bg_dot = bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2;
+  const float fn = kFarZ / (kFarZ - kNearZ);
+  uint32_t todo = last;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
+  const int slot = reduce18_slot(lane);
+  float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f, last_dL_dT = 0.0f;
+  for (uint32_t done_n = 0; done_n < todo; done_n += k2BChunk) {
+    const uint32_t top = todo - 1 - done_n;
+    bool hit = false;
+    float4 r0, r1, r2, r3, r4;
+    uint32_t id = 0;
+    if (done_n + lane < todo) {
+      id = point_list[beg + top - lane];
+      const float4 *src = reinterpret_cast<const float4 *>(rec + id);
+      r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3]; r4 = src[4];
+      hit = box_hit(r2, r4, bx0, bx1, by0, by1);
+    }
+    const uint64_t m = __ballot(hit);
+    __builtin_amdgcn_wave_barrier();   // every lane is past the previous chunk's reads of the ring
+    if (hit) {
+      const int qi = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      q0[qi] = r0; q1[qi] = r1; q2[qi] = r2; q3[qi] = r3; q4[qi] = make_float2(r4.x, r4.y);
+      q_id[qi] = id; q_pos[qi] = top - (uint32_t)lane + 1u;
+    }
+    const int cnt = __builtin_popcountll(m);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int s = 0; s < cnt; s++) {
+      const uint32_t pos1 = q_pos[s];
+      const float4 a0 = q0[s], a1 = q1[s], a2 = q2[s];
+      Eval2 h;
+      const bool valid = eval_surfel(a0, a1, a2, pxf, pyf, h) && pos1 <= last;
+      if (__ballot(valid) == 0) continue;
+      float g[18];
+#pragma unroll
+      for (int q = 0; q < 18; q++) g[q] = 0.0f;
+      if (valid) {
+        const float4 nr = q3[s];
+        const float2 gb = q4[s];
+        const float Tw0 = a1.z, Tw1 = a1.w;
+        const float rinv = __builtin_amdgcn_rcpf(1.0f - h.alpha);
+        T *= rinv;
+        const float w = h.alpha * T;
+        // the "blended behind" recurrences (colour, depth, alpha, normal) only ever appear dotted with this pixel's
+        // upstream gradient, so one scalar recurrence carries them all (see gs3d_backward.hip)
+        R = last_alpha * (s_last - R) + R;
+        float sc = nr.w * dpix0 + gb.x * dpix1 + gb.y * dpix2;
+        if (kHasMap) sc += h.depth * ddep + dacc + nr.x * dn0 + nr.y * dn1 + nr.z * dn2;
+        float dL_dal = sc - R;
+        s_last = sc;
+        float dL_dz = 0.0f;
+        if (kHasMap) {
+          const float rd = __builtin_amdgcn_rcpf(h.depth);
+          const float m_d = fn * (1.0f - kNearZ * rd);
+          const float dmd_dd = (kFarZ * kNearZ / (kFarZ - kNearZ)) * rd * rd;
+          dL_dz = (pos1 == med_c) ? dmed : 0.0f;
+          const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.0f * m_d * final_D) * dreg;
+          dL_dal += dL_dweight - last_dL_dT;
+          last_dL_dT = dL_dweight * h.alpha + (1.0f - h.alpha) * last_dL_dT;
+          dL_dz += 2.0f * w * (m_d * final_A - final_D) * dreg * dmd_dd;
+          dL_dz += w * ddep;
+        }
+        dL_dal *= T;
+        last_alpha = h.alpha;
+        dL_dal -= T_final * rinv * bg_dot;
+        const float dL_dG = a2.w * dL_dal;
+        if (h.use3d) {
+          const float ds0 = dL_dG * -h.G * h.s0 + dL_dz * Tw0, ds1 = dL_dG * -h.G * h.s1 + dL_dz * Tw1;
+          const float rz = __builtin_amdgcn_rcpf(h.pz);
+          const float dp0 = ds0 * rz, dp1 = ds1 * rz, dp2 = -(dp0 * h.s0 + dp1 * h.s1);
+          const float dk0 = h.l[1] * dp2 - h.l[2] * dp1, dk1 = h.l[2] * dp0 - h.l[0] * dp2, dk2 = h.l[0] * dp1 - h.l[1] * dp0;
+          const float dl0 = dp1 * h.k[2] - dp2 * h.k[1], dl1 = dp2 * h.k[0] - dp0 * h.k[2], dl2 = dp0 * h.k[1] - dp1 * h.k[0];
+          g[0] = -dk0; g[1] = -dk1; g[2] = -dk2;
+          g[3] = -dl0; g[4] = -dl1; g[5] = -dl2;
+          g[6] = pxf * dk0 + pyf * dl0 + dL_dz * h.s0;
+          g[7] = pxf * dk1 + pyf * dl1 + dL_dz * h.s1;
+          g[8] = pxf * dk2 + pyf * dl2 + dL_dz;
+        } else {
+          g[9] = dL_dG * (-h.G * kFilterInvSq * h.dx);
+          g[10] = dL_dG * (-h.G * kFilterInvSq * h.dy);
+          g[8] = dL_dz;
+        }
+        if (kHasMap) { g[11] = w * dn0; g[12] = w * dn1; g[13] = w * dn2; }
+        g[14] = h.G * dL_dal;
+        g[15] = w * dpix0; g[16] = w * dpix1; g[17] = w * dpix2;
+      }
+      const float v = reduce18(g, lane);
+      if (slot >= 0) atomicAdd(acc + (size_t)q_id[s] * kAcc2Stride + slot, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 template <int DEG, bool SPLIT>
 __global__ void __launch_bounds__(256)
 preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const BinRec *__restrict__ bin,
@@ -627,10 +936,17 @@ extern "C" int scorp_gs2d_render(const ScorpGs3dInputs *in, void *state, void *p
   if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
   {
     ProfScope prof(kKBlendForward2d, stream);
-    blend2d_forward_kernel<<<L.tiles, 256, 0, stream>>>(
-        (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
-        (uint32_t)capacity, W, H, L.tiles_x, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
-        (uint32_t *)(base + L.n_contrib));
+    static const bool per_tile = getenv("SCORP_2D_PER_TILE") != nullptr;  // A/B switch: the workgroup-per-tile form
+    if (per_tile)
+      blend2d_forward_kernel<<<L.tiles, 256, 0, stream>>>(
+          (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
+          (uint32_t)capacity, W, H, L.tiles_x, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
+          (uint32_t *)(base + L.n_contrib));
+    else
+      blend2d_forward_wave_kernel<<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(
+          (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
+          (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
+          (uint32_t *)(base + L.n_contrib));
   }
   SCORP_KERNEL_CHECK("blend_forward_2d", in->debug, stream);
   return SCORP_OK;
@@ -651,10 +967,20 @@ extern "C" int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state,
   SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAcc2Stride * sizeof(float), stream));
   {
     ProfScope prof(kKBlendBackward2d, stream);
-    blend2d_backward_kernel<<<L.tiles, 256, 0, stream>>>(
-        (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
-        (uint32_t)capacity, W, H, L.tiles_x, in->bg, (const float *)(base + L.final_T),
-        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc);
+    static const bool per_tile = getenv("SCORP_2D_PER_TILE") != nullptr;  // A/B switch: the workgroup-per-tile form
+#define SCORP_BW2(HASMAP)                                                                                         \
+  blend2d_backward_wave_kernel<HASMAP><<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(                                \
+      (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),    \
+      (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),                     \
+      (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc)
+    if (per_tile)
+      blend2d_backward_kernel<<<L.tiles, 256, 0, stream>>>(
+          (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
+          (uint32_t)capacity, W, H, L.tiles_x, in->bg, (const float *)(base + L.final_T),
+          (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc);
+    else if (dL_dallmap) SCORP_BW2(true);
+    else SCORP_BW2(false);
+#undef SCORP_BW2
   }
   SCORP_KERNEL_CHECK("blend_backward_2d", in->debug, stream);
   {

@@ -161,3 +161,44 @@ class GaussianRasterizer(nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return _RasterizeSurfels.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                        self.raster_settings)
+
+
+class _SurfelMaps(torch.autograd.Function):
+    """allmap -> (render_alpha, render_normal, render_dist, surf_depth, surf_normal): the per-pixel tail of
+    gs2dgs/gaussian_renderer/__init__.py:131-160 as one HIP kernel each way (scorp_gs2d_maps_forward/backward)."""
+
+    @staticmethod
+    def forward(ctx, allmap, viewmatrix, rays_d, rays_o, depth_ratio):
+        L = _C.lib()
+        allmap = _prep(allmap, "allmap")
+        _, H, W = allmap.shape
+        dev = allmap.device
+        out = torch.empty((9, H, W), dtype=torch.float32, device=dev)   # alpha | normal(3) | dist | depth | surf_normal(3)
+        ra, rn, rd, sd, sn = out[0:1], out[1:4], out[4:5], out[5:6], out[6:9]
+        _C.check(L.scorp_gs2d_maps_forward(W, H, _ptr(allmap), _ptr(viewmatrix), _ptr(rays_d), _ptr(rays_o),
+                                           float(depth_ratio), _ptr(ra), _ptr(rn), _ptr(rd), _ptr(sd), _ptr(sn), _stream()),
+                 "scorp_gs2d_maps_forward")
+        ctx.save_for_backward(allmap, viewmatrix, rays_d, rays_o, sd)
+        ctx.depth_ratio = float(depth_ratio)
+        ctx.set_materialize_grads(False)
+        return ra, rn, rd, sd, sn
+
+    @staticmethod
+    def backward(ctx, g_ra, g_rn, g_rd, g_sd, g_sn):
+        L = _C.lib()
+        allmap, viewmatrix, rays_d, rays_o, sd = ctx.saved_tensors
+        _, H, W = allmap.shape
+        gs = [None if g is None else _prep(g, "grad") for g in (g_ra, g_rn, g_rd, g_sd, g_sn)]
+        g_allmap = torch.empty_like(allmap)
+        _C.check(L.scorp_gs2d_maps_backward(W, H, _ptr(allmap), _ptr(viewmatrix), _ptr(rays_d), _ptr(rays_o), ctx.depth_ratio,
+                                            _ptr(sd), _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), _ptr(gs[4]),
+                                            _ptr(g_allmap), _stream()), "scorp_gs2d_maps_backward")
+        return g_allmap, None, None, None, None
+
+
+def surfel_maps(allmap, viewmatrix, rays_d, rays_o, depth_ratio):
+    """(render_alpha[1,H,W], render_normal[3,H,W], render_dist[1,H,W], surf_depth[1,H,W], surf_normal[3,H,W])."""
+    if not allmap.is_cuda:
+        raise RuntimeError("surfel_maps needs CUDA/HIP tensors: scorp_amd has no CPU fallback")
+    return _SurfelMaps.apply(allmap, _prep(viewmatrix, "viewmatrix"), _prep(rays_d, "rays_d"), _prep(rays_o, "rays_o"),
+                             depth_ratio)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .gaussian_model import GaussianModel, build_rotation, inverse_sigmoid
-from .rasterizer2d import GaussianRasterizer, rasterize_surfels_raw
+from .rasterizer2d import GaussianRasterizer, rasterize_surfels_raw, surfel_maps
 from .rasterizer3d import GaussianRasterizationSettings
 from .sh import RGB2SH, eval_sh
 
@@ -100,16 +100,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
             scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
 
     rets = {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
-    render_alpha = allmap[1:2]
-    render_normal = allmap[2:5]
-    render_normal = (render_normal.permute(1, 2, 0) @ (viewpoint_camera.world_view_transform[:3, :3].T)).permute(2, 0, 1)
-    render_depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
-    render_depth_expected = torch.nan_to_num(allmap[0:1] / render_alpha, 0, 0)
-    render_dist = allmap[6:7]
-    depth_ratio = getattr(pipe, "depth_ratio", 1.0)
-    surf_depth = render_depth_expected * (1 - depth_ratio) + depth_ratio * render_depth_median
-    surf_normal = depth_to_normal(viewpoint_camera, surf_depth).permute(2, 0, 1)
-    surf_normal = surf_normal * render_alpha.detach()
+    # the per-pixel tail (gs2dgs/gaussian_renderer/__init__.py:131-160: world-space normals, nan_to_num'd expected /
+    # median depth mixed by depth_ratio, pseudo surface normal of that depth times alpha.detach()) is one HIP kernel
+    rays_d, rays_o = _camera_rays(viewpoint_camera, allmap.device)
+    render_alpha, render_normal, render_dist, surf_depth, surf_normal = surfel_maps(
+        allmap, viewpoint_camera.world_view_transform, rays_d, rays_o, getattr(pipe, "depth_ratio", 1.0))
     rets.update({"render_alpha": render_alpha, "render_normal": render_normal, "render_dist": render_dist,
                  "render_depth": surf_depth, "surf_normal": surf_normal})
     return rets

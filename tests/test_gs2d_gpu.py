@@ -200,3 +200,57 @@ def test_render2d_dict_fused_vs_reference_convention_and_training_step(dev):
     p1.add_densification_stats(r["viewspace_points"], r["visibility_filter"])
     p1.optimizer.step()
     assert torch.isfinite(p1._xyz).all() and torch.isfinite(p1._scaling).all() and p1._scaling.shape[1] == 2
+
+
+@pytest.mark.parametrize("depth_ratio", [1.0, 0.0, 0.3])
+@pytest.mark.parametrize("hw", [(37, 53), (64, 128), (5, 3)])
+def test_surfel_maps_match_torch_restatement(dev, hw, depth_ratio):
+    """scorp_gs2d_maps_forward/backward (the fused per-pixel tail of the 2DGS render()) against the op-for-op PyTorch
+    restatement of gs2dgs/gaussian_renderer/__init__.py:131-160 + point_utils.py (oracle/surfel_maps_ref.py), forward
+    maps and the gradient with respect to allmap, including empty pixels (alpha = 0 -> 0/0) and odd sizes.
+    Tolerances: 1e-5 relative to each map's largest magnitude (same arithmetic, different association)."""
+    from oracle.surfel_maps_ref import camera_rays, surfel_maps_ref
+    from scorp_amd.rasterizer2d import surfel_maps
+    from scorp_amd.synthetic import ring_cameras
+    H, W = hw
+    cam = ring_cameras(3, W, H, 11, device=dev)[1]
+    rays_d, rays_o = camera_rays(cam.world_view_transform, cam.full_proj_transform, W, H)
+    g = torch.Generator(device=dev).manual_seed(H * 1000 + W)
+    alpha = torch.rand(1, H, W, device=dev, generator=g) * 0.98 + 0.01
+    depth = 3.0 + torch.rand(1, H, W, device=dev, generator=g)
+    allmap = torch.cat([depth * alpha, alpha, torch.randn(3, H, W, device=dev, generator=g) * alpha,
+                        depth + 0.05 * torch.randn(1, H, W, device=dev, generator=g),
+                        torch.rand(1, H, W, device=dev, generator=g) * 0.01], 0)
+    empty = torch.rand(H, W, device=dev, generator=g) < 0.15        # pixels nothing was blended into
+    allmap[:, empty] = 0.0
+    ws = [torch.randn(c, H, W, device=dev, generator=g) for c in (1, 3, 1, 1, 3)]
+
+    def run(fn, am):
+        am = am.clone().requires_grad_(True)
+        outs = fn(am)
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        return [o.detach() for o in outs], am.grad
+
+    outs_ref, g_ref = run(lambda am: surfel_maps_ref(am, cam.world_view_transform, rays_d, rays_o, depth_ratio), allmap)
+    outs, g_hip = run(lambda am: surfel_maps(am, cam.world_view_transform, rays_d, rays_o, depth_ratio), allmap)
+    for name, a, b in zip(("render_alpha", "render_normal", "render_dist", "surf_depth", "surf_normal"), outs, outs_ref):
+        assert a.shape == b.shape, name
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-7, name
+    assert torch.isfinite(g_hip).all()
+    ok = torch.isfinite(g_ref)                      # PyTorch's chain leaves 0/0 = NaN at empty pixels; ours writes 0
+    assert bool(ok[:, ~empty].all())
+    for c in range(7):
+        sel = ok[c]
+        scale = g_ref[c][sel].abs().max()
+        assert (g_hip[c][sel] - g_ref[c][sel]).abs().max() <= 2e-5 * scale + 1e-7, f"g_allmap[{c}]"
+        # at the 0/0 pixels ours keeps only the direct term (the render_alpha weight on channel 1, nothing elsewhere)
+        assert torch.equal(g_hip[c][~sel], ws[0][0][~sel] if c == 1 else torch.zeros_like(g_hip[c][~sel]))
+    # None upstream gradients map to NULL pointers
+    am = allmap.clone().requires_grad_(True)
+    o = surfel_maps(am, cam.world_view_transform, rays_d, rays_o, depth_ratio)
+    (o[4] * ws[4]).sum().backward()
+    am2 = allmap.clone().requires_grad_(True)
+    o2 = surfel_maps_ref(am2, cam.world_view_transform, rays_d, rays_o, depth_ratio)
+    (o2[4] * ws[4]).sum().backward()
+    sel = torch.isfinite(am2.grad)
+    assert (am.grad[sel] - am2.grad[sel]).abs().max() <= 2e-5 * am2.grad[sel].abs().max() + 1e-7
