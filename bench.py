@@ -52,10 +52,10 @@ def kernel_algorithmic_bytes(name, N, Nvis, K, HW, D):
         "preprocess_backward": N * (per_g_in + 16) + Nvis * (K * 12 + 48) + N * 248,
         "ssim_l1_forward": HW * 3 * (8 + 12),       # read img+gt, write 3 derivative maps
         "ssim_l1_backward": HW * 3 * (12 + 8 + 4),  # read 3 maps + img+gt, write grad
-        "preprocess_2d": N * (40 + 16 + 4 + 8) + Nvis * (K * 12 + 80),
-        "blend_forward_2d": D * 4 + Nvis * 80 + HW * (40 + 20),
-        "blend_backward_2d": D * 4 + Nvis * 80 + HW * (40 + 20) + Nvis * 72,
-        "preprocess_backward_2d": N * (40 + 16) + Nvis * (K * 12 + 80 + 80) + N * 244,
+        "preprocess_2d": N * (40 + 16 + 4 + 8) + Nvis * (K * 12 + 96),
+        "blend_forward_2d": D * 4 + Nvis * 96 + HW * (40 + 20),
+        "blend_backward_2d": D * 4 + Nvis * 96 + HW * (40 + 20) + Nvis * 72,
+        "preprocess_backward_2d": N * (40 + 16) + Nvis * (K * 12 + 96 + 80) + N * 244,
     }.get(name, 0)
 
 

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscorp_gs.so")
+LIB_PATH = os.environ.get("SCORP_GS_LIB", os.path.join(_HERE, "libscorp_gs.so"))   # override: A/B builds of the library
 
 c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
 

@@ -130,7 +130,7 @@ struct StateLayout {
     size_t n = N > 0 ? (size_t)N : 1, hw = (size_t)(W > 0 ? W : 1) * (size_t)(H > 0 ? H : 1);
     size_t off = 0;
     header = off; off = align_up(off + sizeof(StateHeader), 256);
-    rec = off; off = align_up(off + n * (mode2d ? (size_t)80 : sizeof(SplatRec)), 256);
+    rec = off; off = align_up(off + n * (mode2d ? (size_t)96 : sizeof(SplatRec)), 256);
     bin = off; off = align_up(off + n * sizeof(BinRec), 256);
     tile_mask = off; off = align_up(off + n * 8, 256);   // per splat: which tiles of its (<= 8x8) rectangle it can reach
     tile_count = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);

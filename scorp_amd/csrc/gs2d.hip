@@ -4,8 +4,8 @@
 // color[3,H,W], radii[N], allmap[7,H,W]; channel order :131-148).  Arithmetic follows oracle/gs2d_oracle.c: each
 // surfel is a 3x3 matrix T (rows Tu,Tv,Tw) mapping its local (u,v,1) to (x*w, y*w, w) in pixels; a pixel intersects
 // the surfel plane in uv space, alpha = o * exp(-0.5 * min(u^2+v^2, 2*|pixel - centre|^2)).
-// Binning / per-tile depth sort are the 3DGS ones (common.hpp); the blend kernels use the same tiling (4 wave64 x
-// 8x8 pixels, LDS batches, per-wave ballot cull — here by the bounding box of the alpha >= 1/255 region).
+// Binning / per-tile depth sort are the 3DGS ones (common.hpp); tiles and 8x8 pixel blocks are culled by the exact
+// footprint of {alpha >= 1/255} (an ellipse united with the low-pass disc).
 #include <stdlib.h>
 
 #include "pergaussian.hpp"
@@ -19,16 +19,30 @@ constexpr float kFilterSize = 0.707106f;
 constexpr float kFilterInvSq = 2.0f;
 constexpr float kExtentFloor = 0.0001f;
 constexpr int kAcc2Stride = 20;  // gT[9], gxy[2], gnormal[3], gopacity, grgb[3], pad[2]
-constexpr int kBatch2 = 128;
 
-struct alignas(16) Surfel {  // 80 bytes, gathered as five 16-byte loads
+struct alignas(16) Surfel {  // 96 bytes, gathered as six 16-byte loads
   float4 r0;  // Tu.x Tu.y Tu.z Tv.x
   float4 r1;  // Tv.y Tv.z Tw.x Tw.y
   float4 r2;  // Tw.z cx cy opacity
   float4 r3;  // n.x n.y n.z r
-  float4 r4;  // g b hx hy   (hx, hy: half extents of the alpha >= 1/255 region around (cx, cy))
+  float4 r4;  // g b C lp2   | footprint of {alpha >= 1/255}: the ellipse A dx^2 + 2B dx dy + C dy^2 <= 1 about (ex, ey)
+  float4 r5;  // ex ey A B   | united with the disc |p - (cx,cy)|^2 <= lp2; A == 0: unknown, never cull
 };
-static_assert(sizeof(Surfel) == 80, "Surfel must be 80 bytes");
+static_assert(sizeof(Surfel) == 96, "Surfel must be 96 bytes");
+
+// Exact culling for surfels.  alpha >= 1/255 needs min(rho3d, rho2d) <= kk = 2 ln(255 o).  {rho3d <= kk} is the
+// projection of the surfel's uv-disc of radius sqrt(kk): with p = (x Tw - Tu) x (y Tw - Tv) linear in the pixel,
+// rho3d = (p0^2 + p1^2) / p2^2, so the region is the conic p0^2 + p1^2 - kk p2^2 <= 0 — an ellipse whenever the disc
+// stays in front of the camera; preprocess2d_kernel normalises it (with 1% + 0.02 of slack on kk).  {rho2d <= kk} is
+// a disc about the low-pass centre.  A pixel box that neither reaches cannot hold a contributing pixel, so dropping
+// the (box, surfel) pair changes no output bit.
+__device__ __forceinline__ bool surfel_reaches_box(float cx, float cy, const float4 r4, const float4 r5, float bx0, float bx1,
+                                                   float by0, float by1) {
+  if (r5.z == 0.0f) return true;
+  const float ddx = fmaxf(fmaxf(bx0 - cx, cx - bx1), 0.0f), ddy = fmaxf(fmaxf(by0 - cy, cy - by1), 0.0f);
+  if (ddx * ddx + ddy * ddy <= r4.w) return true;
+  return conic_min_over_box(r5.x, r5.y, r5.z, r5.w, r4.z, bx0, bx1, by0, by1) <= 1.0f;
+}
 
 struct Pg2Args {
   int N, K, W, H, tiles_x, tiles_y, raw, count_with_atomics;
@@ -69,7 +83,9 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
   BinRec br;
   br.x0 = br.y0 = br.x1 = br.y1 = 0; br.depth_bits = 0; br.radius = 0;
   bool vis = false;
-  float T[9], nv[3] = {0, 0, 1}, p[3] = {0, 0, 0}, cx = 0, cy = 0, op = 0, hx = 0, hy = 0, depth = 0, mult = 1;
+  float T[9], nv[3] = {0, 0, 1}, p[3] = {0, 0, 0}, cx = 0, cy = 0, op = 0, depth = 0, mult = 1;
+  float eA = 0, eB = 0, eC = 0, ex = 0, ey = 0, lp2 = 0;
+  uint64_t mask = kMaskAll;
   int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
   if (active) {
     p[0] = a.means3D[3 * (size_t)i]; p[1] = a.means3D[3 * (size_t)i + 1]; p[2] = a.means3D[3 * (size_t)i + 2];
@@ -106,8 +122,8 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
         cy = f0 * Tv[0] * Tw[0] + f1 * Tv[1] * Tw[1] + f2 * Tv[2] * Tw[2];
         const float tx = f0 * Tu[0] * Tu[0] + f1 * Tu[1] * Tu[1] + f2 * Tu[2] * Tu[2];
         const float ty = f0 * Tv[0] * Tv[0] + f1 * Tv[1] * Tv[1] + f2 * Tv[2] * Tv[2];
-        const float ex = sqrtf(fmaxf(kExtentFloor, cx * cx - tx)), ey = sqrtf(fmaxf(kExtentFloor, cy * cy - ty));
-        radius = (int)ceilf(fmaxf(fmaxf(ex, ey), kCutoff * kFilterSize));
+        const float extx = sqrtf(fmaxf(kExtentFloor, cx * cx - tx)), exty = sqrtf(fmaxf(kExtentFloor, cy * cy - ty));
+        radius = (int)ceilf(fmaxf(fmaxf(extx, exty), kCutoff * kFilterSize));
         x0 = min(a.tiles_x, max(0, (int)((cx - radius) / kTile)));
         y0 = min(a.tiles_y, max(0, (int)((cy - radius) / kTile)));
         x1 = min(a.tiles_x, max(0, (int)((cx + radius + kTile - 1) / kTile)));
@@ -115,20 +131,43 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
         if ((x1 - x0) * (y1 - y0) > 0) {
           vis = true;
           op = act_opacity(a.opacities[i], a.raw);
-          // Bounding box (around cx, cy) of {alpha >= 1/255} = {min(rho3d, rho2d) <= kk}, kk = 2 ln(255 o): the
-          // projected uv-disc of radius sqrt(kk) (same closed form as the 3-sigma box) united with the low-pass disc.
-          const float kk = fmaxf(2.0f * logf(fmaxf(255.0f * op, 1.0f)), 1e-3f);
+          // footprint of {alpha >= 1/255} (see surfel_reaches_box), in the frame centred on (cx, cy)
+          const float kk = 1.01f * 2.0f * logf(fmaxf(255.0f * op, 1.0f)) + 0.02f;
+          lp2 = 0.5f * kk;
           const float ddk = kk * Tw[0] * Tw[0] + kk * Tw[1] * Tw[1] - Tw[2] * Tw[2];
-          hx = hy = 1e30f;  // unbounded projection (disc crosses the camera plane): never cull
-          if (ddk < 0.0f) {
-            const float g0 = kk / ddk, g2 = -1.0f / ddk;
-            const float cxk = g0 * Tu[0] * Tw[0] + g0 * Tu[1] * Tw[1] + g2 * Tu[2] * Tw[2];
-            const float cyk = g0 * Tv[0] * Tw[0] + g0 * Tv[1] * Tw[1] + g2 * Tv[2] * Tw[2];
-            const float txk = g0 * Tu[0] * Tu[0] + g0 * Tu[1] * Tu[1] + g2 * Tu[2] * Tu[2];
-            const float tyk = g0 * Tv[0] * Tv[0] + g0 * Tv[1] * Tv[1] + g2 * Tv[2] * Tv[2];
-            const float lp = sqrtf(0.5f * kk);
-            hx = 1.01f * fmaxf(fabsf(cxk - cx) + sqrtf(fmaxf(kExtentFloor, cxk * cxk - txk)), lp) + 0.5f;
-            hy = 1.01f * fmaxf(fabsf(cyk - cy) + sqrtf(fmaxf(kExtentFloor, cyk * cyk - tyk)), lp) + 0.5f;
+          if (ddk < 0.0f) {  // the uv-disc of radius sqrt(kk) stays in front of the camera plane: bounded projection
+            const float pa[3] = {Tv[1] * Tw[2] - Tv[2] * Tw[1], Tv[2] * Tw[0] - Tv[0] * Tw[2], Tv[0] * Tw[1] - Tv[1] * Tw[0]};
+            const float pb[3] = {Tw[1] * Tu[2] - Tw[2] * Tu[1], Tw[2] * Tu[0] - Tw[0] * Tu[2], Tw[0] * Tu[1] - Tw[1] * Tu[0]};
+            float pc[3] = {Tu[1] * Tv[2] - Tu[2] * Tv[1], Tu[2] * Tv[0] - Tu[0] * Tv[2], Tu[0] * Tv[1] - Tu[1] * Tv[0]};
+#pragma unroll
+            for (int q = 0; q < 3; q++) pc[q] += pa[q] * cx + pb[q] * cy;
+            const float Mxx = pa[0] * pa[0] + pa[1] * pa[1] - kk * pa[2] * pa[2];
+            const float Mxy = pa[0] * pb[0] + pa[1] * pb[1] - kk * pa[2] * pb[2];
+            const float Myy = pb[0] * pb[0] + pb[1] * pb[1] - kk * pb[2] * pb[2];
+            const float Mx1 = pa[0] * pc[0] + pa[1] * pc[1] - kk * pa[2] * pc[2];
+            const float My1 = pb[0] * pc[0] + pb[1] * pc[1] - kk * pb[2] * pc[2];
+            const float M11 = pc[0] * pc[0] + pc[1] * pc[1] - kk * pc[2] * pc[2];
+            const float dM = Mxx * Myy - Mxy * Mxy;
+            if (Mxx > 0.0f && dM > 0.0f) {
+              const float ox = (My1 * Mxy - Mx1 * Myy) / dM, oy = (Mx1 * Mxy - My1 * Mxx) / dM;
+              const float t1 = Mx1 * ox, t2 = My1 * oy;
+              const float F = M11 + t1 + t2;
+              // trust the normalisation only when F did not lose its digits to cancellation and the centre is sane
+              if (F < 0.0f && -F > 1e-3f * (fabsf(M11) + fabsf(t1) + fabsf(t2)) && fabsf(ox) < 4096.0f && fabsf(oy) < 4096.0f) {
+                const float nf = -1.0f / F;
+                eA = Mxx * nf; eB = Mxy * nf; eC = Myy * nf; ex = cx + ox; ey = cy + oy;
+                if (!(eA > 0.0f && eC > 0.0f && eA < 3.0e38f && eC < 3.0e38f)) eA = eB = eC = 0.0f;
+              }
+            }
+          }
+          if (eA > 0.0f && x1 - x0 <= 8 && y1 - y0 <= 8) {
+            const float4 t4 = make_float4(0.0f, 0.0f, eC, lp2), t5 = make_float4(ex, ey, eA, eB);
+            mask = 0;
+            for (int ty = y0; ty < y1; ty++)
+              for (int tx = x0; tx < x1; tx++)
+                if (surfel_reaches_box(cx, cy, t4, t5, (float)(tx * kTile), (float)(tx * kTile + kTile - 1), (float)(ty * kTile),
+                                       (float)(ty * kTile + kTile - 1)))
+                  mask |= 1ull << ((ty - y0) * 8 + (tx - x0));
           }
         }
       }
@@ -168,254 +207,25 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
     dst[1] = make_float4(T[4], T[5], T[6], T[7]);
     dst[2] = make_float4(T[8], cx, cy, op);
     dst[3] = make_float4(mult * nv[0], mult * nv[1], mult * nv[2], rgb[0]);
-    dst[4] = make_float4(rgb[1], rgb[2], hx, hy);
+    dst[4] = make_float4(rgb[1], rgb[2], eC, lp2);
+    dst[5] = make_float4(ex, ey, eA, eB);
     br.x0 = (uint16_t)x0; br.y0 = (uint16_t)y0; br.x1 = (uint16_t)x1; br.y1 = (uint16_t)y1;
     br.depth_bits = __float_as_uint(depth);
     br.radius = radius | (clamp_bits << kClampShift) | ((mult < 0.0f ? 1 : 0) << kFlipBit);
     radius_out = radius;
     if (a.count_with_atomics)
-      for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) atomicAdd(&tile_count[y * a.tiles_x + x], 1u);
+      for_each_tile(x0, y0, x1, y1, mask, a.tiles_x, [&](int t) { atomicAdd(&tile_count[t], 1u); });
   }
   reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
-  tile_mask[i] = kMaskAll;  // surfels keep their whole rectangle (the blend kernels cull by bounding box)
+  tile_mask[i] = mask;
   radii[i] = radius_out;
 }
 
-// one ray-surfel evaluation, shared by forward and backward
-struct Hit2 { float k[3], l[3], pz, s0, s1, dx, dy, depth, G, alpha; bool use3d; };
-__device__ __forceinline__ bool eval_hit2(const float4 r0, const float4 r1, const float4 r2, float pxf, float pyf, Hit2 &h) {
-  const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
-#pragma unroll
-  for (int q = 0; q < 3; q++) { h.k[q] = pxf * Tw[q] - Tu[q]; h.l[q] = pyf * Tw[q] - Tv[q]; }
-  const float p0 = h.k[1] * h.l[2] - h.k[2] * h.l[1];
-  const float p1 = h.k[2] * h.l[0] - h.k[0] * h.l[2];
-  h.pz = h.k[0] * h.l[1] - h.k[1] * h.l[0];
-  if (h.pz == 0.0f) return false;
-  h.s0 = p0 / h.pz; h.s1 = p1 / h.pz;
-  const float rho3d = h.s0 * h.s0 + h.s1 * h.s1;
-  h.dx = r2.y - pxf; h.dy = r2.z - pyf;
-  const float rho2d = kFilterInvSq * (h.dx * h.dx + h.dy * h.dy);
-  h.use3d = rho3d <= rho2d;
-  const float rho = fminf(rho3d, rho2d);
-  h.depth = h.use3d ? (h.s0 * Tw[0] + h.s1 * Tw[1]) + Tw[2] : Tw[2];
-  if (h.depth < kNearZ) return false;
-  const float power = -0.5f * rho;
-  if (power > 0.0f) return false;
-  h.G = __expf(power);
-  h.alpha = fminf(kAlphaMax, r2.w * h.G);
-  return h.alpha >= kAlphaMin;
-}
-
-__device__ __forceinline__ bool box_hit(const float4 r2, const float4 r4, float bx0, float bx1, float by0, float by1) {
-  return r2.y + r4.z >= bx0 && r2.y - r4.z <= bx1 && r2.z + r4.w >= by0 && r2.z - r4.w <= by1;
-}
-
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-blend2d_forward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
-                       const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x,
-                       const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ allmap,
-                       float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
-  __shared__ float4 s_r[5][kBatch2];
-  const int tile = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bx = (tile % tiles_x) * kTile + (wave & 1) * 8, by = (tile / tiles_x) * kTile + (wave >> 1) * 8;
-  const int px = bx + (lane & 7), py = by + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  const float fn = kFarZ / (kFarZ - kNearZ);
-  float T = 1.0f, C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
-  uint32_t last = 0, med_c = 0;
-  bool done = !inside;
-  for (uint32_t base = beg; base < end; base += kBatch2) {
-    if (__syncthreads_and(done)) break;
-    const int cnt = (int)min((uint32_t)kBatch2, end - base);
-    if ((int)threadIdx.x < cnt) {
-      const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[base + threadIdx.x]);
-#pragma unroll
-      for (int q = 0; q < 5; q++) s_r[q][threadIdx.x] = src[q];
-    }
-    __syncthreads();
-    for (int q = 0; q < cnt; q += 64) {
-      const int j = q + lane;
-      const bool hit = j < cnt && box_hit(s_r[2][j], s_r[4][j], bx0, bx1, by0, by1);
-      uint64_t mask = __ballot(hit);
-      while (mask) {
-        const int jj = q + __builtin_ctzll(mask);
-        mask &= mask - 1;
-        if (done) continue;
-        const float4 r2 = s_r[2][jj];
-        Hit2 h;
-        if (!eval_hit2(s_r[0][jj], s_r[1][jj], r2, pxf, pyf, h)) continue;
-        const float test_T = T * (1.0f - h.alpha);
-        if (test_T < kTMin) { done = true; continue; }
-        const float4 r3 = s_r[3][jj], r4 = s_r[4][jj];
-        const float w = h.alpha * T;
-        const float A = 1.0f - T;
-        const float m = fn * (1.0f - kNearZ / h.depth);
-        dist += (m * m * A + M2 - 2.0f * m * M1) * w;
-        Dp += h.depth * w; M1 += m * w; M2 += m * m * w;
-        const uint32_t pos1 = (base - beg) + (uint32_t)jj + 1u;
-        if (T > 0.5f) { med = h.depth; med_c = pos1; }
-        N0 += r3.x * w; N1 += r3.y * w; N2 += r3.z * w;
-        C0 += r3.w * w; C1 += r4.x * w; C2 += r4.y * w;
-        T = test_T;
-        last = pos1;
-      }
-    }
-  }
-  if (inside) {
-    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
-    final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
-    n_contrib[pix] = last; n_contrib[HW + pix] = med_c;
-    out_color[pix] = C0 + T * bg[0]; out_color[HW + pix] = C1 + T * bg[1]; out_color[2 * HW + pix] = C2 + T * bg[2];
-    allmap[pix] = Dp; allmap[HW + pix] = 1.0f - T;
-    allmap[2 * HW + pix] = N0; allmap[3 * HW + pix] = N1; allmap[4 * HW + pix] = N2;
-    allmap[5 * HW + pix] = med; allmap[6 * HW + pix] = dist;
-  }
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-blend2d_backward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
-                        const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x,
-                        const float *__restrict__ bg, const float *__restrict__ final_T,
-                        const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
-                        const float *__restrict__ dL_dallmap, float *__restrict__ acc) {
-  __shared__ float4 s_r[5][kBatch2];
-  __shared__ uint32_t s_id[kBatch2];
-  __shared__ uint32_t s_max;
-  const int tile = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bx = (tile % tiles_x) * kTile + (wave & 1) * 8, by = (tile / tiles_x) * kTile + (wave >> 1) * 8;
-  const int px = bx + (lane & 7), py = by + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  if (end == beg) return;
-  const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
-  const float T_final = inside ? final_T[pix] : 0.0f;
-  const uint32_t last = inside ? n_contrib[pix] : 0u;
-  float final_D = 0, final_D2 = 0, dpix0 = 0, dpix1 = 0, dpix2 = 0, ddep = 0, dacc = 0, dn0 = 0, dn1 = 0, dn2 = 0,
-        dmed = 0, dreg = 0;
-  uint32_t med_c = 0;
-  if (last > 0) {  // pixels nothing was blended into never read their upstream gradient (it may be NaN)
-    final_D = final_T[HW + pix]; final_D2 = final_T[2 * HW + pix];
-    med_c = n_contrib[HW + pix];
-    dpix0 = dL_dcolor[pix]; dpix1 = dL_dcolor[HW + pix]; dpix2 = dL_dcolor[2 * HW + pix];
-    if (dL_dallmap) {
-      ddep = dL_dallmap[pix]; dacc = dL_dallmap[HW + pix];
-      dn0 = dL_dallmap[2 * HW + pix]; dn1 = dL_dallmap[3 * HW + pix]; dn2 = dL_dallmap[4 * HW + pix];
-      dmed = dL_dallmap[5 * HW + pix]; dreg = dL_dallmap[6 * HW + pix];
-    }
-  }
-  const float final_A = 1.0f - T_final;
-  const float bg_dot = bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2;
-  const float fn = kFarZ / (kFarZ - kNearZ);
-  if (threadIdx.x == 0) s_max = 0;
-  __syncthreads();
-  atomicMax(&s_max, last);
-  __syncthreads();
-  const uint32_t todo = s_max;
-  float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f, last_dL_dT = 0.0f;
-  for (uint32_t done_n = 0; done_n < todo; done_n += kBatch2) {
-    __syncthreads();
-    const uint32_t top = todo - 1 - done_n;
-    const int cnt = (int)min((uint32_t)kBatch2, todo - done_n);
-    if ((int)threadIdx.x < cnt) {
-      const uint32_t id = point_list[beg + top - threadIdx.x];
-      const float4 *src = reinterpret_cast<const float4 *>(rec + id);
-#pragma unroll
-      for (int q = 0; q < 5; q++) s_r[q][threadIdx.x] = src[q];
-      s_id[threadIdx.x] = id;
-    }
-    __syncthreads();
-    for (int q = 0; q < cnt; q += 64) {
-      const int j = q + lane;
-      const bool hit = j < cnt && box_hit(s_r[2][j], s_r[4][j], bx0, bx1, by0, by1);
-      uint64_t mask = __ballot(hit);
-      while (mask) {
-        const int jj = q + __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const uint32_t pos1 = top - (uint32_t)jj + 1u;
-        const float4 r0 = s_r[0][jj], r1 = s_r[1][jj], r2 = s_r[2][jj];
-        Hit2 h;
-        const bool valid = eval_hit2(r0, r1, r2, pxf, pyf, h) && pos1 <= last;
-        if (__ballot(valid) == 0) continue;
-        float g[18];
-#pragma unroll
-        for (int q2 = 0; q2 < 18; q2++) g[q2] = 0.0f;
-        if (valid) {
-          const float4 r3 = s_r[3][jj], r4 = s_r[4][jj];
-          const float Tw0 = r1.z, Tw1 = r1.w;
-          const float rinv = __builtin_amdgcn_rcpf(1.0f - h.alpha);
-          T *= rinv;
-          const float w = h.alpha * T;
-          // the five "blended behind" recurrences (colour, depth, alpha, normal) only ever appear dotted with this
-          // pixel's upstream gradient, so one scalar recurrence carries them all (see gs3d_backward.hip)
-          R = last_alpha * (s_last - R) + R;
-          const float sc = r3.w * dpix0 + r4.x * dpix1 + r4.y * dpix2 + h.depth * ddep + dacc + r3.x * dn0 + r3.y * dn1 + r3.z * dn2;
-          float dL_dal = sc - R;
-          s_last = sc;
-          const float m_d = fn * (1.0f - kNearZ / h.depth);
-          const float dmd_dd = (kFarZ * kNearZ) / ((kFarZ - kNearZ) * h.depth * h.depth);
-          float dL_dz = (pos1 == med_c) ? dmed : 0.0f;
-          const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.0f * m_d * final_D) * dreg;
-          dL_dal += dL_dweight - last_dL_dT;
-          last_dL_dT = dL_dweight * h.alpha + (1.0f - h.alpha) * last_dL_dT;
-          dL_dz += 2.0f * w * (m_d * final_A - final_D) * dreg * dmd_dd;
-          dL_dal *= T;
-          last_alpha = h.alpha;
-          dL_dal -= T_final * rinv * bg_dot;
-          const float dL_dG = r2.w * dL_dal;
-          dL_dz += w * ddep;
-          if (h.use3d) {
-            const float ds0 = dL_dG * -h.G * h.s0 + dL_dz * Tw0, ds1 = dL_dG * -h.G * h.s1 + dL_dz * Tw1;
-            const float q0 = ds0 / h.pz, q1 = ds1 / h.pz;
-            const float dp0 = q0, dp1 = q1, dp2 = -(q0 * h.s0 + q1 * h.s1);
-            const float dk0 = h.l[1] * dp2 - h.l[2] * dp1, dk1 = h.l[2] * dp0 - h.l[0] * dp2, dk2 = h.l[0] * dp1 - h.l[1] * dp0;
-            const float dl0 = dp1 * h.k[2] - dp2 * h.k[1], dl1 = dp2 * h.k[0] - dp0 * h.k[2], dl2 = dp0 * h.k[1] - dp1 * h.k[0];
-            g[0] = -dk0; g[1] = -dk1; g[2] = -dk2;
-            g[3] = -dl0; g[4] = -dl1; g[5] = -dl2;
-            g[6] = pxf * dk0 + pyf * dl0 + dL_dz * h.s0;
-            g[7] = pxf * dk1 + pyf * dl1 + dL_dz * h.s1;
-            g[8] = pxf * dk2 + pyf * dl2 + dL_dz;
-          } else {
-            g[9] = dL_dG * (-h.G * kFilterInvSq * h.dx);
-            g[10] = dL_dG * (-h.G * kFilterInvSq * h.dy);
-            g[8] = dL_dz;
-          }
-          g[11] = w * dn0; g[12] = w * dn1; g[13] = w * dn2;
-          g[14] = h.G * dL_dal;
-          g[15] = w * dpix0; g[16] = w * dpix1; g[17] = w * dpix2;
-        }
-        // 18 sums as 9 paired reductions: lane p (< 9) of the lower half ends up with sum(g[2p]), of the upper half
-        // with sum(g[2p+1]); those 18 lanes add to consecutive floats of the splat's accumulator row
-        float v = 0.0f;
-#pragma unroll
-        for (int p2 = 0; p2 < 9; p2++) {
-          const float s = wave_sum_pair(g[2 * p2], g[2 * p2 + 1]);
-          v = (lane & 31) == p2 ? s : v;
-        }
-        if ((lane & 31) < 9) atomicAdd(acc + (size_t)s_id[jj] * kAcc2Stride + 2 * (lane & 31) + (lane >> 5), v);
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Wave-per-8x8-block forms (the defaults): 64-thread workgroups, no workgroup barriers, the four blocks of a tile
-// numbered onto the same XCD — the 2DGS twins of blend_forward_wave_kernel / blend_backward_wave_kernel.
+// Blend kernels: one wave per 8x8 pixel block (64-thread workgroups, no workgroup barriers), the four blocks of a tile
+// numbered onto the same XCD — the 2DGS twins of blend_forward_wave_kernel / blend_backward_wave_kernel.  Each lane
+// of a chunk gathers one surfel of the tile's list and tests its exact footprint against the block
+// (surfel_reaches_box); survivors are compacted into a per-wave LDS ring.
 // ---------------------------------------------------------------------------------------------------------
 struct Eval2 { float s0, s1, pz, dx, dy, depth, G, alpha; float k[3], l[3]; bool use3d; };
 // Same decisions in forward and backward: every product-sum is written as an explicit fma and contraction is off, so
@@ -475,7 +285,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
     if (base + lane < n) {
       const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[beg + base + lane]);
       r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3]; r4 = src[4];
-      hit = box_hit(r2, r4, bx0, bx1, by0, by1);
+      hit = surfel_reaches_box(r2.y, r2.z, r4, src[5], bx0, bx1, by0, by1);
     }
     const uint64_t m = __ballot(hit);
     if (hit) {
@@ -645,7 +455,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       id = point_list[beg + top - lane];
       const float4 *src = reinterpret_cast<const float4 *>(rec + id);
       r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3]; r4 = src[4];
-      hit = box_hit(r2, r4, bx0, bx1, by0, by1);
+      hit = surfel_reaches_box(r2.y, r2.z, r4, src[5], bx0, bx1, by0, by1);
     }
     const uint64_t m = __ballot(hit);
     __builtin_amdgcn_wave_barrier();   // every lane is past the previous chunk's reads of the ring
@@ -936,17 +746,10 @@ extern "C" int scorp_gs2d_render(const ScorpGs3dInputs *in, void *state, void *p
   if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
   {
     ProfScope prof(kKBlendForward2d, stream);
-    static const bool per_tile = getenv("SCORP_2D_PER_TILE") != nullptr;  // A/B switch: the workgroup-per-tile form
-    if (per_tile)
-      blend2d_forward_kernel<<<L.tiles, 256, 0, stream>>>(
-          (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
-          (uint32_t)capacity, W, H, L.tiles_x, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
-          (uint32_t *)(base + L.n_contrib));
-    else
-      blend2d_forward_wave_kernel<<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(
-          (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
-          (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
-          (uint32_t *)(base + L.n_contrib));
+    blend2d_forward_wave_kernel<<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(
+        (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
+        (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
+        (uint32_t *)(base + L.n_contrib));
   }
   SCORP_KERNEL_CHECK("blend_forward_2d", in->debug, stream);
   return SCORP_OK;
@@ -967,18 +770,12 @@ extern "C" int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state,
   SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAcc2Stride * sizeof(float), stream));
   {
     ProfScope prof(kKBlendBackward2d, stream);
-    static const bool per_tile = getenv("SCORP_2D_PER_TILE") != nullptr;  // A/B switch: the workgroup-per-tile form
 #define SCORP_BW2(HASMAP)                                                                                         \
   blend2d_backward_wave_kernel<HASMAP><<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(                                \
       (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),    \
       (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),                     \
       (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc)
-    if (per_tile)
-      blend2d_backward_kernel<<<L.tiles, 256, 0, stream>>>(
-          (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
-          (uint32_t)capacity, W, H, L.tiles_x, in->bg, (const float *)(base + L.final_T),
-          (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc);
-    else if (dL_dallmap) SCORP_BW2(true);
+    if (dL_dallmap) SCORP_BW2(true);
     else SCORP_BW2(false);
 #undef SCORP_BW2
   }
