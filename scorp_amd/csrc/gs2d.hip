@@ -444,6 +444,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   uint32_t todo = last;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
+  todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // wave-uniform: keeps the chunk loop's counters in SGPRs
   const int slot = reduce18_slot(lane);
   float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f, last_dL_dT = 0.0f;
   for (uint32_t done_n = 0; done_n < todo; done_n += k2BChunk) {

@@ -397,8 +397,9 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
                            const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
                            const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dalpha,
                            float *__restrict__ acc) {
-  __shared__ float4 q_a[kRing], q_b[kRing];   // (x, y, A', B'), (C', opacity, r, g): conic pre-scaled for exp2
-  __shared__ float2 q_c[kRing];               // (b, depth)
+  // ring entries: (x, y, A', B'), (C', log2 opacity, r, g), (b, depth, opacity, -): conic pre-scaled so that
+  // opacity * G = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity)
+  __shared__ float4 q_a[kRing], q_b[kRing], q_c[kRing];
   __shared__ uint32_t q_id[kRing], q_pos[kRing];
   __shared__ float xv[kGroup * kXStride], xw[kGroup * kXStride];
   float *dbuf = xw;  // the 16x12 result tile reuses the w matrix once the MFMAs have consumed it
@@ -428,7 +429,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   uint32_t todo = last;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
-  if (todo == 0) return;
+  todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // tell the compiler it is wave-uniform: the chunk loop,
+  if (todo == 0) return;                                        // ring head / count and slot indices then live in SGPRs
   const int bn = lane & 15, bk = lane >> 4;
   float bv[16], bw[16];
 #pragma unroll
@@ -454,8 +456,14 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
   int head = 0, count = 0;
 
+  // head stays a multiple of kGroup (only a wave's final group is partial), so the slots of a group are head + i
+  // without wrap-around: one LDS base per array, immediate offsets
   auto process_group = [&](int nslots) {
     {
+      int hv = head;
+      asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
+      const float4 *ga = q_a + hv, *gb = q_b + hv, *gc = q_c + hv;
+      const uint32_t *gp = q_pos + hv;
       // 1a + 1b in two halves of 8 splats: the straight-line part keeps only 8 (alpha, G*opacity) pairs live
 #pragma unroll
       for (int h = 0; h < 2; h++) {
@@ -463,24 +471,23 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
 #pragma unroll
         for (int i8 = 0; i8 < 8; i8++) {
           const int i = h * 8 + i8;
-          const int qi = (head + i) & (kRing - 1);
-          const float4 a = q_a[qi];
-          const float2 co = *reinterpret_cast<const float2 *>(&q_b[qi]);
+          const float4 a = ga[i];
+          const float2 co = *reinterpret_cast<const float2 *>(&gb[i]);
+          const uint32_t pos = gp[i];
           const float dx = a.x - pxf, dy = a.y - pyf;
-          const float p2 = a.z * dx * dx + co.x * dy * dy + a.w * dx * dy;
-          const float G = __builtin_amdgcn_exp2f(p2);
-          const float alpha = fminf(kAlphaMax, co.y * G);
-          const bool ok = i < nslots && q_pos[qi] <= last && p2 <= 0.0f && alpha >= kAlphaMin;
+          const float e = co.y + a.z * dx * dx + co.x * dy * dy + a.w * dx * dy;   // log2(opacity * G)
+          const float g_o = __builtin_amdgcn_exp2f(e);
+          const float alpha = fminf(kAlphaMax, g_o);
+          const bool ok = (i < nslots) & (pos <= last) & (e <= co.y) & (alpha >= kAlphaMin);
           al[i8] = ok ? alpha : 0.0f;
-          Go[i8] = ok ? G * co.y : 0.0f;
+          Go[i8] = ok ? g_o : 0.0f;
         }
 #pragma unroll
         for (int i8 = 0; i8 < 8; i8++) {
           const int i = h * 8 + i8;
           if (i < nslots) {  // wave-uniform: stale ring entries beyond the group must not enter the recurrence
-            const int qi = (head + i) & (kRing - 1);
-            const float2 rg = *reinterpret_cast<const float2 *>(&q_b[qi].z);
-            const float2 bz = q_c[qi];
+            const float2 rg = *reinterpret_cast<const float2 *>(&gb[i].z);
+            const float2 bz = *reinterpret_cast<const float2 *>(&gc[i]);
             const float alpha = al[i8];
             const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
             T *= rinv;
@@ -517,10 +524,10 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (lane < nslots) {  // block-frame moments -> the ten screen-space gradients of slot `lane`
-        const int qi = (head + lane) & (kRing - 1);
         float *m = dbuf + lane * kAccStride;
-        const float4 a = q_a[qi];
-        const float4 b = q_b[qi];
+        const float4 a = ga[lane];
+        const float4 b = gb[lane];
+        const float opac = gc[lane].z;
         const float cA = a.z * (-2.0f / kLog2e), cB = a.w * (-1.0f / kLog2e), cC = b.x * (-2.0f / kLog2e);
         const float xl = a.x - cx, yl = a.y - cy;
         const float m0 = m[0], mx = m[1], my = m[2], mxx = m[3], mxy = m[4], myy = m[5];
@@ -533,7 +540,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
         m[2] = -0.5f * svdx2;
         m[3] = -svdxdy;
         m[4] = -0.5f * svdy2;
-        m[5] = m0 / b.y;
+        m[5] = m0 / opac;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -543,13 +550,13 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
         const int sl = f / 10, col = f - sl * 10;
         if (sl < nslots) {
           const float v = dbuf[sl * kAccStride + col];
-          if (v != 0.0f) atomicAdd(acc + (size_t)q_id[(head + sl) & (kRing - 1)] * kAccStride + col, v);
+          if (v != 0.0f) atomicAdd(acc + (size_t)q_id[head + sl] * kAccStride + col, v);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    head = (head + nslots) & (kRing - 1);
+    head = (head + kGroup) & (kRing - 1);   // a partial group is the wave's last one
     count -= nslots;
   };
 
@@ -569,8 +576,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     if (hit) {
       const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (kRing - 1);
       q_a[qi] = make_float4(a.x, a.y, -0.5f * kLog2e * a.z, -kLog2e * a.w);
-      q_b[qi] = make_float4(-0.5f * kLog2e * b.x, b.y, b.z, b.w);
-      q_c[qi] = make_float2(c.x, c.y);
+      q_b[qi] = make_float4(-0.5f * kLog2e * b.x, __builtin_amdgcn_logf(b.y), b.z, b.w);
+      q_c[qi] = make_float4(c.x, c.y, b.y, 0.0f);
       q_id[qi] = id;
       q_pos[qi] = pos1;
     }

@@ -327,8 +327,10 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
                           float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
-  __shared__ float4 q_a[kFRing], q_b[kFRing];  // (x, y, A', B'), (C', opacity, r, g): conic pre-scaled for exp2
-  __shared__ float2 q_c[kFRing];               // (b, depth)
+  // ring entries: (x, y, A', B'), (C', log2 opacity, r, g), (b, depth): conic pre-scaled so that
+  // alpha = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity), one v_exp and no multiply
+  __shared__ float4 q_a[kFRing], q_b[kFRing];
+  __shared__ float2 q_c[kFRing];
   __shared__ uint32_t q_pos[kFRing];
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
@@ -341,10 +343,11 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t n = end - beg;
-  float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f, Wt = 0.0f;
+  float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f;
   uint32_t last = 0;
   bool done = !inside;
-  int head = 0, count = 0;
+  int head = 0, count = 0;   // head stays a multiple of kFGroup (only a wave's final group is partial), so the
+                             // slots of a group are head + i without wrap-around: one LDS base, immediate offsets
   for (uint32_t base = 0; base < n; base += kFChunk) {
     if (__ballot(!done) == 0) break;
     bool hit = false;
@@ -358,7 +361,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     if (hit) {
       const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (kFRing - 1);
       q_a[qi] = make_float4(a.x, a.y, -0.5f * kLog2eF * a.z, -kLog2eF * a.w);
-      q_b[qi] = make_float4(-0.5f * kLog2eF * b.x, b.y, b.z, b.w);
+      q_b[qi] = make_float4(-0.5f * kLog2eF * b.x, __builtin_amdgcn_logf(b.y), b.z, b.w);
       q_c[qi] = make_float2(c.x, c.y);
       q_pos[qi] = base + lane + 1u;
     }
@@ -368,23 +371,26 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     const bool last_chunk = base + kFChunk >= n;
     while (count >= kFGroup || (last_chunk && count > 0)) {
       const int nslots = min(count, kFGroup);
+      int hv = head;
+      asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
+      const float4 *ga = q_a + hv, *gb = q_b + hv;
+      const float2 *gc = q_c + hv;
+      const uint32_t *gp = q_pos + hv;
       float al[kFGroup];
 #pragma unroll
       for (int i = 0; i < kFGroup; i++) {
-        const int qi = (head + i) & (kFRing - 1);
-        const float4 qa = q_a[qi];
-        const float2 co = *reinterpret_cast<const float2 *>(&q_b[qi]);
+        const float4 qa = ga[i];
+        const float2 co = *reinterpret_cast<const float2 *>(&gb[i]);
         const float dx = qa.x - pxf, dy = qa.y - pyf;
-        const float p2 = qa.z * dx * dx + co.x * dy * dy + qa.w * dx * dy;
-        const float alpha = fminf(kAlphaMax, co.y * __builtin_amdgcn_exp2f(p2));
-        al[i] = (i < nslots && p2 <= 0.0f && alpha >= kAlphaMin) ? alpha : 0.0f;
+        const float e = co.y + qa.z * dx * dx + co.x * dy * dy + qa.w * dx * dy;   // log2(opacity * G)
+        const float alpha = fminf(kAlphaMax, __builtin_amdgcn_exp2f(e));
+        al[i] = ((i < nslots) & (e <= co.y) & (alpha >= kAlphaMin)) ? alpha : 0.0f;   // e <= log2 o: power <= 0
       }
 #pragma unroll
       for (int i = 0; i < kFGroup; i++) {
         if (i < nslots) {  // wave-uniform
-          const int qi = (head + i) & (kFRing - 1);
-          const float2 rg = *reinterpret_cast<const float2 *>(&q_b[qi].z);
-          const float2 bz = q_c[qi];
+          const float2 rg = *reinterpret_cast<const float2 *>(&gb[i].z);
+          const float2 bz = gc[i];
           const float alpha = al[i];
           const float test_T = T * (1.0f - alpha);
           done = done || (alpha > 0.0f && test_T < kTMin);   // the splat that would saturate the pixel is not blended
@@ -392,12 +398,11 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
           const float w = ae * T;
           C0 += rg.x * w; C1 += rg.y * w; C2 += bz.x * w;
           Dp += bz.y * w;
-          Wt += w;
           T = done ? T : test_T;
-          last = ae > 0.0f ? q_pos[qi] : last;
+          last = ae > 0.0f ? gp[i] : last;
         }
       }
-      head = (head + nslots) & (kFRing - 1);
+      head = (head + kFGroup) & (kFRing - 1);   // a partial group is the wave's last one
       count -= nslots;
     }
   }
@@ -409,7 +414,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     out_color[HW + pix] = C1 + T * bg[1];
     out_color[2 * HW + pix] = C2 + T * bg[2];
     out_depth[pix] = Dp;
-    out_alpha[pix] = Wt;
+    out_alpha[pix] = 1.0f - T;   // = sum of the blend weights (sum_i alpha_i T_i telescopes to 1 - T)
   }
 }
 
