@@ -6,6 +6,8 @@
 // only read, so the backward can be replayed on one forward.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace scorp {
@@ -400,7 +402,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   // ring entries: (x, y, A', B'), (C', log2 opacity, r, g), (b, depth, opacity, -): conic pre-scaled so that
   // opacity * G = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity)
   __shared__ float4 q_a[kRing], q_b[kRing], q_c[kRing];
-  __shared__ uint32_t q_id[kRing], q_pos[kRing];
+  __shared__ __attribute__((aligned(16))) uint32_t q_id[kRing], q_pos[kRing];
   __shared__ float xv[kGroup * kXStride], xw[kGroup * kXStride];
   float *dbuf = xw;  // the 16x12 result tile reuses the w matrix once the MFMAs have consumed it
   const int lane = threadIdx.x;
@@ -458,7 +460,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
 
   // head stays a multiple of kGroup (only a wave's final group is partial), so the slots of a group are head + i
   // without wrap-around: one LDS base per array, immediate offsets
-  auto process_group = [&](int nslots) {
+  auto process_group = [&](auto full, int nslots) {
+    constexpr bool kFull = decltype(full)::value;   // full groups run straight-line; only a wave's last one is partial
     {
       int hv = head;
       asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
@@ -468,24 +471,26 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         float Go[8], al[8];
+        const uint4 pl = *reinterpret_cast<const uint4 *>(gp + h * 8), ph = *reinterpret_cast<const uint4 *>(gp + h * 8 + 4);
+        const uint32_t pos8[8] = {pl.x, pl.y, pl.z, pl.w, ph.x, ph.y, ph.z, ph.w};
 #pragma unroll
         for (int i8 = 0; i8 < 8; i8++) {
           const int i = h * 8 + i8;
           const float4 a = ga[i];
           const float2 co = *reinterpret_cast<const float2 *>(&gb[i]);
-          const uint32_t pos = gp[i];
+          const uint32_t pos = pos8[i8];
           const float dx = a.x - pxf, dy = a.y - pyf;
           const float e = co.y + a.z * dx * dx + co.x * dy * dy + a.w * dx * dy;   // log2(opacity * G)
           const float g_o = __builtin_amdgcn_exp2f(e);
           const float alpha = fminf(kAlphaMax, g_o);
-          const bool ok = (i < nslots) & (pos <= last) & (e <= co.y) & (alpha >= kAlphaMin);
+          const bool ok = (kFull || i < nslots) & (pos <= last) & (e <= co.y) & (alpha >= kAlphaMin);
           al[i8] = ok ? alpha : 0.0f;
           Go[i8] = ok ? g_o : 0.0f;
         }
 #pragma unroll
         for (int i8 = 0; i8 < 8; i8++) {
           const int i = h * 8 + i8;
-          if (i < nslots) {  // wave-uniform: stale ring entries beyond the group must not enter the recurrence
+          if (kFull || i < nslots) {  // wave-uniform: stale ring entries beyond the group must not enter the recurrence
             const float2 rg = *reinterpret_cast<const float2 *>(&gb[i].z);
             const float2 bz = *reinterpret_cast<const float2 *>(&gc[i]);
             const float alpha = al[i8];
@@ -585,7 +590,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool last_chunk = done_n + kChunk >= todo;
-    while (count >= kGroup || (last_chunk && count > 0)) process_group(min(count, kGroup));  // single call site
+    while (count >= kGroup) process_group(std::true_type{}, kGroup);
+    if (last_chunk && count > 0) process_group(std::false_type{}, count);
   }
 }
 

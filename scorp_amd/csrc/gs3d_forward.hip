@@ -10,6 +10,8 @@
 // and therefore the image — independent of atomic arrival order.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace scorp {
@@ -331,7 +333,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   // alpha = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity), one v_exp and no multiply
   __shared__ float4 q_a[kFRing], q_b[kFRing];
   __shared__ float2 q_c[kFRing];
-  __shared__ uint32_t q_pos[kFRing];
+  __shared__ __attribute__((aligned(16))) uint32_t q_pos[kFRing];
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
@@ -369,14 +371,18 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool last_chunk = base + kFChunk >= n;
-    while (count >= kFGroup || (last_chunk && count > 0)) {
-      const int nslots = min(count, kFGroup);
+    // full groups run straight-line (nslots is the compile-time kFGroup); only a wave's final group is partial
+    auto blend_group = [&](auto full, int nslots) {
+      constexpr bool kFull = decltype(full)::value;
       int hv = head;
       asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
       const float4 *ga = q_a + hv, *gb = q_b + hv;
       const float2 *gc = q_c + hv;
       const uint32_t *gp = q_pos + hv;
       float al[kFGroup];
+      static_assert(kFGroup == 8, "positions are fetched as two 16-byte LDS reads");
+      const uint4 pl = *reinterpret_cast<const uint4 *>(gp), ph = *reinterpret_cast<const uint4 *>(gp + 4);
+      const uint32_t pos[kFGroup] = {pl.x, pl.y, pl.z, pl.w, ph.x, ph.y, ph.z, ph.w};
 #pragma unroll
       for (int i = 0; i < kFGroup; i++) {
         const float4 qa = ga[i];
@@ -384,11 +390,11 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
         const float dx = qa.x - pxf, dy = qa.y - pyf;
         const float e = co.y + qa.z * dx * dx + co.x * dy * dy + qa.w * dx * dy;   // log2(opacity * G)
         const float alpha = fminf(kAlphaMax, __builtin_amdgcn_exp2f(e));
-        al[i] = ((i < nslots) & (e <= co.y) & (alpha >= kAlphaMin)) ? alpha : 0.0f;   // e <= log2 o: power <= 0
+        al[i] = ((kFull || i < nslots) & (e <= co.y) & (alpha >= kAlphaMin)) ? alpha : 0.0f;   // e <= log2 o: power <= 0
       }
 #pragma unroll
       for (int i = 0; i < kFGroup; i++) {
-        if (i < nslots) {  // wave-uniform
+        if (kFull || i < nslots) {  // wave-uniform
           const float2 rg = *reinterpret_cast<const float2 *>(&gb[i].z);
           const float2 bz = gc[i];
           const float alpha = al[i];
@@ -399,12 +405,14 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
           C0 += rg.x * w; C1 += rg.y * w; C2 += bz.x * w;
           Dp += bz.y * w;
           T = done ? T : test_T;
-          last = ae > 0.0f ? gp[i] : last;
+          last = ae > 0.0f ? pos[i] : last;
         }
       }
-      head = (head + kFGroup) & (kFRing - 1);   // a partial group is the wave's last one
+      head = (head + kFGroup) & (kFRing - 1);
       count -= nslots;
-    }
+    };
+    while (count >= kFGroup) blend_group(std::true_type{}, kFGroup);
+    if (last_chunk && count > 0) blend_group(std::false_type{}, count);
   }
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
