@@ -8,6 +8,8 @@
 // footprint of {alpha >= 1/255} (an ellipse united with the low-pass disc).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pergaussian.hpp"
 
 namespace scorp {
@@ -261,7 +263,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
                             float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
   __shared__ float4 q0[k2FRing], q1[k2FRing], q2[k2FRing], q3[k2FRing];
   __shared__ float2 q4[k2FRing];
-  __shared__ uint32_t q_pos[k2FRing];
+  __shared__ __attribute__((aligned(16))) uint32_t q_pos[k2FRing];
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
@@ -297,24 +299,32 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool last_chunk = base + k2FChunk >= n;
-    while (count >= k2FGroup || (last_chunk && count > 0)) {
-      const int nslots = min(count, k2FGroup);
+    // full groups run straight-line; only a wave's final group is partial, so head stays a multiple of k2FGroup and
+    // the slots of a group are head + i without wrap-around (one LDS base per array, immediate offsets)
+    auto blend_group = [&](auto full, int nslots) {
+      constexpr bool kFull = decltype(full)::value;
+      int hv = head;
+      asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs
+      const float4 *g0 = q0 + hv, *g1 = q1 + hv, *g2 = q2 + hv, *g3 = q3 + hv;
+      const float2 *g4 = q4 + hv;
+      const uint32_t *gp = q_pos + hv;
+      static_assert(k2FGroup == 8, "positions are fetched as two 16-byte LDS reads");
+      const uint4 pl = *reinterpret_cast<const uint4 *>(gp), ph = *reinterpret_cast<const uint4 *>(gp + 4);
+      const uint32_t pos[k2FGroup] = {pl.x, pl.y, pl.z, pl.w, ph.x, ph.y, ph.z, ph.w};
       float al[k2FGroup], dz[k2FGroup], mm[k2FGroup];
 #pragma unroll
       for (int i = 0; i < k2FGroup; i++) {
-        const int qi = (head + i) & (k2FRing - 1);
         Eval2 h;
-        const bool ok = eval_surfel(q0[qi], q1[qi], q2[qi], pxf, pyf, h) && i < nslots;
+        const bool ok = eval_surfel(g0[i], g1[i], g2[i], pxf, pyf, h) & (kFull || i < nslots);
         al[i] = ok ? h.alpha : 0.0f;
         dz[i] = ok ? h.depth : 1.0f;
         mm[i] = fn * (1.0f - kNearZ * __builtin_amdgcn_rcpf(dz[i]));
       }
 #pragma unroll
       for (int i = 0; i < k2FGroup; i++) {
-        if (i < nslots) {  // wave-uniform
-          const int qi = (head + i) & (k2FRing - 1);
-          const float4 nr = q3[qi];
-          const float2 gb = q4[qi];
+        if (kFull || i < nslots) {  // wave-uniform
+          const float4 nr = g3[i];
+          const float2 gb = g4[i];
           const float alpha = al[i];
           const float test_T = T * (1.0f - alpha);
           done = done || (alpha > 0.0f && test_T < kTMin);
@@ -323,18 +333,21 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
           const float A = 1.0f - T, mz = mm[i];
           dist += (mz * mz * A + M2 - 2.0f * mz * M1) * w;
           Dp += dz[i] * w; M1 += mz * w; M2 += mz * mz * w;
-          const uint32_t pos1 = q_pos[qi];
           const bool contributes = ae > 0.0f;
-          if (contributes && T > 0.5f) { med = dz[i]; med_c = pos1; }
+          const bool is_med = contributes & (T > 0.5f);
+          med = is_med ? dz[i] : med;
+          med_c = is_med ? pos[i] : med_c;
           N0 += nr.x * w; N1 += nr.y * w; N2 += nr.z * w;
           C0 += nr.w * w; C1 += gb.x * w; C2 += gb.y * w;
           T = done ? T : test_T;
-          last = contributes ? pos1 : last;
+          last = contributes ? pos[i] : last;
         }
       }
-      head = (head + nslots) & (k2FRing - 1);
+      head = (head + k2FGroup) & (k2FRing - 1);
       count -= nslots;
-    }
+    };
+    while (count >= k2FGroup) blend_group(std::true_type{}, k2FGroup);
+    if (last_chunk && count > 0) blend_group(std::false_type{}, count);
   }
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
@@ -468,7 +481,9 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
     const int cnt = __builtin_popcountll(m);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int s = 0; s < cnt; s++) {
+    for (int s_ = 0; s_ < cnt; s_++) {
+      int s = s_;
+      asm volatile("" : "+v"(s));   // one VGPR slot index: the ds_reads below share it instead of re-moving SGPR bases
       const uint32_t pos1 = q_pos[s];
       const float4 a0 = q0[s], a1 = q1[s], a2 = q2[s];
       Eval2 h;
