@@ -37,6 +37,13 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
   __shared__ float s_sh[256 * kShStride];
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.N;
+  // Full blocks of the split K = 16 layout start their SH rows on the way to LDS right now (direct global -> LDS
+  // loads), so the 48 KiB stream overlaps the projection maths instead of following it.
+  constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
+  const size_t i0 = (size_t)blockIdx.x * 256;
+  const int nrows_f = min(256, a.N - (int)i0);
+  const bool lin = SPLIT && NFL == 48 && a.shs != nullptr && a.K == 16 && nrows_f == 256;
+  if (lin) stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
   float vm[16], pm[16];
 #pragma unroll
   for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
@@ -136,14 +143,12 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
   float rgb[3] = {0.0f, 0.0f, 0.0f};
   int clamp_bits = 0;
   if (a.shs) {
+    if (lin) stage_sh_wait();
     if (__syncthreads_or(vis ? 1 : 0)) {  // a block with nothing visible never touches its SH rows
-      constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
-      const size_t i0 = (size_t)blockIdx.x * 256;
-      const int nrows_f = min(256, a.N - (int)i0);
-      const bool lin = SPLIT && NFL == 48 && a.K == 16 && nrows_f == 256;
-      if (lin) stage_sh_linear(s_sh, a.shs, a.shs_rest, i0);
-      else stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows_f);
-      __syncthreads();
+      if (!lin) {
+        stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows_f);
+        __syncthreads();
+      }
       if (vis) {
         const float dx = px_ - a.campos[0], dy = py_ - a.campos[1], dz = pz_ - a.campos[2];
         const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -194,17 +199,22 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
   bool staged = false;
   const bool lin = SPLIT && NFL == 48 && a.K == 16 && nrows == 256;
   if (a.shs) {
-    if (__syncthreads_or(visible ? 1 : 0)) {
-      if (lin) stage_sh_linear(s_sh, a.shs, a.shs_rest, i0);
-      else stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows);
+    if (lin) {  // direct global -> LDS loads, in flight while the geometry chain below runs
+      stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
       staged = true;
+    } else {
+      if (__syncthreads_or(visible ? 1 : 0)) {
+        stage_sh_rows<NFL, SPLIT>(s_sh, a.shs, a.shs_rest, a.K, i0, nrows);
+        staged = true;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   float vm[16], pm[16];
 #pragma unroll
   for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
   float gm[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gc6[6] = {0, 0, 0, 0, 0, 0};
+  float shx = 0, shy = 0, shz = 0, shinv = 0, gr3[3] = {0, 0, 0};
   float a_[kAccStride];
 #pragma unroll
   for (int q = 0; q < kAccStride; q++) a_[q] = 0.0f;
@@ -313,17 +323,12 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
       const float o = act_opacity(a.opacities[i], a.raw);
       g_op *= o * (1.0f - o);
     }
-    if (a.shs) {
+    if (a.shs) {   // the SH part itself runs after the rows have landed in LDS (below)
       const float d0 = p0 - a.campos[0], d1 = p1 - a.campos[1], d2_ = p2 - a.campos[2];
-      const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2_ * d2_);
-      const float x = d0 * inv, y = d1 * inv, z = d2_ * inv;
-      float gdir[3] = {0, 0, 0};
-      float gr3[3];
+      shinv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2_ * d2_);
+      shx = d0 * shinv; shy = d1 * shinv; shz = d2_ * shinv;
 #pragma unroll
       for (int ch = 0; ch < 3; ch++) gr3[ch] = ((rad_bits >> (kClampShift + ch)) & 1) ? 0.0f : a_[6 + ch];
-      sh_row_backward<DEG>(row, x, y, z, gr3, want_sh_grad, gdir);
-      const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
-      gm[0] += (gdir[0] - x * dot) * inv; gm[1] += (gdir[1] - y * dot) * inv; gm[2] += (gdir[2] - z * dot) * inv;
     }
     if (!a.cov3D_precomp) {
       const float r = qn.x, x = qn.y, y = qn.z, z = qn.w;
@@ -356,6 +361,13 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
         gq[2] = (gq[2] - y * dotq) * inv_qn; gq[3] = (gq[3] - z * dotq) * inv_qn;
       }
     }
+  }
+  if (a.shs && lin) { stage_sh_wait(); __syncthreads(); }
+  if (visible && a.shs) {
+    float gdir[3] = {0, 0, 0};
+    sh_row_backward<DEG>(row, shx, shy, shz, gr3, want_sh_grad, gdir);
+    const float dot = shx * gdir[0] + shy * gdir[1] + shz * gdir[2];
+    gm[0] += (gdir[0] - shx * dot) * shinv; gm[1] += (gdir[1] - shy * dot) * shinv; gm[2] += (gdir[2] - shz * dot) * shinv;
   } else if (want_sh_grad && active) {
     sh_row_zero(row);
   }

@@ -139,6 +139,25 @@ __device__ __forceinline__ void stage_sh_linear(float *__restrict__ lds, const f
   for (int e = threadIdx.x; e < 256 * 3 / 4; e += 256) l4[e] = d4[e];
   for (int e = threadIdx.x; e < 256 * 45 / 4; e += 256) lr4[e] = r4[e];
 }
+// The same copy issued as direct global -> LDS loads (global_load_lds_dwordx4: each lane's 16 bytes land at
+// M0 base + lane * 16, no VGPR round trip).  Fire-and-forget: the caller does its other work, then
+// stage_sh_wait() + a workgroup barrier before anyone reads the rows.  48 wave-chunks of 1 KiB, 12 per wave.
+__device__ __forceinline__ void stage_sh_linear_async(float *__restrict__ lds, const float *__restrict__ dc,
+                                                      const float *__restrict__ rest, size_t i0) {
+  typedef const __attribute__((address_space(1))) void *GPtr;
+  typedef __attribute__((address_space(3))) void *LPtr;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float4 *d4 = reinterpret_cast<const float4 *>(dc + i0 * 3), *r4 = reinterpret_cast<const float4 *>(rest + i0 * 45);
+  float4 *l4 = reinterpret_cast<float4 *>(lds), *lr4 = reinterpret_cast<float4 *>(lds + kShLinearRest);
+#pragma unroll
+  for (int q = 0; q < 12; q++) {
+    const int c = wave + 4 * q;   // wave-uniform chunk id: 0..2 dc, 3..47 rest
+    if (c < 3) __builtin_amdgcn_global_load_lds((GPtr)(d4 + c * 64 + lane), (LPtr)(l4 + c * 64), 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((GPtr)(r4 + (c - 3) * 64 + lane), (LPtr)(lr4 + (c - 3) * 64), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ void stage_sh_wait() { __builtin_amdgcn_s_waitcnt(0); }
+
 __device__ __forceinline__ void unstage_sh_linear(const float *__restrict__ lds, float *__restrict__ g_dc,
                                                   float *__restrict__ g_rest, size_t i0) {
   float4 *d4 = reinterpret_cast<float4 *>(g_dc + i0 * 3), *r4 = reinterpret_cast<float4 *>(g_rest + i0 * 45);
