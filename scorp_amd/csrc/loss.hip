@@ -19,6 +19,8 @@ constexpr int kLH = 5;             // halo
 constexpr int kLP = kLT + 2 * kLH; // patch edge (42)
 constexpr int kLPS = kLP + 3;      // patch row stride 45: the 4-wide horizontal work items hit 32 distinct banks
 constexpr int kLHS = kLT + 1;      // row stride of the horizontal-pass results (33: conflict-free writes)
+constexpr int kHO = 6;             // output columns per horizontal work item
+constexpr int kHG = (kLT + kHO - 1) / kHO;  // groups per patch row (6): kLP * kHG = 252 items <= 256 threads
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 struct Window { float w[11]; };
@@ -42,14 +44,31 @@ __device__ __forceinline__ float block_sum_256(float v, float *s_red) {
   return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+// Workgroup -> (channel, tile) with XCD locality: the hardware deals consecutive workgroup ids round-robin to the 8
+// XCDs, each with its own L2.  Giving XCD x the x-th contiguous eighth of the (channel, tile-row, tile-column) order
+// keeps neighbouring tiles — which share their 5-pixel halos — in one L2 instead of refetching them over the fabric.
+struct LossTile { int ch, x0, y0, logical; bool valid; };
+__device__ __forceinline__ LossTile loss_tile(int gx, int gy, int C) {
+  const int total = gx * gy * C, per = (total + 7) / 8;
+  const int b = blockIdx.x, logical = (b & 7) * per + (b >> 3);
+  LossTile t;
+  t.valid = (b >> 3) < per && logical < total;
+  t.logical = logical;
+  t.ch = logical / (gx * gy);
+  const int rem = logical - t.ch * gx * gy;
+  t.y0 = (rem / gx) * kLT; t.x0 = (rem % gx) * kLT;
+  return t;
+}
+
 __global__ void __launch_bounds__(256)
 ssim_l1_forward_kernel(const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ mask,
-                       int H, int W, Window win, float *__restrict__ dmaps, float *__restrict__ partials) {
+                       int C, int H, int W, Window win, float *__restrict__ dmaps, float *__restrict__ partials) {
   __shared__ float s_x[kLP][kLPS], s_y[kLP][kLPS];
-  __shared__ float s_h[5][kLP][kLHS];
+  __shared__ float s_h[4][kLP][kLHS];   // mu1, mu2, E[x^2] + E[y^2] (only the sum enters SSIM and d/dx), E[xy]
   __shared__ float s_red[4];
-  const int ch = blockIdx.z;
-  const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+  const LossTile lt = loss_tile((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+  if (!lt.valid) return;
+  const int ch = lt.ch, x0 = lt.x0, y0 = lt.y0;
   const size_t HW = (size_t)H * W;
   const float *xp = img + ch * HW, *yp = gt + ch * HW;
   for (int i = threadIdx.x; i < kLP * kLP; i += 256) {
@@ -64,45 +83,53 @@ ssim_l1_forward_kernel(const float *__restrict__ img, const float *__restrict__ 
     s_x[r][c] = xv; s_y[r][c] = yv;
   }
   __syncthreads();
-  // horizontal pass: each work item = one patch row x 4 adjacent output columns
-  for (int it = threadIdx.x; it < kLP * (kLT / 4); it += 256) {
-    const int r = it / (kLT / 4), c0 = (it % (kLT / 4)) * 4;
-    float xs[14], ys[14];
+  // horizontal pass: one work item = one patch row x 6 adjacent output columns, 42 x 6 = 252 items = one pass of the
+  // workgroup; the products x^2, y^2, xy are formed once per loaded element, not once per tap
+  {
+    const int it = threadIdx.x;
+    const int r = it / kHG, c0 = (it % kHG) * kHO;
+    if (it < kLP * kHG) {
+      float xs[kHO + 10], ys[kHO + 10], ss[kHO + 10], xy[kHO + 10];
 #pragma unroll
-    for (int k = 0; k < 14; k++) { xs[k] = s_x[r][c0 + k]; ys[k] = s_y[r][c0 + k]; }
-#pragma unroll
-    for (int o = 0; o < 4; o++) {
-      float m1 = 0, m2 = 0, e11 = 0, e22 = 0, e12 = 0;
-#pragma unroll
-      for (int k = 0; k < 11; k++) {
-        const float w = win.w[k], xv = xs[o + k], yv = ys[o + k];
-        m1 += w * xv; m2 += w * yv; e11 += w * xv * xv; e22 += w * yv * yv; e12 += w * xv * yv;
+      for (int k = 0; k < kHO + 10; k++) {
+        const bool in = c0 + k < kLP;   // the last group of a row covers columns 30..35 of 32
+        xs[k] = in ? s_x[r][c0 + k] : 0.0f; ys[k] = in ? s_y[r][c0 + k] : 0.0f;
+        ss[k] = xs[k] * xs[k] + ys[k] * ys[k]; xy[k] = xs[k] * ys[k];
       }
-      s_h[0][r][c0 + o] = m1; s_h[1][r][c0 + o] = m2; s_h[2][r][c0 + o] = e11; s_h[3][r][c0 + o] = e22; s_h[4][r][c0 + o] = e12;
+#pragma unroll
+      for (int o = 0; o < kHO; o++) {
+        float m1 = 0, m2 = 0, ess = 0, e12 = 0;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+          const float w = win.w[k];
+          m1 += w * xs[o + k]; m2 += w * ys[o + k]; ess += w * ss[o + k]; e12 += w * xy[o + k];
+        }
+        if (c0 + o < kLT) { s_h[0][r][c0 + o] = m1; s_h[1][r][c0 + o] = m2; s_h[2][r][c0 + o] = ess; s_h[3][r][c0 + o] = e12; }
+      }
     }
   }
   __syncthreads();
   // vertical pass: thread = one column x 4 adjacent rows
   const int c = threadIdx.x % kLT, r0 = (threadIdx.x / kLT) * 4;
   float l1_sum = 0.0f, ssim_sum = 0.0f;
-  float col[5][14];
+  float col[4][14];
 #pragma unroll
-  for (int q = 0; q < 5; q++)
+  for (int q = 0; q < 4; q++)
 #pragma unroll
     for (int k = 0; k < 14; k++) col[q][k] = s_h[q][r0 + k][c];
 #pragma unroll
   for (int o = 0; o < 4; o++) {
-    float m1 = 0, m2 = 0, e11 = 0, e22 = 0, e12 = 0;
+    float m1 = 0, m2 = 0, ess = 0, e12 = 0;
 #pragma unroll
     for (int k = 0; k < 11; k++) {
       const float w = win.w[k];
-      m1 += w * col[0][o + k]; m2 += w * col[1][o + k]; e11 += w * col[2][o + k]; e22 += w * col[3][o + k]; e12 += w * col[4][o + k];
+      m1 += w * col[0][o + k]; m2 += w * col[1][o + k]; ess += w * col[2][o + k]; e12 += w * col[3][o + k];
     }
     const int gy = y0 + r0 + o, gx = x0 + c;
     if (gy < H && gx < W) {
       const float m1s = m1 * m1, m2s = m2 * m2, m12 = m1 * m2;
-      const float s1 = e11 - m1s, s2 = e22 - m2s, s12 = e12 - m12;
-      const float A1 = 2 * m12 + kC1, A2 = 2 * s12 + kC2, B1 = m1s + m2s + kC1, B2 = s1 + s2 + kC2;
+      const float s12 = e12 - m12;
+      const float A1 = 2 * m12 + kC1, A2 = 2 * s12 + kC2, B1 = m1s + m2s + kC1, B2 = (ess - m1s - m2s) + kC2;
       const float inv = 1.0f / (B1 * B2);
       const float ssim = A1 * A2 * inv;
       ssim_sum += ssim;
@@ -110,7 +137,7 @@ ssim_l1_forward_kernel(const float *__restrict__ img, const float *__restrict__ 
       l1_sum += fabsf(xv - yv);
       if (dmaps) {
         const size_t p = (size_t)gy * W + gx;
-        const size_t CHW = (size_t)gridDim.z * HW;
+        const size_t CHW = (size_t)C * HW;
         dmaps[ch * HW + p] = (2 * m2 * (A2 - A1) - 2 * m1 * ssim * (B2 - B1)) * inv;  // d ssim / d mu1
         dmaps[CHW + ch * HW + p] = -ssim / B2;                                        // d ssim / d E[x^2]
         dmaps[2 * CHW + ch * HW + p] = 2 * A1 * inv;                                   // d ssim / d E[xy]
@@ -120,7 +147,7 @@ ssim_l1_forward_kernel(const float *__restrict__ img, const float *__restrict__ 
   const float bl1 = block_sum_256(l1_sum, s_red);
   const float bss = block_sum_256(ssim_sum, s_red);
   if (threadIdx.x == 0) {
-    const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int b = lt.logical;
     partials[2 * b] = bl1;
     partials[2 * b + 1] = bss;
   }
@@ -147,65 +174,74 @@ loss_finalize_kernel(const float *__restrict__ partials, int nblocks, double n_e
 
 __global__ void __launch_bounds__(256)
 ssim_l1_backward_kernel(const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ mask,
-                        const float *__restrict__ dmaps, int H, int W, Window win, float lambda, float inv_n,
+                        const float *__restrict__ dmaps, int C, int H, int W, Window win, float lambda, float inv_n,
                         const float *__restrict__ grad_out, float *__restrict__ grad_img) {
-  __shared__ float s_m[3][kLP][kLPS];
-  __shared__ float s_h[3][kLP][kLHS];
-  const int ch = blockIdx.z;
-  const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
-  const size_t HW = (size_t)H * W, CHW = (size_t)gridDim.z * HW;
-  for (int i = threadIdx.x; i < kLP * kLP; i += 256) {
-    const int r = i / kLP, c = i % kLP;
-    const int gy = y0 + r - kLH, gx = x0 + c - kLH;
-    float a = 0, b = 0, d = 0;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      const size_t p = ch * HW + (size_t)gy * W + gx;
-      a = dmaps[p]; b = dmaps[CHW + p]; d = dmaps[2 * CHW + p];
-    }
-    s_m[0][r][c] = a; s_m[1][r][c] = b; s_m[2][r][c] = d;
-  }
-  __syncthreads();
-  for (int it = threadIdx.x; it < kLP * (kLT / 4); it += 256) {
-    const int r = it / (kLT / 4), c0 = (it % (kLT / 4)) * 4;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      float v[14];
-#pragma unroll
-      for (int k = 0; k < 14; k++) v[k] = s_m[q][r][c0 + k];
-#pragma unroll
-      for (int o = 0; o < 4; o++) {
-        float s = 0;
-#pragma unroll
-        for (int k = 0; k < 11; k++) s += win.w[k] * v[o + k];
-        s_h[q][r][c0 + o] = s;
-      }
-    }
-  }
-  __syncthreads();
+  // The three derivative maps go through the same two LDS buffers one after the other (13 KB per workgroup instead
+  // of 39 KB: occupancy, not arithmetic, limits this kernel); each thread accumulates its four output pixels.
+  __shared__ float s_m[kLP][kLPS];
+  __shared__ float s_h[kLP][kLHS];
+  const LossTile lt = loss_tile((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+  if (!lt.valid) return;
+  const int ch = lt.ch, x0 = lt.x0, y0 = lt.y0;
+  const size_t HW = (size_t)H * W, CHW = (size_t)C * HW;
   const int c = threadIdx.x % kLT, r0 = (threadIdx.x / kLT) * 4;
   const float go = grad_out ? grad_out[0] : 1.0f;
-  float col[3][14];
+  float xv[4], yv[4], mk[4], acc[4];
 #pragma unroll
-  for (int q = 0; q < 3; q++)
+  for (int o = 0; o < 4; o++) {
+    const int gy = y0 + r0 + o, gx = x0 + c;
+    xv[o] = yv[o] = mk[o] = acc[o] = 0.0f;
+    if (gy < H && gx < W) {
+      const size_t p = (size_t)gy * W + gx;
+      mk[o] = mask ? mask[p] : 1.0f;
+      xv[o] = img[ch * HW + p] * mk[o]; yv[o] = gt[ch * HW + p] * mk[o];
+    }
+  }
+#pragma unroll 1
+  for (int q = 0; q < 3; q++) {
+    const float *map = dmaps + q * CHW + ch * HW;
+    for (int i = threadIdx.x; i < kLP * kLP; i += 256) {
+      const int r = i / kLP, cc = i % kLP;
+      const int gy = y0 + r - kLH, gx = x0 + cc - kLH;
+      s_m[r][cc] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? map[(size_t)gy * W + gx] : 0.0f;
+    }
+    __syncthreads();
+    {  // horizontal pass: 42 rows x 6 groups of 6 output columns = 252 work items, one pass
+      const int it = threadIdx.x;
+      const int r = it / kHG, c0 = (it % kHG) * kHO;
+      if (it < kLP * kHG) {
+        float v[kHO + 10];
 #pragma unroll
-    for (int k = 0; k < 14; k++) col[q][k] = s_h[q][r0 + k][c];
+        for (int k = 0; k < kHO + 10; k++) v[k] = c0 + k < kLP ? s_m[r][c0 + k] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < kHO; o++) {
+          float sacc = 0;
+#pragma unroll
+          for (int k = 0; k < 11; k++) sacc += win.w[k] * v[o + k];
+          if (c0 + o < kLT) s_h[r][c0 + o] = sacc;
+        }
+      }
+    }
+    __syncthreads();
+    float col[14];
+#pragma unroll
+    for (int k = 0; k < 14; k++) col[k] = s_h[r0 + k][c];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float cv = 0;
+#pragma unroll
+      for (int k = 0; k < 11; k++) cv += win.w[k] * col[o + k];
+      acc[o] += q == 0 ? cv : (q == 1 ? 2.0f * xv[o] * cv : yv[o] * cv);   // ca + 2 x cb + y cd
+    }
+  }
 #pragma unroll
   for (int o = 0; o < 4; o++) {
     const int gy = y0 + r0 + o, gx = x0 + c;
     if (gy < H && gx < W) {
-      float ca = 0, cb = 0, cd = 0;
-#pragma unroll
-      for (int k = 0; k < 11; k++) {
-        const float w = win.w[k];
-        ca += w * col[0][o + k]; cb += w * col[1][o + k]; cd += w * col[2][o + k];
-      }
-      const size_t p = (size_t)gy * W + gx;
-      const float m = mask ? mask[p] : 1.0f;
-      const float xv = img[ch * HW + p] * m, yv = gt[ch * HW + p] * m;
-      const float diff = xv - yv;
+      const float diff = xv[o] - yv[o];
       const float sgn = diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f);
-      const float g = (1.0f - lambda) * sgn - lambda * (ca + 2.0f * xv * cb + yv * cd);
-      grad_img[ch * HW + p] = go * inv_n * m * g;
+      const float g = (1.0f - lambda) * sgn - lambda * acc[o];
+      grad_img[ch * HW + (size_t)gy * W + gx] = go * inv_n * mk[o] * g;
     }
   }
 }
@@ -233,11 +269,11 @@ extern "C" int scorp_loss_l1_ssim_forward(const float *img, const float *gt, con
   hipStream_t stream = (hipStream_t)stream_;
   float *dmaps = (float *)workspace;
   float *partials = (float *)((char *)workspace + align_up((size_t)3 * C * H * W * 4, 256));
-  const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+  const int grid = (loss_blocks(C, H, W) + 7) / 8 * 8;
   const Window win = make_window();
   {
     ProfScope prof(kKLossForward, stream);
-    ssim_l1_forward_kernel<<<grid, 256, 0, stream>>>(img, gt, mask, H, W, win, need_backward ? dmaps : nullptr, partials);
+    ssim_l1_forward_kernel<<<grid, 256, 0, stream>>>(img, gt, mask, C, H, W, win, need_backward ? dmaps : nullptr, partials);
   }
   SCORP_KERNEL_CHECK("ssim_l1_forward", 0, stream);
   loss_finalize_kernel<<<1, 256, 0, stream>>>(partials, loss_blocks(C, H, W), (double)C * H * W, lambda_dssim, out_loss3);
@@ -250,11 +286,11 @@ extern "C" int scorp_loss_l1_ssim_backward(const float *img, const float *gt, co
                                            float *grad_img, scorp_stream_t stream_) {
   if (!img || !gt || !workspace || !grad_img) { set_error("NULL argument to scorp_loss_l1_ssim_backward"); return SCORP_ERR_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
-  const dim3 grid((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+  const int grid = (loss_blocks(C, H, W) + 7) / 8 * 8;
   const Window win = make_window();
   {
     ProfScope prof(kKLossBackward, stream);
-    ssim_l1_backward_kernel<<<grid, 256, 0, stream>>>(img, gt, mask, (const float *)workspace, H, W, win, lambda_dssim,
+    ssim_l1_backward_kernel<<<grid, 256, 0, stream>>>(img, gt, mask, (const float *)workspace, C, H, W, win, lambda_dssim,
                                                       (float)(1.0 / ((double)C * H * W)), grad_out, grad_img);
   }
   SCORP_KERNEL_CHECK("ssim_l1_backward", 0, stream);

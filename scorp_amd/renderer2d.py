@@ -59,11 +59,10 @@ def depth_to_normal(view, depth):
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # gradient sink for the screen-space means; the reference builds it as `zeros_like(...) + 0` with retain_grad()
+    # (gaussian_renderer/__init__.py:39-43) — a leaf with requires_grad gives the caller the same `.grad` without the
+    # extra 12 MB add kernel per view
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
     tanfovx, tanfovy = math.tan(viewpoint_camera.FoVx * 0.5), math.tan(viewpoint_camera.FoVy * 0.5)
     w, h = viewpoint_camera.resolution
     raster_settings = GaussianRasterizationSettings(
