@@ -84,14 +84,16 @@ scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__re
 //   scatter: the block reloads its row (+ tile_start) as LDS cursors and ranks its pairs with returning LDS atomics.
 // Slot order inside a tile is arbitrary but deterministic; the per-tile depth sort fixes the final order.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+constexpr int kBinThreads = 1024;   // few Gaussians per thread: the count / scatter loops are latency chains (load -> LDS atomic -> store)
+
+__global__ void __launch_bounds__(kBinThreads)
 count_tiles_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
                        int tiles, int tiles_x, uint32_t *__restrict__ block_hist) {
   extern __shared__ uint32_t s_hist[];
-  for (int t = threadIdx.x; t < tiles; t += 256) s_hist[t] = 0;
+  for (int t = threadIdx.x; t < tiles; t += kBinThreads) s_hist[t] = 0;
   __syncthreads();
   const int lo = blockIdx.x * per_block, hi = min(N, lo + per_block);
-  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+  for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
     const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
     const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
     if ((br.radius & kRadiusMask) == 0) continue;
@@ -99,7 +101,7 @@ count_tiles_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, con
   }
   __syncthreads();
   uint32_t *row = block_hist + (size_t)blockIdx.x * tiles;
-  for (int t = threadIdx.x; t < tiles; t += 256) row[t] = s_hist[t];
+  for (int t = threadIdx.x; t < tiles; t += kBinThreads) row[t] = s_hist[t];
 }
 
 // 64 tiles x 16 segments of the block range per workgroup: wave `seg` sums its blocks for 64 consecutive tiles
@@ -128,7 +130,7 @@ scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uin
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kBinThreads)
 scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
                          int tiles, int tiles_x,
                          const uint32_t *__restrict__ block_hist, const uint32_t *__restrict__ tile_start,
@@ -139,10 +141,10 @@ scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, c
     if (header->num_pairs > capacity) header->overflow = 1;
   }
   const uint32_t *row = block_hist + (size_t)blockIdx.x * tiles;
-  for (int t = threadIdx.x; t < tiles; t += 256) s_cur[t] = tile_start[t] + row[t];
+  for (int t = threadIdx.x; t < tiles; t += kBinThreads) s_cur[t] = tile_start[t] + row[t];
   __syncthreads();
   const int lo = blockIdx.x * per_block, hi = min(N, lo + per_block);
-  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+  for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
     const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
     const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
     if ((br.radius & kRadiusMask) == 0) continue;
@@ -469,7 +471,7 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
     uint32_t *block_hist = (uint32_t *)(base + L.block_hist);
     {
       ProfScope prof(kKCountTiles, stream);
-      count_tiles_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(N, per_block, (const BinRec *)(base + L.bin),
+      count_tiles_lds_kernel<<<L.nb, kBinThreads, (size_t)L.tiles * 4, stream>>>(N, per_block, (const BinRec *)(base + L.bin),
                                                                         (const uint64_t *)(base + L.tile_mask), L.tiles,
                                                                         L.tiles_x, block_hist);
       scan_block_hist_kernel<<<(L.tiles + 63) / 64, 1024, 0, stream>>>(L.nb, L.tiles, block_hist, tile_count);
@@ -495,7 +497,7 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
     ProfScope prof(kKScatterPairs, stream);
     if (L.lds_binning) {
       const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
-      scatter_pairs_lds_kernel<<<L.nb, 256, (size_t)L.tiles * 4, stream>>>(
+      scatter_pairs_lds_kernel<<<L.nb, kBinThreads, (size_t)L.tiles * 4, stream>>>(
           N, per_block, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
           (const uint32_t *)(base + L.block_hist), tile_start, keys, capacity, header);
     } else {
