@@ -67,7 +67,7 @@ __device__ __forceinline__ float conic_min_over_box(float cx, float cy, float A,
                                                     float by0, float by1) {
   const float x0 = bx0 - cx, x1 = bx1 - cx, y0 = by0 - cy, y1 = by1 - cy;
   if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return 0.0f;
-  const float iC = 1.0f / C, iA = 1.0f / A;
+  const float iC = __builtin_amdgcn_rcpf(C), iA = __builtin_amdgcn_rcpf(A);   // 1 ulp: far inside the cull slack
   float best = 3.4e38f;
 #pragma unroll
   for (int e = 0; e < 2; e++) {
