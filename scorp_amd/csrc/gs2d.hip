@@ -720,6 +720,9 @@ int validate2(const ScorpGs3dInputs *in) {
     }
   }
   if (!in->bg || !in->viewmatrix || !in->projmatrix || !in->campos) { set_error("bg / matrices / campos is NULL"); return SCORP_ERR_INVALID; }
+  if ((((uintptr_t)in->shs | (uintptr_t)in->shs_rest | (uintptr_t)in->rotations) & 15) != 0) {
+    set_error("shs / shs_rest / rotations must be 16-byte aligned"); return SCORP_ERR_INVALID;
+  }
   return SCORP_OK;
 }
 

@@ -457,6 +457,10 @@ int validate(const ScorpGs3dInputs *in) {
   if (!in->bg || !in->viewmatrix || !in->projmatrix || !in->campos) {
     set_error("bg / viewmatrix / projmatrix / campos is NULL"); return SCORP_ERR_INVALID;
   }
+  // SH rows and quaternions are fetched as 16-byte words (and SH rows by direct global -> LDS loads)
+  if ((((uintptr_t)in->shs | (uintptr_t)in->shs_rest | (uintptr_t)in->rotations) & 15) != 0) {
+    set_error("shs / shs_rest / rotations must be 16-byte aligned"); return SCORP_ERR_INVALID;
+  }
   return SCORP_OK;
 }
 

@@ -83,7 +83,10 @@ def _prep(t, name, shape_tail=None):
         raise RuntimeError(f"{name} must be a GPU tensor (scorp_amd has no CPU path)")
     if t.dtype != torch.float32:
         t = t.float()
-    return t.contiguous()
+    t = t.contiguous()
+    if t.data_ptr() % 16:      # an offset view: the kernels fetch 16-byte words
+        t = t.clone()
+    return t
 
 
 def _inputs_struct(s, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D, keep, sh_rest=None, raw=0):

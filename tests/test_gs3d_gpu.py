@@ -392,3 +392,37 @@ def test_fused_activation_path_matches_reference_convention(deg, maxdeg, dev):
             assert int((rowdiff > 2e-3 * a.abs().max() + 1e-12).sum()) <= 4, name
             assert rowdiff.max() <= 2e-2 * a.abs().max() + 1e-12, name
     assert (r0["viewspace_points"].grad - r1["viewspace_points"].grad).abs().max() <= 2e-2 * r0["viewspace_points"].grad.abs().max()
+
+
+def test_offset_views_and_alignment_contract(dev):
+    """SH rows / quaternions are fetched as 16-byte words: the C ABI rejects misaligned pointers with an error, and the
+    Python front-end realigns offset views (e.g. `params[1:]` of a larger buffer), giving the same image."""
+    import ctypes
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from scorp_amd import _C, rasterizer3d as R
+    kw, _ = make_case(300, 64, 48, 3, 5, bg=(0.2, 0.1, 0.4))
+    out_ref, _ = hip_render(kw, dev, requires_grad=False)
+    T = lambda a: torch.tensor(a, device=dev)
+    N = kw["means3D"].shape[0]
+    pad = lambda a: torch.cat([torch.zeros((1,) + a.shape[1:], device=dev), T(a)])[1:]   # data_ptr offset by one row
+    shs, rot = pad(kw["shs"]), pad(kw["rotations"])
+    s = GaussianRasterizationSettings(kw["H"], kw["W"], kw["tanfovx"], kw["tanfovy"], T(kw["bg"]), 1.0, T(kw["view"]), T(kw["proj"]),
+                                      kw["sh_degree"], T(kw["campos"]), False, False)
+    with torch.no_grad():
+        out = GaussianRasterizer(raster_settings=s)(means3D=T(kw["means3D"]), means2D=torch.zeros(N, 3, device=dev),
+                                                    opacities=T(kw["opacities"].reshape(N, 1)), shs=shs,
+                                                    scales=T(kw["scales"]), rotations=rot)
+    assert torch.equal(out[0], out_ref[0]) and torch.equal(out[1], out_ref[1])
+    # raw C ABI: a pointer that is only 4-byte aligned is refused, not dereferenced
+    L = _C.lib()
+    keep = []
+    big = torch.zeros(N * 48 + 1, device=dev)
+    mis = big[1:].view(N, 16, 3)
+    assert mis.data_ptr() % 16 == 4
+    args = R._inputs_struct(s, T(kw["means3D"]), T(kw["shs"]), None, T(kw["opacities"]), T(kw["scales"]), T(kw["rotations"]), None, keep)
+    args.shs = mis.data_ptr()
+    sb = L.scorp_gs3d_state_bytes(N, kw["W"], kw["H"])
+    state = torch.empty(sb, dtype=torch.uint8, device=dev)
+    radii = torch.empty(N, dtype=torch.int32, device=dev)
+    rc = L.scorp_gs3d_preprocess(ctypes.byref(args), R._ptr(radii), R._ptr(state), sb, R._stream())
+    assert rc != 0 and b"aligned" in L.scorp_last_error()
