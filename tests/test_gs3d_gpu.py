@@ -404,7 +404,12 @@ def test_offset_views_and_alignment_contract(dev):
     out_ref, _ = hip_render(kw, dev, requires_grad=False)
     T = lambda a: torch.tensor(a, device=dev)
     N = kw["means3D"].shape[0]
-    pad = lambda a: torch.cat([torch.zeros((1,) + a.shape[1:], device=dev), T(a)])[1:]   # data_ptr offset by one row
+    def pad(a):   # same values in a view whose data_ptr is only 4-byte aligned
+        flat = torch.zeros(a.size + 1, device=dev)
+        v = flat[1:].view(a.shape)
+        v.copy_(T(a))
+        assert v.data_ptr() % 16 == 4 and v.is_contiguous()
+        return v
     shs, rot = pad(kw["shs"]), pad(kw["rotations"])
     s = GaussianRasterizationSettings(kw["H"], kw["W"], kw["tanfovx"], kw["tanfovy"], T(kw["bg"]), 1.0, T(kw["view"]), T(kw["proj"]),
                                       kw["sh_degree"], T(kw["campos"]), False, False)
