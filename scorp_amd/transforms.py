@@ -17,22 +17,23 @@ def quat_multiply(a, b):
 
 
 def matrix_to_quat(R):
-    """One proper rotation matrix -> (w,x,y,z), numerically safe branch selection."""
+    """One proper rotation matrix -> (w,x,y,z).  The four candidate formulas (largest of trace / diagonal entries) are
+    all evaluated and selected with torch.where, so a device matrix never forces a host synchronisation (the sweep
+    captures this in a HIP graph)."""
     R = R.double()
-    t = R.trace()
-    if t > 0:
-        s = torch.sqrt(t + 1.0) * 2
-        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
-    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
-        s = torch.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
-        q = [(R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s]
-    elif R[1, 1] > R[2, 2]:
-        s = torch.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
-        q = [(R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s]
-    else:
-        s = torch.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
-        q = [(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s]
-    return torch.stack([torch.as_tensor(v) for v in q]).float()
+    m00, m11, m22 = R[0, 0], R[1, 1], R[2, 2]
+    t = m00 + m11 + m22
+    eps = 1e-300
+
+    def cand(s2, w, x, y, z):
+        s = torch.sqrt(torch.clamp_min(s2, eps)) * 2
+        return torch.stack([w(s), x(s), y(s), z(s)])
+    q0 = cand(t + 1.0, lambda s: 0.25 * s, lambda s: (R[2, 1] - R[1, 2]) / s, lambda s: (R[0, 2] - R[2, 0]) / s, lambda s: (R[1, 0] - R[0, 1]) / s)
+    q1 = cand(1.0 + m00 - m11 - m22, lambda s: (R[2, 1] - R[1, 2]) / s, lambda s: 0.25 * s, lambda s: (R[0, 1] + R[1, 0]) / s, lambda s: (R[0, 2] + R[2, 0]) / s)
+    q2 = cand(1.0 + m11 - m00 - m22, lambda s: (R[0, 2] - R[2, 0]) / s, lambda s: (R[0, 1] + R[1, 0]) / s, lambda s: 0.25 * s, lambda s: (R[1, 2] + R[2, 1]) / s)
+    q3 = cand(1.0 + m22 - m00 - m11, lambda s: (R[1, 0] - R[0, 1]) / s, lambda s: (R[0, 2] + R[2, 0]) / s, lambda s: (R[1, 2] + R[2, 1]) / s, lambda s: 0.25 * s)
+    q = torch.where(t > 0, q0, torch.where((m00 > m11) & (m00 > m22), q1, torch.where(m11 > m22, q2, q3)))
+    return q.float()
 
 
 def sh_rotation_blocks(R, max_degree=3):

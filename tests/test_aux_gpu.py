@@ -176,6 +176,11 @@ def test_rotation_sweep_recovers_the_planted_rotation(dev):
     tgt_model._features_rest = m._features_rest.detach().clone()
     gaussians_rotate(tgt_model, torch.tensor(rots[planted], dtype=torch.float32, device=dev), fix_center=True)
     targets = render_views(tgt_model, cams, bg)
-    ids, fit, best = rotation_sweep(m, rots, cams, targets, bg)
+    ids, fit, best = rotation_sweep(m, rots, cams, targets, bg)          # HIP-graph replay on the GPU
     assert ids.numel() == 128 and best == planted
     assert float(fit[planted, 0]) > -1e-6 and float(fit[:, 0].sort().values[-2]) < float(fit[planted, 0]) - 1e-4
+    ids_e, fit_e, best_e = rotation_sweep(m, rots, cams, targets, bg, use_graph=False)   # eager launches
+    assert best_e == planted and torch.equal(ids, ids_e)
+    assert (fit - fit_e).abs().max() < 1e-6
+    # the model itself is untouched by the sweep
+    assert torch.equal(tgt_model._features_dc, m._features_dc)
