@@ -167,15 +167,52 @@ constexpr int kSortLds = 4096;  // 32 KiB of 64-bit keys
 // b % 4 in every stage whose partners are < 128 apart.  Those stages (all of k <= 128 and every j <= 64) therefore
 // need no workgroup barrier: a wave's LDS operations retire in order, a wave-level fence is enough.  Only the few
 // stages that cross 128-element blocks synchronise the workgroup (3 of 45 for a 512-entry list).
-template <bool kWaveLocal, typename Ptr>
+__device__ __forceinline__ void ce(uint64_t &lo, uint64_t &hi) {   // compare-exchange, ascending
+  const uint64_t u = lo, v = hi;
+  const bool sw = u > v;
+  lo = sw ? v : u; hi = sw ? u : v;
+}
+
+// kRegTail (LDS lists only): every thread also owns 4 consecutive keys; the stages whose partners are 1 or 2 apart —
+// two per level, the ones with the worst LDS bank behaviour — and the whole of levels k = 2, 4 run on those four keys
+// in registers, one 16-byte LDS round trip per level instead of one per stage (45 -> 28 LDS stages at 512 keys).
+template <bool kWaveLocal, bool kRegTail, typename Ptr>
 __device__ __forceinline__ void bitonic_sort(Ptr a, uint32_t n, uint32_t P) {
   const uint32_t tid = threadIdx.x;
   auto sync = [&](bool cross) {
     if (!kWaveLocal || cross) __syncthreads();
     else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
   };
+  constexpr uint64_t kInf = ~0ull;
   bool prev_cross = true;  // the loads that filled `a` came from all waves
-  for (uint32_t lk = 1; (1u << lk) <= P; lk++) {
+  // Register phases keep the LDS stages' ownership (128-key block b belongs to wave b % 4), so they too need only a
+  // wave-level fence: lanes 0-31 of wave w take block w (+8, +16, ...), lanes 32-63 block w + 4.
+  auto reg_phase = [&](bool first) {
+    sync(prev_cross);
+    prev_cross = false;
+    const uint32_t w = tid >> 6, l = tid & 63;
+    for (uint32_t b = w + 4 * (l >> 5); 128 * b < P; b += 8) {
+      const uint32_t e = 128 * b + 4 * (l & 31);
+      if (e < n) {
+        uint64_t v0 = a[e], v1 = e + 1 < n ? a[e + 1] : kInf, v2 = e + 2 < n ? a[e + 2] : kInf, v3 = e + 3 < n ? a[e + 3] : kInf;
+        if (first) {
+          ce(v0, v1); ce(v2, v3);   // k = 2
+          ce(v0, v3); ce(v1, v2);   // k = 4: flip
+          ce(v0, v1); ce(v2, v3);   //        j = 1
+        } else {
+          ce(v0, v2); ce(v1, v3);   // j = 2
+          ce(v0, v1); ce(v2, v3);   // j = 1
+        }
+        a[e] = v0;
+        if (e + 1 < n) a[e + 1] = v1;
+        if (e + 2 < n) a[e + 2] = v2;
+        if (e + 3 < n) a[e + 3] = v3;
+      }
+    }
+  };
+  uint32_t lk0 = 1;
+  if (kRegTail && P >= 4) { reg_phase(true); lk0 = 3; }
+  for (uint32_t lk = lk0; (1u << lk) <= P; lk++) {
     const uint32_t k = 1u << lk, half = k >> 1;
     {
       const bool cross = k > 128;
@@ -190,7 +227,8 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, uint32_t n, uint32_t P) {
         }
       }
     }
-    for (int lj = (int)lk - 2; lj >= 0; lj--) {
+    const int lj_min = kRegTail ? 2 : 0;
+    for (int lj = (int)lk - 2; lj >= lj_min; lj--) {
       const uint32_t j = 1u << lj;
       const bool cross = j >= 128;
       sync(cross || prev_cross);
@@ -204,6 +242,7 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, uint32_t n, uint32_t P) {
         }
       }
     }
+    if (kRegTail) reg_phase(false);
   }
   __syncthreads();
 }
@@ -224,13 +263,13 @@ sort_tiles_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict_
   while (P < n) P <<= 1;
   if (n <= (uint32_t)min(lds_limit, kCap)) {
     for (uint32_t i = threadIdx.x; i < n; i += 256) s_keys[i] = keys[beg + i];
-    if (n > 1) bitonic_sort<true>(s_keys, n, P);
+    if (n > 1) bitonic_sort<true, true>(s_keys, n, P);
     else __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[beg + i] = (uint32_t)s_keys[i];
   } else {
     // Oversize tile: same network straight on global memory. Global accesses of one workgroup are made visible
     // to its own waves by the barrier (same CU, same L1/L2).
-    bitonic_sort<false>(keys + beg, n, P);
+    bitonic_sort<false, false>(keys + beg, n, P);
     for (uint32_t i = threadIdx.x; i < n; i += 256) point_list[beg + i] = (uint32_t)keys[beg + i];
   }
 }
