@@ -5,15 +5,22 @@
   post_refine(...)         the 800-iteration appearance refinement of post_refine_gs.py:30-203: everything frozen
                            but the colours, masked L1 + SSIM
 
+  train(..., data_parallel=True)   the same loop on G ranks of ONE scene: rank r renders view
+                           r of every group of G views, the per-Gaussian gradients are averaged (bucketed
+                           all-reduce, RCCL over xGMI), and the densification statistics are reduced before every
+                           densify step so that all replicas clone / split / prune identically
+
 Dataset I/O, tensorboard and checkpoint plumbing of the scripts are out of scope; the loops take
 cameras and ground-truth tensors that are already resident on the GPU.
 """
 import random
 
 import torch
+import torch.distributed as dist
 
 from .fused_loss import fused_l1_ssim_loss
 from .loss import psnr
+from .parallel import average_gradients, world
 from .renderer import render
 
 
@@ -25,23 +32,40 @@ class PipelineParams:
     fused_activations = True
 
 
+def _sync_densification_stats(gaussians):
+    """Before a densify / prune decision every replica must see the same statistics: sums of the screen-space gradient
+    norms and visit counts, max of the screen radii."""
+    _, w = world()
+    if w > 1:
+        dist.all_reduce(gaussians.xyz_gradient_accum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(gaussians.denom, op=dist.ReduceOp.SUM)
+        dist.all_reduce(gaussians.max_radii2D, op=dist.ReduceOp.MAX)
+
+
 def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteration, scene_extent=4.0, densify=True,
-                       render_fn=render):
-    """Returns (loss tensor, render package). Mirrors train_3dgs.py:74-193 for one camera."""
+                       render_fn=render, loss_fn=fused_l1_ssim_loss, data_parallel=False):
+    """Returns (loss tensor, render package). Mirrors train_3dgs.py:74-193 for one camera.  With `data_parallel` the
+    caller hands each rank a different camera; gradients are averaged over ranks before the optimizer step and the
+    densification statistics are reduced before they are used, so the replicas stay bit-identical."""
     gaussians.update_learning_rate(iteration)
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
     bg = torch.rand(3, device=background.device) if opt.random_background else background
     pkg = render_fn(cam, gaussians, pipe, bg)
-    loss = fused_l1_ssim_loss(pkg["render"], gt_image, opt.lambda_dssim)
+    loss = loss_fn(pkg["render"], gt_image, opt.lambda_dssim)
     loss.backward()
     with torch.no_grad():
+        if data_parallel:
+            average_gradients([g["params"][0] for g in gaussians.optimizer.param_groups])
         if densify and iteration < opt.densify_until_iter:
             vis, radii = pkg["visibility_filter"], pkg["radii"]
             gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis].float())
             gaussians.add_densification_stats(pkg["viewspace_points"], vis)
             if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
                 size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+                if data_parallel:
+                    _sync_densification_stats(gaussians)
+                    torch.manual_seed(1_000_003 * iteration)   # densify_and_split samples positions: same draw on every rank
                 gaussians.densify_and_prune(opt.densify_grad_threshold, 0.005, scene_extent, size_threshold)
             if iteration % opt.opacity_reset_interval == 0:
                 gaussians.reset_opacity()
@@ -50,21 +74,29 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
     return loss, pkg
 
 
-def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, background=None, seed=0, **kw):
-    """Runs `iterations` training iterations over shuffled cameras; returns the list of per-iteration losses."""
+def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, background=None, seed=0, data_parallel=False,
+          **kw):
+    """Runs `iterations` training iterations over shuffled cameras; returns the list of per-iteration losses.
+    `data_parallel`: every rank runs this with the same arguments and the same initial model; one iteration then
+    consumes world_size views (rank r takes the r-th of each group), i.e. a batch of views per optimizer step."""
     pipe = pipe or PipelineParams()
     dev = gaussians.get_xyz.device
     background = torch.zeros(3, device=dev) if background is None else background
     if gaussians.optimizer is None:
         gaussians.training_setup(opt)
-    rng = random.Random(seed)
+    rank, w = world() if data_parallel else (0, 1)
+    rng = random.Random(seed)            # same seed on every rank: identical camera order
     stack, losses = [], []
     for it in range(1, (iterations or opt.iterations) + 1):
-        if not stack:
-            stack = list(range(len(cameras)))
-            rng.shuffle(stack)
-        k = stack.pop()
-        loss, _ = training_iteration(gaussians, cameras[k], gt_images[k], opt, pipe, background, it, **kw)
+        ks = []
+        for _ in range(w):
+            if not stack:
+                stack = list(range(len(cameras)))
+                rng.shuffle(stack)
+            ks.append(stack.pop())
+        k = ks[rank]
+        loss, _ = training_iteration(gaussians, cameras[k], gt_images[k], opt, pipe, background, it,
+                                     data_parallel=data_parallel and w > 1, **kw)
         losses.append(loss.detach())
     return [float(l) for l in losses]
 

@@ -99,3 +99,116 @@ def test_sh_rotation_blocks_are_consistent():
     assert abs(float(q.norm()) - 1) < 1e-6
     qq = quat_multiply(q, torch.tensor([1.0, 0, 0, 0]))
     assert torch.allclose(qq, q)
+
+
+# ---- data-parallel training of one scene, two gloo ranks on CPU ----
+class _FakeCam:
+    def __init__(self, k, n_max, hw):
+        g = torch.Generator().manual_seed(100 + k)
+        self.basis = torch.randn(n_max, hw, generator=g) / n_max ** 0.5
+        self.k = k
+
+
+def _fake_render(cam, pc, pipe, bg):
+    """A differentiable stand-in for the rasterizer (the HIP one needs a GPU): every parameter group reaches the image,
+    and the screen-space gradient sink, radii and visibility mask exist with the shapes render() returns."""
+    N = pc.get_xyz.shape[0]
+    vsp = torch.zeros(N, 3, requires_grad=True)
+    B = cam.basis[torch.arange(N) % cam.basis.shape[0]]
+    col = torch.sigmoid(pc._features_dc[:, 0, :] + pc._features_rest.sum(1))
+    geo = ((pc.get_xyz + vsp) * pc.get_scaling * pc.get_rotation[:, 1:]).sum(1, keepdim=True)
+    img = ((col * pc.get_opacity + geo).T @ B).reshape(3, 8, 8) + bg[:, None, None] * 0.01
+    radii = (torch.arange(N) % 5 + (cam.k % 2)).int()
+    return {"render": img, "viewspace_points": vsp, "visibility_filter": radii > 0, "radii": radii}
+
+
+def _plain_loss(img, gt, lambda_dssim):
+    return (img - gt).abs().mean() * (1.0 - lambda_dssim) + ((img - gt) ** 2).mean() * lambda_dssim
+
+
+def _dp_setup():
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.synthetic import make_gaussians
+    m = GaussianModel.from_raw(make_gaussians(40, 1, 3), 1, device="cpu")
+    opt = OptimizationParams()
+    opt.random_background = False
+    opt.densify_from_iter, opt.densification_interval, opt.densify_until_iter = 2, 4, 100
+    opt.opacity_reset_interval, opt.densify_grad_threshold = 9, 1e-9
+    cams = [_FakeCam(k, 64, 64) for k in range(6)]
+    g = torch.Generator().manual_seed(5)
+    gts = [torch.rand(3, 8, 8, generator=g) for _ in cams]
+    return m, opt, cams, gts
+
+
+def _dp_worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from scorp_amd.train import train
+        m, opt, cams, gts = _dp_setup()
+        losses = train(m, cams, gts, opt, iterations=14, data_parallel=True, render_fn=_fake_render, loss_fn=_plain_loss,
+                       scene_extent=4.0)
+        flat = torch.cat([p.detach().reshape(-1) for p in (m._xyz, m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation)])
+        other = [torch.zeros(1, dtype=torch.int64) for _ in range(world_size)]
+        dist.all_gather(other, torch.tensor([flat.numel()]))
+        assert all(int(o) == flat.numel() for o in other), "replicas diverged in size"
+        both = [torch.zeros_like(flat) for _ in range(world_size)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), "replicas diverged"
+        q.put((rank, "ok", m._xyz.shape[0], losses, flat.tolist()))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), 0, [], None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_training_keeps_replicas_identical():
+    """Rank r renders view r of every pair; gradients are averaged, densification statistics reduced: both replicas end
+    bit-identical (through clone / split / prune / opacity reset), and equal to one process stepping on the mean of
+    the two views' losses."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    n_final, flat = res[0][2], torch.tensor(res[0][4])
+    assert n_final != 40, "densification never changed the model: the synchronised path was not exercised"
+    # single-process emulation: both views of a pair in one iteration
+    import random
+    from scorp_amd.train import PipelineParams
+    m, opt, cams, gts = _dp_setup()
+    m.training_setup(opt)
+    rng = random.Random(0)
+    stack = []
+    for it in range(1, 15):
+        ks = []
+        for _ in range(2):
+            if not stack:
+                stack = list(range(len(cams)))
+                rng.shuffle(stack)
+            ks.append(stack.pop())
+        m.update_learning_rate(it)
+        pk = [_fake_render(cams[k], m, PipelineParams(), torch.zeros(3)) for k in ks]
+        loss = sum(_plain_loss(p["render"], gts[k], opt.lambda_dssim) for p, k in zip(pk, ks)) / 2
+        loss.backward()
+        with torch.no_grad():
+            for p in pk:
+                vis = p["visibility_filter"]
+                m.max_radii2D[vis] = torch.max(m.max_radii2D[vis], p["radii"][vis].float())
+                m.add_densification_stats(p["viewspace_points"], vis)
+            if it > opt.densify_from_iter and it % opt.densification_interval == 0:
+                torch.manual_seed(1_000_003 * it)
+                m.densify_and_prune(opt.densify_grad_threshold, 0.005, 4.0, 20 if it > opt.opacity_reset_interval else None)
+            if it % opt.opacity_reset_interval == 0:
+                m.reset_opacity()
+            m.optimizer.step()
+            m.optimizer.zero_grad(set_to_none=True)
+    ref = torch.cat([p.detach().reshape(-1) for p in (m._xyz, m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation)])
+    assert ref.numel() == flat.numel()
+    assert (ref - flat).abs().max() < 1e-5
