@@ -20,7 +20,7 @@ constexpr float kCutoff = 3.0f;
 constexpr float kFilterSize = 0.707106f;
 constexpr float kFilterInvSq = 2.0f;
 constexpr float kExtentFloor = 0.0001f;
-constexpr int kAcc2Stride = 20;  // gT[9], gxy[2], gnormal[3], gopacity, grgb[3], pad[2]
+constexpr int kAcc2Stride = 20;  // d/d(pa, pb, pc)[9], d/dD, d/dTw.z, gxy[2], gnormal[3], gopacity, grgb[3]
 
 struct alignas(16) Surfel {  // 96 bytes, gathered as six 16-byte loads
   float4 r0;  // Tu.x Tu.y Tu.z Tv.x
@@ -233,29 +233,55 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
 // of a chunk gathers one surfel of the tile's list and tests its exact footprint against the block
 // (surfel_reaches_box); survivors are compacted into a per-wave LDS ring.
 // ---------------------------------------------------------------------------------------------------------
-struct Eval2 { float s0, s1, pz, dx, dy, depth, G, alpha; float k[3], l[3]; bool use3d; };
-// Same decisions in forward and backward: every product-sum is written as an explicit fma and contraction is off, so
-// the two kernels cannot round the ray-surfel intersection differently.
-__device__ __forceinline__ bool eval_surfel(const float4 r0, const float4 r1, const float4 r2, float pxf, float pyf, Eval2 &h) {
+// The ray-surfel intersection in linear form.  With k = x Tw - Tu, l = y Tw - Tv the reference intersects with
+// p = k x l and s = (p0, p1) / p2.  p is LINEAR in the pixel: p = x (Tv x Tw) + y (Tw x Tu) + Tu x Tv, and
+// p . Tw = det[Tu; Tv; Tw] =: D for every pixel, so the hit depth s0 Tw0 + s1 Tw1 + Tw2 = D / p2.  The lane that
+// inserts a surfel into a wave's ring computes pa = Tv x Tw, pb = Tw x Tu, pc = Tu x Tv, D once; a pixel then needs
+// six FMAs for p instead of two 3-vectors and a cross product, no reciprocal for the depth (nor for 1 / depth:
+// p2 / D), and the backward accumulates gradients of (pa, pb, pc, D) — products of dp with (x, y, 1) — which
+// preprocess2d_backward_kernel chains back to T.
+struct SurfelLin { float4 e0, e1, e2, e3; };   // (pa, pb0) (pb1, pb2, pc0, pc1) (pc2, D, cx, cy) (log2 o, Tw2, 1/D, 1/Tw2)
+__device__ __forceinline__ SurfelLin surfel_lin(const float4 r0, const float4 r1, const float4 r2) {
 #pragma clang fp contract(off)
   const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
+  float pa[3], pb[3], pc[3];
 #pragma unroll
-  for (int q = 0; q < 3; q++) { h.k[q] = __builtin_fmaf(pxf, Tw[q], -Tu[q]); h.l[q] = __builtin_fmaf(pyf, Tw[q], -Tv[q]); }
-  const float p0 = __builtin_fmaf(h.k[1], h.l[2], -(h.k[2] * h.l[1]));
-  const float p1 = __builtin_fmaf(h.k[2], h.l[0], -(h.k[0] * h.l[2]));
-  h.pz = __builtin_fmaf(h.k[0], h.l[1], -(h.k[1] * h.l[0]));
-  const float rz = __builtin_amdgcn_rcpf(h.pz);
-  h.s0 = p0 * rz; h.s1 = p1 * rz;
+  for (int i = 0; i < 3; i++) {
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    pa[i] = __builtin_fmaf(Tv[j], Tw[k], -(Tv[k] * Tw[j]));
+    pb[i] = __builtin_fmaf(Tw[j], Tu[k], -(Tw[k] * Tu[j]));
+    pc[i] = __builtin_fmaf(Tu[j], Tv[k], -(Tu[k] * Tv[j]));
+  }
+  const float D = __builtin_fmaf(Tu[0], pa[0], __builtin_fmaf(Tu[1], pa[1], Tu[2] * pa[2]));
+  SurfelLin L;
+  L.e0 = make_float4(pa[0], pa[1], pa[2], pb[0]);
+  L.e1 = make_float4(pb[1], pb[2], pc[0], pc[1]);
+  L.e2 = make_float4(pc[2], D, r2.y, r2.z);
+  L.e3 = make_float4(__builtin_amdgcn_logf(r2.w), Tw[2], __builtin_amdgcn_rcpf(D), __builtin_amdgcn_rcpf(Tw[2]));
+  return L;
+}
+
+struct Eval2 { float s0, s1, pz, rz, dx, dy, depth, rdepth, Go, alpha; bool use3d; };
+// Same decisions in forward and backward: every product-sum is written as an explicit fma and contraction is off, so
+// the two kernels cannot round the intersection differently.  Go = opacity * G (alpha before the 0.99 clamp).
+__device__ __forceinline__ bool eval_surfel(const float4 e0, const float4 e1, const float4 e2, const float4 e3, float pxf,
+                                            float pyf, Eval2 &h) {
+#pragma clang fp contract(off)
+  const float p0 = __builtin_fmaf(e0.x, pxf, __builtin_fmaf(e0.w, pyf, e1.z));
+  const float p1 = __builtin_fmaf(e0.y, pxf, __builtin_fmaf(e1.x, pyf, e1.w));
+  h.pz = __builtin_fmaf(e0.z, pxf, __builtin_fmaf(e1.y, pyf, e2.x));
+  h.rz = __builtin_amdgcn_rcpf(h.pz);
+  h.s0 = p0 * h.rz; h.s1 = p1 * h.rz;
   const float rho3d = __builtin_fmaf(h.s0, h.s0, h.s1 * h.s1);
-  h.dx = r2.y - pxf; h.dy = r2.z - pyf;
+  h.dx = e2.z - pxf; h.dy = e2.w - pyf;
   const float rho2d = kFilterInvSq * __builtin_fmaf(h.dx, h.dx, h.dy * h.dy);
   h.use3d = rho3d <= rho2d;
-  const float rho = fminf(rho3d, rho2d);
-  h.depth = h.use3d ? __builtin_fmaf(h.s0, Tw[0], __builtin_fmaf(h.s1, Tw[1], Tw[2])) : Tw[2];
-  h.G = __builtin_amdgcn_exp2f(-0.5f * 1.4426950408889634f * rho);
-  h.alpha = fminf(kAlphaMax, r2.w * h.G);
-  // pz == 0 gives inf/NaN in rho (comparisons false); rho >= 0 otherwise, so the reference's `power > 0` never fires
-  return h.pz != 0.0f && h.depth >= kNearZ && h.alpha >= kAlphaMin && rho >= 0.0f;
+  const float rho = fminf(rho3d, rho2d);            // rho2d is finite, so a NaN / inf rho3d (pz == 0) falls back to it
+  h.depth = h.use3d ? e2.y * h.rz : e3.y;
+  h.rdepth = h.use3d ? h.pz * e3.z : e3.w;          // 1 / depth without a reciprocal
+  h.Go = __builtin_amdgcn_exp2f(__builtin_fmaf(-0.5f * 1.4426950408889634f, rho, e3.x));
+  h.alpha = fminf(kAlphaMax, h.Go);
+  return (h.pz != 0.0f) & (h.depth >= kNearZ) & (h.alpha >= kAlphaMin);
 }
 
 constexpr int k2FRing = 128, k2FChunk = 64, k2FGroup = 8;
@@ -265,8 +291,8 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
                             const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                             const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ allmap,
                             float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
-  __shared__ float4 q0[k2FRing], q1[k2FRing], q2[k2FRing], q3[k2FRing];
-  __shared__ float2 q4[k2FRing];
+  __shared__ float4 q0[k2FRing], q1[k2FRing], q2[k2FRing], q3[k2FRing], q4[k2FRing];   // SurfelLin + (normal, r)
+  __shared__ float2 q5[k2FRing];                                                          // (g, b)
   __shared__ __attribute__((aligned(16))) uint32_t q_pos[k2FRing];
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
@@ -296,7 +322,8 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
     const uint64_t m = __ballot(hit);
     if (hit) {
       const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (k2FRing - 1);
-      q0[qi] = r0; q1[qi] = r1; q2[qi] = r2; q3[qi] = r3; q4[qi] = make_float2(r4.x, r4.y);
+      const SurfelLin L = surfel_lin(r0, r1, r2);
+      q0[qi] = L.e0; q1[qi] = L.e1; q2[qi] = L.e2; q3[qi] = L.e3; q4[qi] = r3; q5[qi] = make_float2(r4.x, r4.y);
       q_pos[qi] = base + lane + 1u;
     }
     count += __builtin_popcountll(m);
@@ -309,8 +336,8 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
       constexpr bool kFull = decltype(full)::value;
       int hv = head;
       asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs
-      const float4 *g0 = q0 + hv, *g1 = q1 + hv, *g2 = q2 + hv, *g3 = q3 + hv;
-      const float2 *g4 = q4 + hv;
+      const float4 *g0 = q0 + hv, *g1 = q1 + hv, *g2 = q2 + hv, *g3 = q3 + hv, *g4 = q4 + hv;
+      const float2 *g5 = q5 + hv;
       const uint32_t *gp = q_pos + hv;
       static_assert(k2FGroup == 8, "positions are fetched as two 16-byte LDS reads");
       const uint4 pl = *reinterpret_cast<const uint4 *>(gp), ph = *reinterpret_cast<const uint4 *>(gp + 4);
@@ -319,16 +346,16 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
 #pragma unroll
       for (int i = 0; i < k2FGroup; i++) {
         Eval2 h;
-        const bool ok = eval_surfel(g0[i], g1[i], g2[i], pxf, pyf, h) & (kFull || i < nslots);
+        const bool ok = eval_surfel(g0[i], g1[i], g2[i], g3[i], pxf, pyf, h) & (kFull || i < nslots);
         al[i] = ok ? h.alpha : 0.0f;
         dz[i] = ok ? h.depth : 1.0f;
-        mm[i] = fn * (1.0f - kNearZ * __builtin_amdgcn_rcpf(dz[i]));
+        mm[i] = fn * (1.0f - kNearZ * (ok ? h.rdepth : 1.0f));
       }
 #pragma unroll
       for (int i = 0; i < k2FGroup; i++) {
         if (kFull || i < nslots) {  // wave-uniform
-          const float4 nr = g3[i];
-          const float2 gb = g4[i];
+          const float4 nr = g4[i];
+          const float2 gb = g5[i];
           const float alpha = al[i];
           const float test_T = T * (1.0f - alpha);
           done = done || (alpha > 0.0f && test_T < kTMin);
@@ -364,10 +391,11 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   }
 }
 
-// Eighteen wave-wide sums as one butterfly: each level halves the number of live values by pairing them (the lane
-// keeps one of the pair and receives the partner's copy of it), so the whole reduction costs ~43 instructions instead
-// of 18 x 6.  Levels 32 and 16 are v_permlane{32,16}_swap + add; in-row levels 8 and 4 are two DPP adds (the partner
-// lanes are whole banks, so bank_mask picks which value a lane keeps), levels 2 and 1 a select pair + a DPP add.  Value q's total ends in lane acc_writer_lane(q); reduce18_slot() gives each lane the q it holds (or -1).
+// Twenty wave-wide sums as one butterfly: each level halves the number of live values by pairing them (the lane
+// keeps one of the pair and receives the partner's copy of it), so the whole reduction costs ~42 instructions instead
+// of 20 x 6.  Levels 32 and 16 are v_permlane{32,16}_swap + add; in-row levels 8 and 4 are two DPP adds (the partner
+// lanes are whole banks, so bank_mask picks which value a lane keeps), levels 2 and 1 a select pair + a DPP add.
+// reduce20_slot() gives each lane the index of the value whose total it ends up holding (or -1).
 __device__ __forceinline__ float fold32(float a, float b) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -391,20 +419,18 @@ __device__ __forceinline__ float fold4_banked(float a, float b) {   // lanes wit
   asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(t) : "v"(b));
   return t;
 }
-__device__ __forceinline__ int reduce18_slot(int lane) {
+__device__ __forceinline__ int reduce20_slot(int lane) {
   const int h = lane >> 5, r = (lane >> 4) & 1, b8 = (lane >> 3) & 1, b4 = (lane >> 2) & 1, b2 = (lane >> 1) & 1, b1 = lane & 1;
   if (b1) return -1;
   if (!b2) return 8 * b4 + 4 * b8 + 2 * r + h;
-  return (r == 0 && b8 == 0 && b4 == 0) ? 16 + h : -1;
+  return (b8 == 0 && b4 == 0) ? 16 + 2 * r + h : -1;
 }
-__device__ __forceinline__ float reduce18(const float *g, int lane) {
-  float w[9], x[5], y[3];
+__device__ __forceinline__ float reduce20(const float *g, int lane) {
+  float w[10], x[5], y[3];
 #pragma unroll
-  for (int j = 0; j < 9; j++) w[j] = fold32(g[2 * j], g[2 * j + 1]);
+  for (int j = 0; j < 10; j++) w[j] = fold32(g[2 * j], g[2 * j + 1]);
 #pragma unroll
-  for (int j = 0; j < 4; j++) x[j] = fold16(w[2 * j], w[2 * j + 1]);
-  x[4] = fold16(w[8], 0.0f);
-  const bool u2 = (lane & 2) != 0;
+  for (int j = 0; j < 5; j++) x[j] = fold16(w[2 * j], w[2 * j + 1]);
   y[0] = fold8_banked(x[0], x[1]);
   y[1] = fold8_banked(x[2], x[3]);
   y[2] = dpp_add<0x128>(x[4]);
@@ -412,7 +438,7 @@ __device__ __forceinline__ float reduce18(const float *g, int lane) {
   // row_half_mirror (l <-> 7 - l), then quad_perm [2,3,0,1] and [1,0,3,2]
   const float z0 = fold4_banked(y[0], y[1]);
   const float z1 = dpp_add<0x141>(y[2]);
-  const float u = fold_row<0x4E>(z0, z1, u2);
+  const float u = fold_row<0x4E>(z0, z1, (lane & 2) != 0);
   return dpp_add<0xB1>(u);
 }
 
@@ -425,9 +451,8 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
                              const float *__restrict__ bg, const float *__restrict__ final_T,
                              const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
                              const float *__restrict__ dL_dallmap, float *__restrict__ acc) {
-  __shared__ float4 q0[k2BChunk], q1[k2BChunk], q2[k2BChunk], q3[k2BChunk];
-  __shared__ float2 q4[k2BChunk];
-  __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];
+  __shared__ float4 q0[k2BChunk], q1[k2BChunk], q2[k2BChunk], q3[k2BChunk], q4[k2BChunk], q5[k2BChunk];
+  __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];   // q0..q3: SurfelLin, q4: (normal, r), q5: (g, b, 1 / opacity, -)
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
@@ -462,7 +487,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
   todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // wave-uniform: keeps the chunk loop's counters in SGPRs
-  const int slot = reduce18_slot(lane);
+  const int slot = reduce20_slot(lane);
   float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f, last_dL_dT = 0.0f;
   for (uint32_t done_n = 0; done_n < todo; done_n += k2BChunk) {
     const uint32_t top = todo - 1 - done_n;
@@ -479,7 +504,9 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
     __builtin_amdgcn_wave_barrier();   // every lane is past the previous chunk's reads of the ring
     if (hit) {
       const int qi = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      q0[qi] = r0; q1[qi] = r1; q2[qi] = r2; q3[qi] = r3; q4[qi] = make_float2(r4.x, r4.y);
+      const SurfelLin L = surfel_lin(r0, r1, r2);
+      q0[qi] = L.e0; q1[qi] = L.e1; q2[qi] = L.e2; q3[qi] = L.e3; q4[qi] = r3;
+      q5[qi] = make_float4(r4.x, r4.y, __builtin_amdgcn_rcpf(r2.w), 0.0f);
       q_id[qi] = id; q_pos[qi] = top - (uint32_t)lane + 1u;
     }
     const int cnt = __builtin_popcountll(m);
@@ -489,17 +516,18 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       int s = s_;
       asm volatile("" : "+v"(s));   // one VGPR slot index: the ds_reads below share it instead of re-moving SGPR bases
       const uint32_t pos1 = q_pos[s];
-      const float4 a0 = q0[s], a1 = q1[s], a2 = q2[s];
+      const float4 a0 = q0[s], a1 = q1[s], a2 = q2[s], a3 = q3[s];
       Eval2 h;
-      const bool valid = eval_surfel(a0, a1, a2, pxf, pyf, h) && pos1 <= last;
+      const bool valid = eval_surfel(a0, a1, a2, a3, pxf, pyf, h) & (pos1 <= last);
       if (__ballot(valid) == 0) continue;
-      float g[18];
+      // acc row: d/d pa (3), d/d pb (3), d/d pc (3), d/d D, d/d Tw.z (low-pass depth), d/d (cx, cy), normal (3),
+      // opacity, rgb (3)
+      float g[20];
 #pragma unroll
-      for (int q = 0; q < 18; q++) g[q] = 0.0f;
+      for (int q = 0; q < 20; q++) g[q] = 0.0f;
       if (valid) {
-        const float4 nr = q3[s];
-        const float2 gb = q4[s];
-        const float Tw0 = a1.z, Tw1 = a1.w;
+        const float4 nr = q4[s];
+        const float4 gb = q5[s];
         const float rinv = __builtin_amdgcn_rcpf(1.0f - h.alpha);
         T *= rinv;
         const float w = h.alpha * T;
@@ -512,7 +540,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         s_last = sc;
         float dL_dz = 0.0f;
         if (kHasMap) {
-          const float rd = __builtin_amdgcn_rcpf(h.depth);
+          const float rd = h.rdepth;
           const float m_d = fn * (1.0f - kNearZ * rd);
           const float dmd_dd = (kFarZ * kNearZ / (kFarZ - kNearZ)) * rd * rd;
           dL_dz = (pos1 == med_c) ? dmed : 0.0f;
@@ -525,28 +553,25 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         dL_dal *= T;
         last_alpha = h.alpha;
         dL_dal -= T_final * rinv * bg_dot;
-        const float dL_dG = a2.w * dL_dal;
+        const float t = -h.Go * dL_dal;          // dL/dG * (-G), G = Go / opacity
         if (h.use3d) {
-          const float ds0 = dL_dG * -h.G * h.s0 + dL_dz * Tw0, ds1 = dL_dG * -h.G * h.s1 + dL_dz * Tw1;
-          const float rz = __builtin_amdgcn_rcpf(h.pz);
-          const float dp0 = ds0 * rz, dp1 = ds1 * rz, dp2 = -(dp0 * h.s0 + dp1 * h.s1);
-          const float dk0 = h.l[1] * dp2 - h.l[2] * dp1, dk1 = h.l[2] * dp0 - h.l[0] * dp2, dk2 = h.l[0] * dp1 - h.l[1] * dp0;
-          const float dl0 = dp1 * h.k[2] - dp2 * h.k[1], dl1 = dp2 * h.k[0] - dp0 * h.k[2], dl2 = dp0 * h.k[1] - dp1 * h.k[0];
-          g[0] = -dk0; g[1] = -dk1; g[2] = -dk2;
-          g[3] = -dl0; g[4] = -dl1; g[5] = -dl2;
-          g[6] = pxf * dk0 + pyf * dl0 + dL_dz * h.s0;
-          g[7] = pxf * dk1 + pyf * dl1 + dL_dz * h.s1;
-          g[8] = pxf * dk2 + pyf * dl2 + dL_dz;
+          const float dp0 = t * h.s0 * h.rz, dp1 = t * h.s1 * h.rz;
+          const float zr = dL_dz * h.rz;          // depth = D / pz
+          const float dp2 = -(dp0 * h.s0 + dp1 * h.s1) - zr * h.depth;
+          g[0] = dp0 * pxf; g[1] = dp1 * pxf; g[2] = dp2 * pxf;
+          g[3] = dp0 * pyf; g[4] = dp1 * pyf; g[5] = dp2 * pyf;
+          g[6] = dp0; g[7] = dp1; g[8] = dp2;
+          g[9] = zr;
         } else {
-          g[9] = dL_dG * (-h.G * kFilterInvSq * h.dx);
-          g[10] = dL_dG * (-h.G * kFilterInvSq * h.dy);
-          g[8] = dL_dz;
+          g[10] = dL_dz;
+          g[11] = t * (kFilterInvSq * h.dx);
+          g[12] = t * (kFilterInvSq * h.dy);
         }
-        if (kHasMap) { g[11] = w * dn0; g[12] = w * dn1; g[13] = w * dn2; }
-        g[14] = h.G * dL_dal;
-        g[15] = w * dpix0; g[16] = w * dpix1; g[17] = w * dpix2;
+        if (kHasMap) { g[13] = w * dn0; g[14] = w * dn1; g[15] = w * dn2; }
+        g[16] = h.Go * gb.z * dL_dal;
+        g[17] = w * dpix0; g[18] = w * dpix1; g[19] = w * dpix2;
       }
-      const float v = reduce18(g, lane);
+      const float v = reduce20(g, lane);
       if (slot >= 0) atomicAdd(acc + (size_t)q_id[s] * kAcc2Stride + slot, v);
     }
   }
@@ -591,14 +616,25 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
   if (visible) {
     const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAcc2Stride);
     const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
-    gT[0] = a0.x; gT[1] = a0.y; gT[2] = a0.z; gT[3] = a0.w; gT[4] = a1.x; gT[5] = a1.y; gT[6] = a1.z; gT[7] = a1.w; gT[8] = a2.x;
-    const float gx = a2.y, gy = a2.z;
-    const float gn[3] = {a2.w, a3.x, a3.y};
-    g_op = a3.z;
-    grgb[0] = a3.w; grgb[1] = a4.x; grgb[2] = a4.y;
+    const float ga[3] = {a0.x, a0.y, a0.z}, gb[3] = {a0.w, a1.x, a1.y}, gc[3] = {a1.z, a1.w, a2.x};
+    const float gD = a2.y, gTw2 = a2.z, gx = a2.w, gy = a3.x;
+    const float gn[3] = {a3.y, a3.z, a3.w};
+    g_op = a4.x;
+    grgb[0] = a4.y; grgb[1] = a4.z; grgb[2] = a4.w;
     const float4 *rp = reinterpret_cast<const float4 *>(rec + i);
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
     const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
+    // the blend kernels differentiate the linear form p = x pa + y pb + pc, depth = D / p.z (see surfel_lin):
+    // pa = Tv x Tw, pb = Tw x Tu, pc = Tu x Tv, D = Tu . pa; for c = u x v: dL/du = v x g, dL/dv = g x u
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int j = (q + 1) % 3, k = (q + 2) % 3;
+      const float pa_q = Tv[j] * Tw[k] - Tv[k] * Tw[j], pb_q = Tw[j] * Tu[k] - Tw[k] * Tu[j], pc_q = Tu[j] * Tv[k] - Tu[k] * Tv[j];
+      gT[q] = (gb[j] * Tw[k] - gb[k] * Tw[j]) + (Tv[j] * gc[k] - Tv[k] * gc[j]) + gD * pa_q;        // d/dTu
+      gT[3 + q] = (Tw[j] * ga[k] - Tw[k] * ga[j]) + (gc[j] * Tu[k] - gc[k] * Tu[j]) + gD * pb_q;    // d/dTv
+      gT[6 + q] = (ga[j] * Tv[k] - ga[k] * Tv[j]) + (Tu[j] * gb[k] - Tu[k] * gb[j]) + gD * pc_q;    // d/dTw
+    }
+    gT[8] += gTw2;
     const float depth = __uint_as_float(bin[i].depth_bits);
     gm2[0] = gT[2] * depth * 0.5f * a.W;   // densification statistic (gs2dgs/scene/gaussian_model.py:495 consumes it)
     gm2[1] = gT[5] * depth * 0.5f * a.H;
