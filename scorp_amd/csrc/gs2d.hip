@@ -520,17 +520,17 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       Eval2 h;
       const bool valid = eval_surfel(a0, a1, a2, a3, pxf, pyf, h) & (pos1 <= last);
       if (__ballot(valid) == 0) continue;
-      // acc row: d/d pa (3), d/d pb (3), d/d pc (3), d/d D, d/d Tw.z (low-pass depth), d/d (cx, cy), normal (3),
-      // opacity, rgb (3)
-      float g[20];
-#pragma unroll
-      for (int q = 0; q < 20; q++) g[q] = 0.0f;
+      // The per-pixel recurrence runs under `valid`; it leaves three scalars (blend weight w, t = dL/dG * (-G), dL/dz)
+      // that are zero on the other lanes, and the twenty sums are formed from them outside the branch with the
+      // geometry zeroed where it is not used (pz ~ 0 makes s, rz, depth non-finite there), so no lane ever needs
+      // its twenty accumulators cleared first.
+      float w = 0.0f, t = 0.0f, dL_dz = 0.0f;
+      const float4 nr = q4[s];
+      const float4 gb = q5[s];
       if (valid) {
-        const float4 nr = q4[s];
-        const float4 gb = q5[s];
         const float rinv = __builtin_amdgcn_rcpf(1.0f - h.alpha);
         T *= rinv;
-        const float w = h.alpha * T;
+        w = h.alpha * T;
         // the "blended behind" recurrences (colour, depth, alpha, normal) only ever appear dotted with this pixel's
         // upstream gradient, so one scalar recurrence carries them all (see gs3d_backward.hip)
         R = last_alpha * (s_last - R) + R;
@@ -538,7 +538,6 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         if (kHasMap) sc += h.depth * ddep + dacc + nr.x * dn0 + nr.y * dn1 + nr.z * dn2;
         float dL_dal = sc - R;
         s_last = sc;
-        float dL_dz = 0.0f;
         if (kHasMap) {
           const float rd = h.rdepth;
           const float m_d = fn * (1.0f - kNearZ * rd);
@@ -553,22 +552,28 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         dL_dal *= T;
         last_alpha = h.alpha;
         dL_dal -= T_final * rinv * bg_dot;
-        const float t = -h.Go * dL_dal;          // dL/dG * (-G), G = Go / opacity
-        if (h.use3d) {
-          const float dp0 = t * h.s0 * h.rz, dp1 = t * h.s1 * h.rz;
-          const float zr = dL_dz * h.rz;          // depth = D / pz
-          const float dp2 = -(dp0 * h.s0 + dp1 * h.s1) - zr * h.depth;
-          g[0] = dp0 * pxf; g[1] = dp1 * pxf; g[2] = dp2 * pxf;
-          g[3] = dp0 * pyf; g[4] = dp1 * pyf; g[5] = dp2 * pyf;
-          g[6] = dp0; g[7] = dp1; g[8] = dp2;
-          g[9] = zr;
-        } else {
-          g[10] = dL_dz;
-          g[11] = t * (kFilterInvSq * h.dx);
-          g[12] = t * (kFilterInvSq * h.dy);
-        }
-        if (kHasMap) { g[13] = w * dn0; g[14] = w * dn1; g[15] = w * dn2; }
-        g[16] = h.Go * gb.z * dL_dal;
+        t = -h.Go * dL_dal;          // dL/dG * (-G), G = Go / opacity
+      }
+      // acc row: d/d pa (3), d/d pb (3), d/d pc (3), d/d D, d/d Tw.z (low-pass depth), d/d (cx, cy), normal (3),
+      // opacity, rgb (3)
+      float g[20];
+      {
+        const bool u3 = valid & h.use3d;
+        const float s0 = u3 ? h.s0 : 0.0f, s1 = u3 ? h.s1 : 0.0f, rz = u3 ? h.rz : 0.0f, dep = u3 ? h.depth : 0.0f;
+        const float t2 = h.use3d ? 0.0f : t, z2 = h.use3d ? 0.0f : dL_dz;   // low-pass branch (t, dL_dz are 0 if !valid)
+        const float tr = t * rz;
+        const float dp0 = tr * s0, dp1 = tr * s1;
+        const float zr = dL_dz * rz;                                        // depth = D / pz
+        const float dp2 = -(dp0 * s0 + dp1 * s1) - zr * dep;
+        g[0] = dp0 * pxf; g[1] = dp1 * pxf; g[2] = dp2 * pxf;
+        g[3] = dp0 * pyf; g[4] = dp1 * pyf; g[5] = dp2 * pyf;
+        g[6] = dp0; g[7] = dp1; g[8] = dp2;
+        g[9] = zr;
+        g[10] = z2;
+        g[11] = t2 * (kFilterInvSq * h.dx);
+        g[12] = t2 * (kFilterInvSq * h.dy);
+        g[13] = kHasMap ? w * dn0 : 0.0f; g[14] = kHasMap ? w * dn1 : 0.0f; g[15] = kHasMap ? w * dn2 : 0.0f;
+        g[16] = -t * gb.z;                                                  // G * dL/dalpha
         g[17] = w * dpix0; g[18] = w * dpix1; g[19] = w * dpix2;
       }
       const float v = reduce20(g, lane);
