@@ -275,87 +275,7 @@ sort_tiles_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K5: front-to-back blend. One workgroup (4 wave64) per 16x16 tile; each wave owns an 8x8 pixel block.
-// Splat records are gathered 256 at a time into LDS; each wave first ballots which of them can reach its 8x8
-// block at all (min of the conic over the block > kcut  =>  alpha < 1/255 on every pixel of the block), then walks only
-// those, reading each record from LDS at a wave-uniform address (broadcast, conflict-free).
-// ---------------------------------------------------------------------------------------------------------
-template <bool kCull>
-__global__ void __launch_bounds__(256)
-blend_forward_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
-                     const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x,
-                     const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
-                     float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
-  __shared__ float4 s_a[256], s_b[256], s_c[256];
-  const int tile = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int bx = (tile % tiles_x) * kTile + (wave & 1) * 8, by = (tile / tiles_x) * kTile + (wave >> 1) * 8;
-  const int px = bx + (lane & 7), py = by + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f, Wt = 0.0f;
-  uint32_t last = 0;
-  bool done = !inside;
-  for (uint32_t base = beg; base < end; base += 256) {
-    if (__syncthreads_and(done)) break;  // also the barrier that protects the LDS batch being overwritten
-    const uint32_t k = base + threadIdx.x;
-    if (k < end) {
-      const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[k]);
-      s_a[threadIdx.x] = src[0];
-      s_b[threadIdx.x] = src[1];
-      s_c[threadIdx.x] = src[2];
-    }
-    __syncthreads();
-    const int cnt = (int)min(256u, end - base);
-    for (int q = 0; q < cnt; q += 64) {
-      const int j = q + lane;
-      bool hit = false;
-      if (j < cnt) {
-        if (kCull) {
-          const float4 a = s_a[j];
-          hit = conic_min_over_box(a.x, a.y, a.z, a.w, s_b[j].x, bx0, bx1, by0, by1) <= s_c[j].z;
-        } else {
-          hit = true;
-        }
-      }
-      uint64_t mask = __ballot(hit);
-      while (mask) {
-        const int jj = q + __builtin_ctzll(mask);
-        mask &= mask - 1;
-        if (done) continue;
-        const float4 a = s_a[jj], b = s_b[jj], c = s_c[jj];
-        const float dx = a.x - pxf, dy = a.y - pyf;
-        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-        if (power > 0.0f) continue;
-        const float alpha = fminf(kAlphaMax, b.y * __expf(power));
-        if (alpha < kAlphaMin) continue;
-        const float test_T = T * (1.0f - alpha);
-        if (test_T < kTMin) { done = true; continue; }
-        const float w = alpha * T;
-        C0 += b.z * w; C1 += b.w * w; C2 += c.x * w;
-        Dp += c.y * w;
-        Wt += w;
-        T = test_T;
-        last = (base - beg) + (uint32_t)jj + 1u;
-      }
-    }
-  }
-  if (inside) {
-    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
-    final_T[pix] = T;
-    n_contrib[pix] = last;
-    out_color[pix] = C0 + T * bg[0];
-    out_color[HW + pix] = C1 + T * bg[1];
-    out_color[2 * HW + pix] = C2 + T * bg[2];
-    out_depth[pix] = Dp;
-    out_alpha[pix] = Wt;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// K5w: the same blend with ONE WAVE PER 8x8 BLOCK as the unit (64-thread workgroups, no workgroup barriers), the
+// K5: front-to-back blend with ONE WAVE PER 8x8 BLOCK as the unit (64-thread workgroups, no workgroup barriers), the
 // forward twin of blend_backward_wave_kernel: the wave walks the tile's list front to back 32 entries at a time, each
 // lane gathers one record and runs the exact conic-vs-block test, survivors are compacted into a per-wave LDS ring,
 // and groups of 8 go through a straight-line alpha phase followed by the branch-free sequential blend (a splat that
@@ -369,7 +289,8 @@ __global__ void __launch_bounds__(64)
 blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
-                          float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
+                          float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                          uint8_t *__restrict__ hit_flags) {
   // ring entries: (x, y, A', B'), (C', log2 opacity, r, g), (b, depth): conic pre-scaled so that
   // alpha = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity), one v_exp and no multiply
   __shared__ float4 q_a[kFRing], q_b[kFRing];
@@ -399,6 +320,9 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[beg + base + lane]);
       a = src[0]; b = src[1]; c = src[2];
       hit = conic_min_over_box(a.x, a.y, a.z, a.w, b.x, bx0, bx1, by0, by1) <= c.z;
+      // remembered for the backward (one byte per (block, entry), in the pair buffer's key region, which is dead after
+      // the sort): it then gathers and replays only the entries that passed this test
+      hit_flags[(size_t)quad * capacity + beg + base + lane] = hit ? 1 : 0;
     }
     const uint64_t m = __ballot(hit);
     if (hit) {
@@ -631,18 +555,13 @@ extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *p
   uint32_t *point_list = (uint32_t *)(pb + P.list);
   StateHeader *header = (StateHeader *)(base + L.header);
   if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
-  static const bool fwd_per_tile = getenv("SCORP_FWD_PER_TILE") != nullptr;  // A/B switch: workgroup-per-tile form
-  if (!fwd_per_tile) {
+  {
     ProfScope prof(kKBlendForward, stream);
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
     blend_forward_wave_kernel<<<blocks, 64, 0, stream>>>(
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
-        out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib));
-  } else {
-    ProfScope prof(kKBlendForward, stream);
-    blend_forward_kernel<true><<<L.tiles, 256, 0, stream>>>(
-        tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, in->bg,
-        out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib));
+        out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib),
+        (uint8_t *)keys);
   }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;
