@@ -312,13 +312,26 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   bool done = !inside;
   int head = 0, count = 0;   // head stays a multiple of kFGroup (only a wave's final group is partial), so the
                              // slots of a group are head + i without wrap-around: one LDS base, immediate offsets
+  // The chunk's gathers (list entry -> record) are dependent loads of ~1 us each; they are software-pipelined: while
+  // chunk c is blended the records of chunk c+1 and the list entries of chunk c+2 are already in flight.
+  auto fetch_id = [&](uint32_t bs) { return (bs + lane < n) ? point_list[beg + bs + lane] : 0xFFFFFFFFu; };
+  auto fetch_rec = [&](uint32_t id_, float4 &a_, float4 &b_, float4 &c_) {
+    if (id_ != 0xFFFFFFFFu) {
+      const float4 *src = reinterpret_cast<const float4 *>(rec + id_);
+      a_ = src[0]; b_ = src[1]; c_ = src[2];
+    }
+  };
+  float4 a, b, c;
+  uint32_t id0 = fetch_id(0);
+  fetch_rec(id0, a, b, c);
+  uint32_t id1 = fetch_id(kFChunk);
   for (uint32_t base = 0; base < n; base += kFChunk) {
     if (__ballot(!done) == 0) break;
+    float4 a1, b1, c1;
+    fetch_rec(id1, a1, b1, c1);
+    const uint32_t id2 = fetch_id(base + 2 * kFChunk);
     bool hit = false;
-    float4 a, b, c;
-    if (lane < kFChunk && base + lane < n) {
-      const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[beg + base + lane]);
-      a = src[0]; b = src[1]; c = src[2];
+    if (id0 != 0xFFFFFFFFu) {
       hit = conic_min_over_box(a.x, a.y, a.z, a.w, b.x, bx0, bx1, by0, by1) <= c.z;
       // remembered for the backward (one byte per (block, entry), in the pair buffer's key region, which is dead after
       // the sort): it then gathers and replays only the entries that passed this test
@@ -378,6 +391,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     };
     while (count >= kFGroup) blend_group(std::true_type{}, kFGroup);
     if (last_chunk && count > 0) blend_group(std::false_type{}, count);
+    id0 = id1; a = a1; b = b1; c = c1; id1 = id2;
   }
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
