@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(64)
 blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                             const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                             const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ allmap,
-                            float *__restrict__ final_T, uint32_t *__restrict__ n_contrib) {
+                            float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, uint8_t *__restrict__ hit_flags) {
   __shared__ float4 q0[k2FRing], q1[k2FRing], q2[k2FRing], q3[k2FRing], q4[k2FRing];   // SurfelLin + (normal, r)
   __shared__ float2 q5[k2FRing];                                                          // (g, b)
   __shared__ __attribute__((aligned(16))) uint32_t q_pos[k2FRing];
@@ -310,14 +310,29 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   uint32_t last = 0, med_c = 0;
   bool done = !inside;
   int head = 0, count = 0;
+  // The chunk's gathers (list entry -> 96-byte record) are dependent loads; software-pipelined: while chunk c is blended
+  // the records of chunk c+1 and the list entries of chunk c+2 are in flight.  The footprint verdict of every
+  // (block, entry) is left for the backward in the pair buffer's key region (dead after the sort).
+  auto fetch_id = [&](uint32_t bs) { return (bs + lane < n) ? point_list[beg + bs + lane] : 0xFFFFFFFFu; };
+  auto fetch_rec = [&](uint32_t id_, float4 &a0_, float4 &a1_, float4 &a2_, float4 &a3_, float4 &a4_, float4 &a5_) {
+    if (id_ != 0xFFFFFFFFu) {
+      const float4 *src = reinterpret_cast<const float4 *>(rec + id_);
+      a0_ = src[0]; a1_ = src[1]; a2_ = src[2]; a3_ = src[3]; a4_ = src[4]; a5_ = src[5];
+    }
+  };
+  float4 r0, r1, r2, r3, r4, r5;
+  uint32_t id0 = fetch_id(0);
+  fetch_rec(id0, r0, r1, r2, r3, r4, r5);
+  uint32_t id1 = fetch_id(k2FChunk);
   for (uint32_t base = 0; base < n; base += k2FChunk) {
     if (__ballot(!done) == 0) break;
+    float4 nx0, nx1, nx2, nx3, nx4, nx5;   // next chunk's records
+    fetch_rec(id1, nx0, nx1, nx2, nx3, nx4, nx5);
+    const uint32_t id2 = fetch_id(base + 2 * k2FChunk);
     bool hit = false;
-    float4 r0, r1, r2, r3, r4;
-    if (base + lane < n) {
-      const float4 *src = reinterpret_cast<const float4 *>(rec + point_list[beg + base + lane]);
-      r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3]; r4 = src[4];
-      hit = surfel_reaches_box(r2.y, r2.z, r4, src[5], bx0, bx1, by0, by1);
+    if (id0 != 0xFFFFFFFFu) {
+      hit = surfel_reaches_box(r2.y, r2.z, r4, r5, bx0, bx1, by0, by1);
+      hit_flags[(size_t)quad * capacity + beg + base + lane] = hit ? 1 : 0;
     }
     const uint64_t m = __ballot(hit);
     if (hit) {
@@ -379,6 +394,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
     };
     while (count >= k2FGroup) blend_group(std::true_type{}, k2FGroup);
     if (last_chunk && count > 0) blend_group(std::false_type{}, count);
+    id0 = id1; r0 = nx0; r1 = nx1; r2 = nx2; r3 = nx3; r4 = nx4; r5 = nx5; id1 = id2;
   }
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
@@ -450,7 +466,8 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
                              const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                              const float *__restrict__ bg, const float *__restrict__ final_T,
                              const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
-                             const float *__restrict__ dL_dallmap, float *__restrict__ acc) {
+                             const float *__restrict__ dL_dallmap, float *__restrict__ acc,
+                             const uint8_t *__restrict__ hit_flags) {
   __shared__ float4 q0[k2BChunk], q1[k2BChunk], q2[k2BChunk], q3[k2BChunk], q4[k2BChunk], q5[k2BChunk];
   __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];   // q0..q3: SurfelLin, q4: (normal, r), q5: (g, b, 1 / opacity, -)
   const int lane = threadIdx.x;
@@ -465,12 +482,14 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   if (end == beg) return;
   const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
-  const float T_final = inside ? final_T[pix] : 0.0f;
-  const uint32_t last = inside ? n_contrib[pix] : 0u;
-  float final_D = 0, final_D2 = 0, dpix0 = 0, dpix1 = 0, dpix2 = 0, ddep = 0, dacc = 0, dn0 = 0, dn1 = 0, dn2 = 0,
+  // all of the pixel's loads are issued together; pixels nothing was blended into drop their upstream gradient
+  // afterwards by a select (it may be NaN)
+  float T_final = 0, final_D = 0, final_D2 = 0, dpix0 = 0, dpix1 = 0, dpix2 = 0, ddep = 0, dacc = 0, dn0 = 0, dn1 = 0, dn2 = 0,
         dmed = 0, dreg = 0;
-  uint32_t med_c = 0;
-  if (last > 0) {  // pixels nothing was blended into never read their upstream gradient (it may be NaN)
+  uint32_t last = 0, med_c = 0;
+  if (inside) {
+    T_final = final_T[pix];
+    last = n_contrib[pix];
     dpix0 = dL_dcolor[pix]; dpix1 = dL_dcolor[HW + pix]; dpix2 = dL_dcolor[2 * HW + pix];
     if (kHasMap) {
       final_D = final_T[HW + pix]; final_D2 = final_T[2 * HW + pix];
@@ -480,6 +499,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       dmed = dL_dallmap[5 * HW + pix]; dreg = dL_dallmap[6 * HW + pix];
     }
   }
+  if (last == 0) { final_D = final_D2 = dpix0 = dpix1 = dpix2 = ddep = dacc = dn0 = dn1 = dn2 = dmed = dreg = 0.0f; med_c = 0; }
   const float final_A = 1.0f - T_final;
   const float bg_dot = bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2;
   const float fn = kFarZ / (kFarZ - kNearZ);
@@ -489,17 +509,34 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // wave-uniform: keeps the chunk loop's counters in SGPRs
   const int slot = reduce20_slot(lane);
   float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f, last_dL_dT = 0.0f;
+  // gathers software-pipelined two chunks deep; only entries the forward's footprint test let through are fetched
+  auto fetch_idx = [&](uint32_t dn, bool &hit_, uint32_t &id_) {
+    hit_ = false; id_ = 0;
+    if (dn + lane < todo) {
+      const uint32_t pos0 = todo - 1 - dn - lane;
+      hit_ = hit_flags[(size_t)quad * capacity + beg + pos0] != 0;
+      id_ = point_list[beg + pos0];
+    }
+  };
+  auto fetch_rec = [&](bool hit_, uint32_t id_, float4 &a0_, float4 &a1_, float4 &a2_, float4 &a3_, float4 &a4_) {
+    if (hit_) {
+      const float4 *src = reinterpret_cast<const float4 *>(rec + id_);
+      a0_ = src[0]; a1_ = src[1]; a2_ = src[2]; a3_ = src[3]; a4_ = src[4];
+    }
+  };
+  bool hit, hit1;
+  uint32_t id, id1;
+  float4 r0, r1, r2, r3, r4;
+  fetch_idx(0, hit, id);
+  fetch_rec(hit, id, r0, r1, r2, r3, r4);
+  fetch_idx(k2BChunk, hit1, id1);
   for (uint32_t done_n = 0; done_n < todo; done_n += k2BChunk) {
     const uint32_t top = todo - 1 - done_n;
-    bool hit = false;
-    float4 r0, r1, r2, r3, r4;
-    uint32_t id = 0;
-    if (done_n + lane < todo) {
-      id = point_list[beg + top - lane];
-      const float4 *src = reinterpret_cast<const float4 *>(rec + id);
-      r0 = src[0]; r1 = src[1]; r2 = src[2]; r3 = src[3]; r4 = src[4];
-      hit = surfel_reaches_box(r2.y, r2.z, r4, src[5], bx0, bx1, by0, by1);
-    }
+    float4 nx0, nx1, nx2, nx3, nx4;   // next chunk's records
+    fetch_rec(hit1, id1, nx0, nx1, nx2, nx3, nx4);
+    bool hit2;
+    uint32_t id2;
+    fetch_idx(done_n + 2 * k2BChunk, hit2, id2);
     const uint64_t m = __ballot(hit);
     __builtin_amdgcn_wave_barrier();   // every lane is past the previous chunk's reads of the ring
     if (hit) {
@@ -579,6 +616,8 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       const float v = reduce20(g, lane);
       if (slot >= 0) atomicAdd(acc + (size_t)q_id[s] * kAcc2Stride + slot, v);
     }
+    hit = hit1; id = id1; r0 = nx0; r1 = nx1; r2 = nx2; r3 = nx3; r4 = nx4;
+    hit1 = hit2; id1 = id2;
   }
 }
 
@@ -821,7 +860,7 @@ extern "C" int scorp_gs2d_render(const ScorpGs3dInputs *in, void *state, void *p
     blend2d_forward_wave_kernel<<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(
         (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
-        (uint32_t *)(base + L.n_contrib));
+        (uint32_t *)(base + L.n_contrib), (uint8_t *)(pb + P.keys));
   }
   SCORP_KERNEL_CHECK("blend_forward_2d", in->debug, stream);
   return SCORP_OK;
@@ -846,7 +885,7 @@ extern "C" int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state,
   blend2d_backward_wave_kernel<HASMAP><<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(                                \
       (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),    \
       (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),                     \
-      (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc)
+      (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc, (const uint8_t *)(pb + P.keys))
     if (dL_dallmap) SCORP_BW2(true);
     else SCORP_BW2(false);
 #undef SCORP_BW2
