@@ -56,6 +56,15 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0, radius = 0;
   if (active) {
     px_ = a.means3D[3 * (size_t)i]; py_ = a.means3D[3 * (size_t)i + 1]; pz_ = a.means3D[3 * (size_t)i + 2];
+    // all parameter loads leave together (one memory latency instead of means -> cull -> the rest); ~4 % of the
+    // Gaussians turn out invisible and waste theirs
+    float4 q_raw = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    float sc_raw[3] = {0.0f, 0.0f, 0.0f};
+    if (!a.cov3D_precomp) {
+      q_raw = reinterpret_cast<const float4 *>(a.rotations)[i];
+      sc_raw[0] = a.scales[3 * (size_t)i]; sc_raw[1] = a.scales[3 * (size_t)i + 1]; sc_raw[2] = a.scales[3 * (size_t)i + 2];
+    }
+    const float op_raw = a.opacities[i];
     const float tx = vm[0] * px_ + vm[4] * py_ + vm[8] * pz_ + vm[12];
     const float ty = vm[1] * px_ + vm[5] * py_ + vm[9] * pz_ + vm[13];
     tz = __builtin_fmaf(vm[10], pz_, __builtin_fmaf(vm[6], py_, __builtin_fmaf(vm[2], px_, vm[14])));
@@ -71,11 +80,10 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
         for (int q = 0; q < 6; q++) c6[q] = a.cov3D_precomp[6 * (size_t)i + q];
       } else {
         float invn;
-        const float4 q4 = act_quat(reinterpret_cast<const float4 *>(a.rotations)[i], a.raw, &invn);
+        const float4 q4 = act_quat(q_raw, a.raw, &invn);
         const float r = q4.x, x = q4.y, y = q4.z, z = q4.w;
-        const float s0 = a.scale_mod * act_scale(a.scales[3 * (size_t)i], a.raw),
-                    s1 = a.scale_mod * act_scale(a.scales[3 * (size_t)i + 1], a.raw),
-                    s2 = a.scale_mod * act_scale(a.scales[3 * (size_t)i + 2], a.raw);
+        const float s0 = a.scale_mod * act_scale(sc_raw[0], a.raw), s1 = a.scale_mod * act_scale(sc_raw[1], a.raw),
+                    s2 = a.scale_mod * act_scale(sc_raw[2], a.raw);
         float L[9];
         L[0] = (1 - 2 * (y * y + z * z)) * s0; L[1] = (2 * (x * y - r * z)) * s1;     L[2] = (2 * (x * z + r * y)) * s2;
         L[3] = (2 * (x * y + r * z)) * s0;     L[4] = (1 - 2 * (x * x + z * z)) * s1; L[5] = (2 * (y * z - r * x)) * s2;
@@ -123,7 +131,7 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
         if ((x1 - x0) * (y1 - y0) > 0) {
           vis = true;
           cA = cc * det_inv; cB = -cb * det_inv; cC = ca * det_inv;
-          op = act_opacity(a.opacities[i], a.raw);
+          op = act_opacity(op_raw, a.raw);
           // alpha >= 1/255 needs q <= 2 ln(255 o): tiles (here) and 8x8 pixel blocks (blend kernels) whose minimum q
           // is larger are skipped without changing a single output bit (common.hpp: conic_min_over_box).
           kcut = 1.01f * 2.0f * logf(fmaxf(255.0f * op, 1.0f)) + 0.02f;
