@@ -95,9 +95,10 @@ count_tiles_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, con
   const int lo = blockIdx.x * per_block, hi = min(N, lo + per_block);
   for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
     const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
+    const uint64_t mask = tile_mask[i];   // issued with the record, not after the visibility test
     const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
     if ((br.radius & kRadiusMask) == 0) continue;
-    for_each_tile(br.x0, br.y0, br.x1, br.y1, tile_mask[i], tiles_x, [&](int t) { atomicAdd(&s_hist[t], 1u); });
+    for_each_tile(br.x0, br.y0, br.x1, br.y1, mask, tiles_x, [&](int t) { atomicAdd(&s_hist[t], 1u); });
   }
   __syncthreads();
   uint32_t *row = block_hist + (size_t)blockIdx.x * tiles;
@@ -146,10 +147,11 @@ scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, c
   const int lo = blockIdx.x * per_block, hi = min(N, lo + per_block);
   for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
     const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
+    const uint64_t mask = tile_mask[i];
     const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
     if ((br.radius & kRadiusMask) == 0) continue;
     const uint64_t key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
-    for_each_tile(br.x0, br.y0, br.x1, br.y1, tile_mask[i], tiles_x, [&](int t) {
+    for_each_tile(br.x0, br.y0, br.x1, br.y1, mask, tiles_x, [&](int t) {
       const uint32_t slot = atomicAdd(&s_cur[t], 1u);
       if (slot < capacity) keys[slot] = key;
     });
