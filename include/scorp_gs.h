@@ -96,7 +96,10 @@ const char *scorp_last_error(void);
 /* ---- workspace sizing (pure host arithmetic) ---- */
 /* Forward state: per-Gaussian projected records, per-tile ranges, per-pixel final-T / last-contributor. */
 size_t scorp_gs3d_state_bytes(int32_t num_gaussians, int32_t image_width, int32_t image_height);
-/* Pair buffer for `capacity` (tile,splat) pairs: unsorted 64-bit keys + the depth-sorted 32-bit splat list. */
+/* Pair buffer for `capacity` (tile,splat) pairs: unsorted 64-bit keys + the depth-sorted 32-bit splat list.  After the
+ * sort the key region is reused by the render for one byte per (8x8 pixel block, list entry): whether the splat's
+ * footprint reaches the block.  The backward replays exactly those entries, so it must get the SAME pair buffer the
+ * render filled (it only reads it). */
 size_t scorp_gs3d_pairs_bytes(uint64_t capacity);
 /* Scratch of one backward call (per-Gaussian screen-space gradient accumulators). */
 size_t scorp_gs3d_backward_scratch_bytes(int32_t num_gaussians);

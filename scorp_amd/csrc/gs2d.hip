@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256)
 preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
                     int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
 #pragma clang fp contract(off)
-  __shared__ float s_sh[256 * kShStride];
+  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.N;
   // full blocks of the split K = 16 layout start their SH rows on the way to LDS now (direct global -> LDS loads)
@@ -626,7 +626,7 @@ template <int DEG, bool SPLIT>
 __global__ void __launch_bounds__(256)
 preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const BinRec *__restrict__ bin,
                              const float *__restrict__ acc, ScorpGs3dGrads g) {
-  __shared__ float s_sh[256 * kShStride];
+  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.N;
   const size_t i0 = (size_t)blockIdx.x * 256;

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256)
 preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
                   int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
 #pragma clang fp contract(off)
-  __shared__ float s_sh[256 * kShStride];
+  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.N;
   // Full blocks of the split K = 16 layout start their SH rows on the way to LDS right now (direct global -> LDS
@@ -195,7 +195,7 @@ template <int DEG, bool SPLIT>
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float *__restrict__ acc,
                            ScorpGs3dGrads g) {
-  __shared__ float s_sh[256 * kShStride];
+  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool active = i < a.N;
   const size_t i0 = (size_t)blockIdx.x * 256;
