@@ -38,7 +38,8 @@ namespace {
 //   they are flushed with float atomics shaped as whole 40-byte row segments (lanes = consecutive floats).
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kXStride = 65;                 // floats per slot row of the wave-private v / w matrices
+constexpr int kXStride = 68;                 // floats per slot row of the wave-private v / w matrices: rows stay 16-byte
+                                             // aligned for the A-operand's ds_read_b128; row writes are conflict-free
 constexpr int kGroup = 16;                   // splats per MFMA group
 constexpr float kLog2e = 1.4426950408889634f;
 
@@ -66,7 +67,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   // opacity * G = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity)
   __shared__ float4 q_a[kRing], q_b[kRing], q_c[kRing];
   __shared__ __attribute__((aligned(16))) uint32_t q_id[kRing], q_pos[kRing];
-  __shared__ float xv[kGroup * kXStride], xw[kGroup * kXStride];
+  __shared__ __attribute__((aligned(16))) float xv[kGroup * kXStride], xw[kGroup * kXStride];
   float *dbuf = xw;  // the 16x12 result tile reuses the w matrix once the MFMAs have consumed it
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
@@ -178,15 +179,27 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       f32x4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      // A operands: the lane's 16 + 16 values are consecutive in its row, fetched as eight 16-byte reads issued
+      // together (one exposed LDS latency per group instead of one per batch of eight MFMAs)
+      float4 av[4], aw[4];
 #pragma unroll
-      for (int t = 0; t < 16; t += 2) {
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[abase + t], bv[t], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[abase + t + 1], bv[t + 1], d1, 0, 0, 0);
+      for (int t4 = 0; t4 < 4; t4++) av[t4] = *reinterpret_cast<const float4 *>(&xv[abase + 4 * t4]);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; t4++) aw[t4] = *reinterpret_cast<const float4 *>(&xw[abase + 4 * t4]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; t4++) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bv[4 * t4], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].y, bv[4 * t4 + 1], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].z, bv[4 * t4 + 2], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].w, bv[4 * t4 + 3], d1, 0, 0, 0);
       }
 #pragma unroll
-      for (int t = 0; t < 16; t += 2) {
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[abase + t], bw[t], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[abase + t + 1], bw[t + 1], d1, 0, 0, 0);
+      for (int t4 = 0; t4 < 4; t4++) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].x, bw[4 * t4], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].y, bw[4 * t4 + 1], d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].z, bw[4 * t4 + 2], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].w, bw[4 * t4 + 3], d1, 0, 0, 0);
       }
       const f32x4 d = d0 + d1;
       if (bn < 10) {
