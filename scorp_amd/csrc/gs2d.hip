@@ -306,9 +306,8 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t n = end - beg;
   const float fn = kFarZ / (kFarZ - kNearZ);
-  float T = 1.0f, C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
+  float T = inside ? 1.0f : -1.0f, C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
   uint32_t last = 0, med_c = 0;
-  bool done = !inside;
   int head = 0, count = 0;
   // The chunk's gathers (list entry -> 96-byte record) are dependent loads; software-pipelined: while chunk c is blended
   // the records of chunk c+1 and the list entries of chunk c+2 are in flight.  The footprint verdict of every
@@ -325,7 +324,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   fetch_rec(id0, r0, r1, r2, r3, r4, r5);
   uint32_t id1 = fetch_id(k2FChunk);
   for (uint32_t base = 0; base < n; base += k2FChunk) {
-    if (__ballot(!done) == 0) break;
+    if (__ballot(T > 0.0f) == 0) break;
     float4 nx0, nx1, nx2, nx3, nx4, nx5;   // next chunk's records
     fetch_rec(id1, nx0, nx1, nx2, nx3, nx4, nx5);
     const uint32_t id2 = fetch_id(base + 2 * k2FChunk);
@@ -371,10 +370,11 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
         if (kFull || i < nslots) {  // wave-uniform
           const float4 nr = g4[i];
           const float2 gb = g5[i];
+          // saturation is latched by the sign of T (see blend_forward_wave_kernel)
           const float alpha = al[i];
           const float test_T = T * (1.0f - alpha);
-          done = done || (alpha > 0.0f && test_T < kTMin);
-          const float ae = done ? 0.0f : alpha;
+          const bool ok = test_T >= kTMin;
+          const float ae = ok ? alpha : 0.0f;
           const float w = ae * T;
           const float A = 1.0f - T, mz = mm[i];
           dist += (mz * mz * A + M2 - 2.0f * mz * M1) * w;
@@ -385,7 +385,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
           med_c = is_med ? pos[i] : med_c;
           N0 += nr.x * w; N1 += nr.y * w; N2 += nr.z * w;
           C0 += nr.w * w; C1 += gb.x * w; C2 += gb.y * w;
-          T = done ? T : test_T;
+          T = ok ? test_T : -fabsf(T);
           last = contributes ? pos[i] : last;
         }
       }
@@ -398,6 +398,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   }
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    T = fabsf(T);
     final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
     n_contrib[pix] = last; n_contrib[HW + pix] = med_c;
     out_color[pix] = C0 + T * bg[0]; out_color[HW + pix] = C1 + T * bg[1]; out_color[2 * HW + pix] = C2 + T * bg[2];

@@ -309,9 +309,8 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t n = end - beg;
-  float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f;
+  float T = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f;   // T < 0: pixel finished (see below)
   uint32_t last = 0;
-  bool done = !inside;
   int head = 0, count = 0;   // head stays a multiple of kFGroup (only a wave's final group is partial), so the
                              // slots of a group are head + i without wrap-around: one LDS base, immediate offsets
   // The chunk's gathers (list entry -> record) are dependent loads of ~1 us each; they are software-pipelined: while
@@ -328,7 +327,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   fetch_rec(id0, a, b, c);
   uint32_t id1 = fetch_id(kFChunk);
   for (uint32_t base = 0; base < n; base += kFChunk) {
-    if (__ballot(!done) == 0) break;
+    if (__ballot(T > 0.0f) == 0) break;
     float4 a1, b1, c1;
     fetch_rec(id1, a1, b1, c1);
     const uint32_t id2 = fetch_id(base + 2 * kFChunk);
@@ -377,14 +376,17 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
         if (kFull || i < nslots) {  // wave-uniform
           const float2 rg = *reinterpret_cast<const float2 *>(&gb[i].z);
           const float2 bz = gc[i];
+          // A saturated pixel is latched by the SIGN of T: the splat that would take T below 1e-4 is not blended and
+          // flips T negative, after which every test_T is negative too (a live pixel always has T >= 1e-4, and
+          // alpha = 0 leaves test_T = T exactly).
           const float alpha = al[i];
           const float test_T = T * (1.0f - alpha);
-          done = done || (alpha > 0.0f && test_T < kTMin);   // the splat that would saturate the pixel is not blended
-          const float ae = done ? 0.0f : alpha;
+          const bool ok = test_T >= kTMin;
+          const float ae = ok ? alpha : 0.0f;
           const float w = ae * T;
           C0 += rg.x * w; C1 += rg.y * w; C2 += bz.x * w;
           Dp += bz.y * w;
-          T = done ? T : test_T;
+          T = ok ? test_T : -fabsf(T);
           last = ae > 0.0f ? pos[i] : last;
         }
       }
@@ -397,6 +399,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   }
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    T = fabsf(T);
     final_T[pix] = T;
     n_contrib[pix] = last;
     out_color[pix] = C0 + T * bg[0];
