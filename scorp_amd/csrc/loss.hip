@@ -197,14 +197,28 @@ ssim_l1_backward_kernel(const float *__restrict__ img, const float *__restrict__
       xv[o] = img[ch * HW + p] * mk[o]; yv[o] = gt[ch * HW + p] * mk[o];
     }
   }
-#pragma unroll 1
-  for (int q = 0; q < 3; q++) {
+  // the patch of map q+1 is fetched into registers while map q is convolved (7 pixels per thread)
+  constexpr int kPerThread = (kLP * kLP + 255) / 256;
+  float pre[kPerThread];
+  auto fetch = [&](int q) {
     const float *map = dmaps + q * CHW + ch * HW;
-    for (int i = threadIdx.x; i < kLP * kLP; i += 256) {
+#pragma unroll
+    for (int j = 0; j < kPerThread; j++) {
+      const int i = threadIdx.x + 256 * j;
       const int r = i / kLP, cc = i % kLP;
       const int gy = y0 + r - kLH, gx = x0 + cc - kLH;
-      s_m[r][cc] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? map[(size_t)gy * W + gx] : 0.0f;
+      pre[j] = (i < kLP * kLP && gy >= 0 && gy < H && gx >= 0 && gx < W) ? map[(size_t)gy * W + gx] : 0.0f;
     }
+  };
+  fetch(0);
+#pragma unroll 1
+  for (int q = 0; q < 3; q++) {
+#pragma unroll
+    for (int j = 0; j < kPerThread; j++) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < kLP * kLP) s_m[i / kLP][i % kLP] = pre[j];
+    }
+    if (q < 2) fetch(q + 1);
     __syncthreads();
     {  // horizontal pass: 42 rows x 6 groups of 6 output columns = 252 work items, one pass
       const int it = threadIdx.x;
