@@ -105,29 +105,41 @@ count_tiles_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, con
   for (int t = threadIdx.x; t < tiles; t += kBinThreads) row[t] = s_hist[t];
 }
 
-// 64 tiles x 16 segments of the block range per workgroup: wave `seg` sums its blocks for 64 consecutive tiles
-// (coalesced 256-byte rows), the segment totals are exchanged through LDS, then the prefixes are written in place.
-__global__ void __launch_bounds__(1024)
+// 32 tiles x 32 segments of the block range per workgroup (235 workgroups at 7500 tiles — enough to cover every CU;
+// the first form, 64 x 16, left half the chip idle): each thread sums its blocks for one tile (coalesced 128-byte
+// rows), the segment totals are exchanged through LDS, then the prefixes are written in place.
+constexpr int kScanTiles = 32, kScanSegs = 32;
+__global__ void __launch_bounds__(kScanTiles * kScanSegs)
 scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uint32_t *__restrict__ tile_count) {
-  __shared__ uint32_t s_seg[16][64];
-  const int tl = threadIdx.x & 63, seg = threadIdx.x >> 6;
-  const int t = blockIdx.x * 64 + tl;
-  const int per = (nb + 15) / 16;
+  __shared__ uint32_t s_seg[kScanSegs][kScanTiles];
+  const int tl = threadIdx.x % kScanTiles, seg = threadIdx.x / kScanTiles;
+  const int t = blockIdx.x * kScanTiles + tl;
+  const int per = (nb + kScanSegs - 1) / kScanSegs;
   const int b0 = min(nb, seg * per), b1 = min(nb, b0 + per);
+  // the segment's counts stay in registers between the two passes (nb <= 512 -> at most 16 per thread), and all of
+  // its loads are in flight together instead of one per loop iteration
+  constexpr int kMaxPer = (kBinBlocksMax + kScanSegs - 1) / kScanSegs;
+  uint32_t cnt[kMaxPer];
   uint32_t sum = 0;
-  if (t < tiles)
-    for (int b = b0; b < b1; b++) sum += block_hist[(size_t)b * tiles + t];
+#pragma unroll
+  for (int j = 0; j < kMaxPer; j++) {
+    const int b = b0 + j;
+    cnt[j] = (t < tiles && b < b1) ? block_hist[(size_t)b * tiles + t] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxPer; j++) sum += cnt[j];
   s_seg[seg][tl] = sum;
   __syncthreads();
   uint32_t run = 0;
   for (int q = 0; q < seg; q++) run += s_seg[q][tl];
   if (t < tiles) {
-    for (int b = b0; b < b1; b++) {
-      const uint32_t c = block_hist[(size_t)b * tiles + t];
-      block_hist[(size_t)b * tiles + t] = run;
-      run += c;
+#pragma unroll
+    for (int j = 0; j < kMaxPer; j++) {
+      const int b = b0 + j;
+      if (b < b1) block_hist[(size_t)b * tiles + t] = run;
+      run += cnt[j];
     }
-    if (seg == 15) tile_count[t] = run;
+    if (seg == kScanSegs - 1) tile_count[t] = run;
   }
 }
 
@@ -460,7 +472,7 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
       count_tiles_lds_kernel<<<L.nb, kBinThreads, (size_t)L.tiles * 4, stream>>>(N, per_block, (const BinRec *)(base + L.bin),
                                                                         (const uint64_t *)(base + L.tile_mask), L.tiles,
                                                                         L.tiles_x, block_hist);
-      scan_block_hist_kernel<<<(L.tiles + 63) / 64, 1024, 0, stream>>>(L.nb, L.tiles, block_hist, tile_count);
+      scan_block_hist_kernel<<<(L.tiles + kScanTiles - 1) / kScanTiles, kScanTiles * kScanSegs, 0, stream>>>(L.nb, L.tiles, block_hist, tile_count);
     }
     SCORP_KERNEL_CHECK("count_tiles", debug, stream);
   }
