@@ -23,28 +23,42 @@ namespace {
 __global__ void __launch_bounds__(1024)
 scan_tiles_kernel(const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_start, int tiles,
                   StateHeader *__restrict__ header) {
-  __shared__ uint32_t s_part[1024];
-  const int t = threadIdx.x;
+  __shared__ uint32_t s_wave[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int per = (tiles + 1023) / 1024;
   const int lo = min(tiles, t * per), hi = min(tiles, lo + per);
   uint32_t sum = 0;
   for (int k = lo; k < hi; k++) sum += tile_count[k];
-  s_part[t] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan over the 1024 partials
-    uint32_t v = t >= off ? s_part[t - off] : 0u;
-    __syncthreads();
-    s_part[t] += v;
-    __syncthreads();
+  // inclusive scan over the 1024 partials: shuffles inside each wave, the 16 wave totals through LDS (two barriers
+  // instead of the twenty of a Hillis-Steele over LDS)
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+    if (lane >= off) incl += v;
   }
-  uint32_t run = s_part[t] - sum;
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < 16 ? s_wave[lane] : 0u;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)w, off, 64);
+      if (lane >= off) w += v;
+    }
+    if (lane < 16) s_wave[lane] = w;   // inclusive totals of waves 0..lane
+  }
+  __syncthreads();
+  incl += wave > 0 ? s_wave[wave - 1] : 0u;
+  const uint32_t total = s_wave[15];
+  uint32_t run = incl - sum;
   for (int k = lo; k < hi; k++) {
     tile_start[k] = run;
     run += tile_count[k];
   }
   if (t == 1023) {
-    tile_start[tiles] = s_part[1023];
-    header->num_pairs = s_part[1023];
+    tile_start[tiles] = total;
+    header->num_pairs = total;
     header->overflow = 0;
   }
 }
