@@ -252,7 +252,7 @@ def main():
         tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        ll = torch.tensor([float(loss)], device=cdev)
+        ll = torch.tensor([float(loss.detach())], device=cdev)
         gathered = [torch.zeros_like(ll) for _ in range(world)]
         dist.all_gather(gathered, ll)     # gather of per-rank results (scalars)
 
