@@ -81,19 +81,10 @@ __device__ __forceinline__ float conic_min_over_box(float cx, float cy, float A,
   return best;
 }
 
-// Two wave-wide sums for the price of little more than one: v_permlane32_swap pairs the halves (lanes 0-31 then hold
-// a.lo + a.hi, lanes 32-63 hold b.lo + b.hi), four row_ror DPP adds reduce each 16-lane row, one bpermute joins the
-// two rows of a half.  Result: total(a) in every lane < 32, total(b) in every lane >= 32.
+// v + (v moved across lanes by the DPP control CTRL): the building block of the in-row reductions (gs2d.hip).
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   return v + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float wave_sum_pair(float a, float b) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  v = dpp_add<0x128>(v); v = dpp_add<0x124>(v); v = dpp_add<0x122>(v); v = dpp_add<0x121>(v);  // row_ror 8,4,2,1
-  v += __shfl_xor(v, 16, 64);
-  return v;
 }
 
 // Tile mask convention: bit (ty - y0) * 8 + (tx - x0) for rectangles of at most 8 x 8 tiles; ~0 = whole rectangle.

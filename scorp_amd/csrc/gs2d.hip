@@ -479,7 +479,6 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   const int px = bx + (lane & 7), py = by + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
-  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   if (end == beg) return;
   const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;

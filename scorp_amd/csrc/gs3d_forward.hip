@@ -595,10 +595,9 @@ extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *p
   if (capacity > 0xFFFFFFFFull) { set_error("capacity above 2^32-1 pairs"); return SCORP_ERR_INVALID; }
   if (!out_color || !out_depth || !out_alpha) { set_error("output image pointer is NULL"); return SCORP_ERR_INVALID; }
   char *base = (char *)state, *pb = (char *)pairs;
-  uint32_t *tile_count = (uint32_t *)(base + L.tile_count), *tile_start = (uint32_t *)(base + L.tile_start);
+  uint32_t *tile_start = (uint32_t *)(base + L.tile_start);
   uint64_t *keys = (uint64_t *)(pb + P.keys);
   uint32_t *point_list = (uint32_t *)(pb + P.list);
-  StateHeader *header = (StateHeader *)(base + L.header);
   if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
   {
     ProfScope prof(kKBlendForward, stream);

@@ -131,15 +131,8 @@ __device__ __forceinline__ void sh_row_zero(ShRow r) {
 #pragma unroll
   for (int c = 3; c < 48; c++) r.pr[c] = 0.0f;
 }
-// Linear staging of a FULL block (256 rows) of the split layout with K = 16: two plain 16-byte streams, no index math.
-__device__ __forceinline__ void stage_sh_linear(float *__restrict__ lds, const float *__restrict__ dc,
-                                                const float *__restrict__ rest, size_t i0) {
-  const float4 *d4 = reinterpret_cast<const float4 *>(dc + i0 * 3), *r4 = reinterpret_cast<const float4 *>(rest + i0 * 45);
-  float4 *l4 = reinterpret_cast<float4 *>(lds), *lr4 = reinterpret_cast<float4 *>(lds + kShLinearRest);
-  for (int e = threadIdx.x; e < 256 * 3 / 4; e += 256) l4[e] = d4[e];
-  for (int e = threadIdx.x; e < 256 * 45 / 4; e += 256) lr4[e] = r4[e];
-}
-// The same copy issued as direct global -> LDS loads (global_load_lds_dwordx4: each lane's 16 bytes land at
+// Linear staging of a FULL block (256 rows) of the split layout with K = 16: two plain 16-byte streams, no index math,
+// issued as direct global -> LDS loads (global_load_lds_dwordx4: each lane's 16 bytes land at
 // M0 base + lane * 16, no VGPR round trip).  Fire-and-forget: the caller does its other work, then
 // stage_sh_wait() + a workgroup barrier before anyone reads the rows.  48 wave-chunks of 1 KiB, 12 per wave.
 __device__ __forceinline__ void stage_sh_linear_async(float *__restrict__ lds, const float *__restrict__ dc,
