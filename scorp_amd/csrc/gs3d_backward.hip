@@ -101,10 +101,12 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // tell the compiler it is wave-uniform: the chunk loop,
   if (todo == 0) return;                                        // ring head / count and slot indices then live in SGPRs
   const int bn = lane & 15, bk = lane >> 4;
-  float bv[16], bw[16];
-  // B operand of the W half: the upstream gradients (dL/dr, dL/dg, dL/db, dL/ddepth) of pixel q in column 6..9.  Every
-  // lane already holds its own pixel's four values, so they are exchanged through LDS (xw is idle until the first
-  // group) instead of being gathered from global memory again.
+  float bb[16];
+  // B operand.  A lane supplies ONE column bn of the 16-column basis: columns 0..5 are the position basis of the V half
+  // (1, x, y, x^2, xy, y^2 in the block frame), 6..9 the upstream gradients (dL/dr, dL/dg, dL/db, dL/ddepth) of the W
+  // half — so one register array serves both halves; the V and W products accumulate separately and the lane keeps the
+  // one that belongs to its column.  Every lane already holds its own pixel's four gradients, so they are exchanged
+  // through LDS (xw is idle until the first group) instead of being gathered from global memory again.
   xw[lane * 4 + 0] = dpix0; xw[lane * 4 + 1] = dpix1; xw[lane * 4 + 2] = dpix2; xw[lane * 4 + 3] = ddep;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -116,9 +118,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     float v = 0.0f;
     v = bn == 0 ? 1.0f : v; v = bn == 1 ? xl : v; v = bn == 2 ? yl : v;
     v = bn == 3 ? xl * xl : v; v = bn == 4 ? xl * yl : v; v = bn == 5 ? yl * yl : v;
-    bv[t] = v;
     const float w = xw[q * 4 + ((bn - 6) & 3)];
-    bw[t] = (bn >= 6 && bn <= 9) ? w : 0.0f;
+    bb[t] = (bn >= 6 && bn <= 9) ? w : v;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -178,30 +179,26 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      f32x4 d0 = {0.0f, 0.0f, 0.0f, 0.0f}, d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      f32x4 dv = {0.0f, 0.0f, 0.0f, 0.0f}, dw = {0.0f, 0.0f, 0.0f, 0.0f};
       // A operands: the lane's 16 + 16 values are consecutive in its row, fetched as eight 16-byte reads issued
-      // together (one exposed LDS latency per group instead of one per batch of eight MFMAs)
+      // together; the V chain and the W chain are independent and interleave on the matrix pipe
       float4 av[4], aw[4];
 #pragma unroll
       for (int t4 = 0; t4 < 4; t4++) av[t4] = *reinterpret_cast<const float4 *>(&xv[abase + 4 * t4]);
 #pragma unroll
       for (int t4 = 0; t4 < 4; t4++) aw[t4] = *reinterpret_cast<const float4 *>(&xw[abase + 4 * t4]);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t4 = 0; t4 < 4; t4++) {
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bv[4 * t4], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].y, bv[4 * t4 + 1], d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].z, bv[4 * t4 + 2], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].w, bv[4 * t4 + 3], d1, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bb[4 * t4], dv, 0, 0, 0);
+        dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].x, bb[4 * t4], dw, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].y, bb[4 * t4 + 1], dv, 0, 0, 0);
+        dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].y, bb[4 * t4 + 1], dw, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].z, bb[4 * t4 + 2], dv, 0, 0, 0);
+        dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].z, bb[4 * t4 + 2], dw, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].w, bb[4 * t4 + 3], dv, 0, 0, 0);
+        dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].w, bb[4 * t4 + 3], dw, 0, 0, 0);
       }
-#pragma unroll
-      for (int t4 = 0; t4 < 4; t4++) {
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].x, bw[4 * t4], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].y, bw[4 * t4 + 1], d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].z, bw[4 * t4 + 2], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].w, bw[4 * t4 + 3], d1, 0, 0, 0);
-      }
-      const f32x4 d = d0 + d1;
+      const f32x4 d = bn < 6 ? dv : dw;
       if (bn < 10) {
 #pragma unroll
         for (int r = 0; r < 4; r++) dbuf[(4 * bk + r) * kAccStride + bn] = d[r];
