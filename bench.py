@@ -147,7 +147,7 @@ def main():
     from scorp_amd.synthetic import SCENES, make_gaussians, ring_cameras
     surfels = args.scene == "S6"                      # BASELINE config #5: the 2DGS surfel path
     if surfels:
-        from scorp_amd.renderer2d import GaussianModel2D as GaussianModel, render as render2d, surfel_regularizers
+        from scorp_amd.renderer2d import GaussianModel2D as GaussianModel, render as render2d, fused_surfel_regularizers as surfel_regularizers
         render = render2d
     else:
         render = render3d

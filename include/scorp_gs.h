@@ -182,6 +182,21 @@ int scorp_gs2d_maps_backward(int32_t image_width, int32_t image_height, const fl
                              const float *g_surf_depth, const float *g_surf_normal, float *g_allmap,
                              scorp_stream_t stream);
 
+/* ---- the 2DGS regularisers of train_2dgs.py:142-150, fused over the same per-pixel tail ----
+ * out2 (device) = { lambda_normal * mean(1 - render_normal . surf_normal), lambda_dist * mean(render_dist) } straight
+ * from allmap (no maps are materialised); the backward writes g_allmap[7,H,W] for upstream gradients g_out2 (device,
+ * two floats; NULL = ones).  workspace: scorp_gs2d_regularizers_workspace_bytes (per-workgroup partial sums; the
+ * reduction order is fixed, so the value is deterministic). */
+size_t scorp_gs2d_regularizers_workspace_bytes(int32_t image_width, int32_t image_height);
+int scorp_gs2d_regularizers_forward(int32_t image_width, int32_t image_height, const float *allmap, const float *viewmatrix,
+                                    const float *rays_d, const float *rays_o, float depth_ratio, float lambda_normal,
+                                    float lambda_dist, float *out2, void *workspace, size_t workspace_bytes,
+                                    scorp_stream_t stream);
+int scorp_gs2d_regularizers_backward(int32_t image_width, int32_t image_height, const float *allmap,
+                                     const float *viewmatrix, const float *rays_d, const float *rays_o, float depth_ratio,
+                                     float lambda_normal, float lambda_dist, const float *g_out2, float *g_allmap,
+                                     scorp_stream_t stream);
+
 /* ---- fused photometric loss (rows a8/a9 of the hot path) ----
  * loss = (1-lambda) * mean|x-y| + lambda * (1 - mean SSIM(x,y)), x = img*mask, y = gt*mask (mask [H,W] or NULL):
  * train_3dgs.py:106-107, post_refine_gs.py:103-111 over gs3dgs/utils/loss_utils.py:17-73 (11x11 Gaussian window,

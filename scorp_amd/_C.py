@@ -43,7 +43,8 @@ EXPORTS = [
     "scorp_knn_dist2", "scorp_adam_step",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
     "scorp_gs2d_backward", "scorp_gs2d_debug_geom", "scorp_gs2d_debug_tiles", "scorp_gs2d_maps_forward",
-    "scorp_gs2d_maps_backward",
+    "scorp_gs2d_maps_backward", "scorp_gs2d_regularizers_workspace_bytes", "scorp_gs2d_regularizers_forward",
+    "scorp_gs2d_regularizers_backward",
     "scorp_prof_enable", "scorp_prof_select", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
 ]
 
@@ -94,6 +95,10 @@ def lib():
     L.scorp_gs2d_debug_tiles.argtypes = [vp, vp, u64, i32, i32, i32, vp, vp, vp]
     L.scorp_gs2d_maps_forward.argtypes = [i32, i32, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp, vp]
     L.scorp_gs2d_maps_backward.argtypes = [i32, i32, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.scorp_gs2d_regularizers_workspace_bytes.restype = sz
+    L.scorp_gs2d_regularizers_workspace_bytes.argtypes = [i32, i32]
+    L.scorp_gs2d_regularizers_forward.argtypes = [i32, i32, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, sz, vp]
+    L.scorp_gs2d_regularizers_backward.argtypes = [i32, i32, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
     L.scorp_knn_dist2.argtypes = [vp, i32, vp, vp]
     L.scorp_adam_step.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i32, vp]
     L.scorp_prof_enable.argtypes = [ctypes.c_int]

@@ -89,17 +89,54 @@ maps_forward_kernel(MapsDev dev, const float *__restrict__ allmap, const float *
   surf_normal[p] = n.x; surf_normal[HW + p] = n.y; surf_normal[2 * HW + p] = n.z;
 }
 
-// Gradient of the loss with respect to the two difference vectors of the normal centred at pixel c (must be interior).
-__device__ __forceinline__ void centre_grads(const MapsArgs &a, const float *__restrict__ sd, const float *__restrict__ rays_d,
-                                             const float *__restrict__ allmap, const float *__restrict__ g_sn, size_t HW,
-                                             size_t c, V3 &g_dv, V3 &g_dh) {
+// Where the backward takes its upstream gradients from.  kReg = false: the five gradient maps of an arbitrary loss
+// (scorp_gs2d_maps_backward).  kReg = true: the two regularisers of train_2dgs.py:142-150 fused in —
+// normal_loss = lambda_n * mean(1 - rend_normal . surf_normal), dist_loss = lambda_d * mean(render_dist) — whose
+// gradient maps are scaled copies of the OTHER map (d/d rend_normal = -k surf_normal, d/d surf_normal = -k rend_normal,
+// d/d dist = k_d) and are re-derived from allmap on the fly; the surface depth is recomputed instead of stored.
+struct MapsGrads {
+  const float *sd, *g_alpha, *g_rn, *g_dist, *g_sd, *g_sn;   // kReg = false
+  float kn, kd;                                               // kReg = true: lambda_n * g0 / HW, lambda_d * g1 / HW
+};
+
+template <bool kReg>
+__device__ __forceinline__ float depth_at(const MapsArgs &a, const MapsGrads &G, const float *__restrict__ allmap, size_t HW, size_t q) {
+  return kReg ? surf_depth_of(allmap, HW, q, a.depth_ratio) : G.sd[q];
+}
+
+// world-space rendered normal at pixel q (what render() returns as render_normal)
+__device__ __forceinline__ V3 world_normal(const MapsArgs &a, const float *__restrict__ allmap, size_t HW, size_t q) {
+  const float n0 = allmap[2 * HW + q], n1 = allmap[3 * HW + q], n2 = allmap[4 * HW + q];
+  return {n0 * a.V[0] + n1 * a.V[1] + n2 * a.V[2], n0 * a.V[3] + n1 * a.V[4] + n2 * a.V[5], n0 * a.V[6] + n1 * a.V[7] + n2 * a.V[8]};
+}
+
+// the two difference vectors of the normal centred at pixel c (must be interior), their cross product and its length
+template <bool kReg>
+__device__ __forceinline__ void centre_frame(const MapsArgs &a, const MapsGrads &G, const float *__restrict__ rays_d,
+                                             const float *__restrict__ allmap, size_t HW, size_t c, V3 &dv, V3 &dh, V3 &cr,
+                                             float &len) {
   const size_t pu = c - a.W, pd = c + a.W, pl = c - 1, pr = c + 1;
-  const V3 dv = point_of(sd[pd], rays_d, pd, a.ro) - point_of(sd[pu], rays_d, pu, a.ro);
-  const V3 dh = point_of(sd[pr], rays_d, pr, a.ro) - point_of(sd[pl], rays_d, pl, a.ro);
-  const V3 cr = cross3(dv, dh);
-  const float len = sqrtf(dot3(cr, cr));
+  dv = point_of(depth_at<kReg>(a, G, allmap, HW, pd), rays_d, pd, a.ro) - point_of(depth_at<kReg>(a, G, allmap, HW, pu), rays_d, pu, a.ro);
+  dh = point_of(depth_at<kReg>(a, G, allmap, HW, pr), rays_d, pr, a.ro) - point_of(depth_at<kReg>(a, G, allmap, HW, pl), rays_d, pl, a.ro);
+  cr = cross3(dv, dh);
+  len = sqrtf(dot3(cr, cr));
+}
+
+// Gradient of the loss with respect to the two difference vectors of the normal centred at pixel c (must be interior).
+template <bool kReg>
+__device__ __forceinline__ void centre_grads(const MapsArgs &a, const MapsGrads &Gr, const float *__restrict__ rays_d,
+                                             const float *__restrict__ allmap, size_t HW, size_t c, V3 &g_dv, V3 &g_dh) {
+  V3 dv, dh, cr;
+  float len;
+  centre_frame<kReg>(a, Gr, rays_d, allmap, HW, c, dv, dh, cr, len);
   const float al = allmap[HW + c];
-  const V3 G = {g_sn[c] * al, g_sn[HW + c] * al, g_sn[2 * HW + c] * al};
+  V3 G;
+  if (kReg) {
+    const V3 rn = world_normal(a, allmap, HW, c);
+    G = {-Gr.kn * rn.x * al, -Gr.kn * rn.y * al, -Gr.kn * rn.z * al};
+  } else {
+    G = {Gr.g_sn[c] * al, Gr.g_sn[HW + c] * al, Gr.g_sn[2 * HW + c] * al};
+  }
   V3 gc;
   if (len > kNormEps) {
     const float inv = 1.0f / len;
@@ -113,38 +150,103 @@ __device__ __forceinline__ void centre_grads(const MapsArgs &a, const float *__r
   g_dh = cross3(gc, dv);   // d(dv x dh)/d dh
 }
 
+template <bool kReg>
 __global__ void __launch_bounds__(256)
-maps_backward_kernel(MapsDev dev, const float *__restrict__ allmap, const float *__restrict__ rays_d,
-                     const float *__restrict__ sd, const float *__restrict__ g_alpha, const float *__restrict__ g_rn,
-                     const float *__restrict__ g_dist, const float *__restrict__ g_sd, const float *__restrict__ g_sn,
-                     float *__restrict__ g_allmap) {
+maps_backward_kernel(MapsDev dev, const float *__restrict__ allmap, const float *__restrict__ rays_d, MapsGrads Gr,
+                     const float *__restrict__ g_out2, float lambda_normal, float lambda_dist, float *__restrict__ g_allmap) {
   const MapsArgs a(dev);
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= a.W || y >= a.H) return;
   const size_t HW = (size_t)a.W * a.H, p = (size_t)y * a.W + x;
-  float gd = g_sd ? g_sd[p] : 0.0f;
-  if (g_sn) {
+  if (kReg) {
+    const float inv_hw = 1.0f / (float)HW;
+    Gr.kn = lambda_normal * (g_out2 ? g_out2[0] : 1.0f) * inv_hw;
+    Gr.kd = lambda_dist * (g_out2 ? g_out2[1] : 1.0f) * inv_hw;
+  }
+  const bool xin = x >= 1 && x < a.W - 1, yin = y >= 1 && y < a.H - 1;
+  float gd = (!kReg && Gr.g_sd) ? Gr.g_sd[p] : 0.0f;
+  if (kReg || Gr.g_sn) {
     V3 gp = {0.0f, 0.0f, 0.0f}, u, v;
-    const bool xin = x >= 1 && x < a.W - 1, yin = y >= 1 && y < a.H - 1;
-    if (xin && y >= 2) { centre_grads(a, sd, rays_d, allmap, g_sn, HW, p - a.W, u, v); gp.x += u.x; gp.y += u.y; gp.z += u.z; }       // this pixel is the lower end of dv there
-    if (xin && y < a.H - 2) { centre_grads(a, sd, rays_d, allmap, g_sn, HW, p + a.W, u, v); gp.x -= u.x; gp.y -= u.y; gp.z -= u.z; }
-    if (yin && x >= 2) { centre_grads(a, sd, rays_d, allmap, g_sn, HW, p - 1, u, v); gp.x += v.x; gp.y += v.y; gp.z += v.z; }
-    if (yin && x < a.W - 2) { centre_grads(a, sd, rays_d, allmap, g_sn, HW, p + 1, u, v); gp.x -= v.x; gp.y -= v.y; gp.z -= v.z; }
+    if (xin && y >= 2) { centre_grads<kReg>(a, Gr, rays_d, allmap, HW, p - a.W, u, v); gp.x += u.x; gp.y += u.y; gp.z += u.z; }       // this pixel is the lower end of dv there
+    if (xin && y < a.H - 2) { centre_grads<kReg>(a, Gr, rays_d, allmap, HW, p + a.W, u, v); gp.x -= u.x; gp.y -= u.y; gp.z -= u.z; }
+    if (yin && x >= 2) { centre_grads<kReg>(a, Gr, rays_d, allmap, HW, p - 1, u, v); gp.x += v.x; gp.y += v.y; gp.z += v.z; }
+    if (yin && x < a.W - 2) { centre_grads<kReg>(a, Gr, rays_d, allmap, HW, p + 1, u, v); gp.x -= v.x; gp.y -= v.y; gp.z -= v.z; }
     gd += gp.x * rays_d[3 * p] + gp.y * rays_d[3 * p + 1] + gp.z * rays_d[3 * p + 2];
   }
   const float a0 = allmap[p], al = allmap[HW + p], med = allmap[5 * HW + p];
-  float g0 = 0.0f, g1 = g_alpha ? g_alpha[p] : 0.0f;
+  float g0 = 0.0f, g1 = (!kReg && Gr.g_alpha) ? Gr.g_alpha[p] : 0.0f;
   const float ge = gd * (1.0f - a.depth_ratio);
   // where the forward's a0/alpha was nan/inf (empty pixels) nan_to_num stops the gradient; PyTorch then still divides
   // 0 by alpha = 0 and hands the rasterizer NaN at pixels it never reads — here those entries are plain zeros
   if (al != 0.0f && passes_grad(a0 / al)) { g0 = ge / al; g1 -= ge * a0 / (al * al); }
   g_allmap[p] = g0;
   g_allmap[HW + p] = g1;
+  V3 grn = {0.0f, 0.0f, 0.0f};   // gradient w.r.t. the world-space rendered normal at this pixel
+  if (kReg) {
+    if (xin && yin) {           // -k * surf_normal = -k * alpha * normalize(dv x dh)
+      V3 dv, dh, cr;
+      float len;
+      centre_frame<kReg>(a, Gr, rays_d, allmap, HW, p, dv, dh, cr, len);
+      const float sc = -Gr.kn * al / fmaxf(len, kNormEps);
+      grn = {cr.x * sc, cr.y * sc, cr.z * sc};
+    }
+  } else if (Gr.g_rn) {
+    grn = {Gr.g_rn[p], Gr.g_rn[HW + p], Gr.g_rn[2 * HW + p]};
+  }
 #pragma unroll
-  for (int i = 0; i < 3; i++)
-    g_allmap[(2 + i) * HW + p] = g_rn ? g_rn[p] * a.V[i] + g_rn[HW + p] * a.V[3 + i] + g_rn[2 * HW + p] * a.V[6 + i] : 0.0f;
+  for (int i = 0; i < 3; i++) g_allmap[(2 + i) * HW + p] = grn.x * a.V[i] + grn.y * a.V[3 + i] + grn.z * a.V[6 + i];
   g_allmap[5 * HW + p] = passes_grad(med) ? gd * a.depth_ratio : 0.0f;
-  g_allmap[6 * HW + p] = g_dist ? g_dist[p] : 0.0f;
+  g_allmap[6 * HW + p] = kReg ? Gr.kd : (Gr.g_dist ? Gr.g_dist[p] : 0.0f);
+}
+
+// ---- the regularisers' forward: per-block partial sums of (1 - rend_normal . surf_normal) and render_dist ----
+__global__ void __launch_bounds__(256)
+reg_forward_kernel(MapsDev dev, const float *__restrict__ allmap, const float *__restrict__ rays_d, float *__restrict__ partials) {
+  const MapsArgs a(dev);
+  __shared__ float s_red[2][4];
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  float t = 0.0f, dist = 0.0f;
+  if (x < a.W && y < a.H) {
+    const size_t HW = (size_t)a.W * a.H, p = (size_t)y * a.W + x;
+    dist = allmap[6 * HW + p];
+    float dotn = 0.0f;
+    if (x >= 1 && y >= 1 && x < a.W - 1 && y < a.H - 1) {
+      MapsGrads none = {};
+      V3 dv, dh, cr;
+      float len;
+      centre_frame<true>(a, none, rays_d, allmap, HW, p, dv, dh, cr, len);
+      const V3 rn = world_normal(a, allmap, HW, p);
+      dotn = dot3(rn, cr) * (allmap[HW + p] / fmaxf(len, kNormEps));
+    }
+    t = 1.0f - dotn;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { t += __shfl_xor(t, off, 64); dist += __shfl_xor(dist, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = t; s_red[1][threadIdx.x >> 6] = dist; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int b = blockIdx.y * gridDim.x + blockIdx.x;
+    partials[2 * b] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    partials[2 * b + 1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+reg_finalize_kernel(const float *__restrict__ partials, int nblocks, double inv_hw, float lambda_normal, float lambda_dist,
+                    float *__restrict__ out2) {
+  __shared__ double s_a[256], s_b[256];
+  double sa = 0, sb = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { sa += partials[2 * i]; sb += partials[2 * i + 1]; }
+  s_a[threadIdx.x] = sa; s_b[threadIdx.x] = sb;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) { s_a[threadIdx.x] += s_a[threadIdx.x + off]; s_b[threadIdx.x] += s_b[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = (float)(lambda_normal * s_a[0] * inv_hw);
+    out2[1] = (float)(lambda_dist * s_b[0] * inv_hw);
+  }
 }
 
 int fill_args(MapsDev &a, int W, int H, const float *viewmatrix, const float *rays_o, float depth_ratio) {
@@ -189,9 +291,56 @@ extern "C" int scorp_gs2d_maps_backward(int32_t W, int32_t H, const float *allma
   hipStream_t stream = (hipStream_t)stream_;
   {
     ProfScope prof(kKMapsBackward2d, stream);
-    maps_backward_kernel<<<dim3((W + 63) / 64, (H + 3) / 4), 256, 0, stream>>>(
-        a, allmap, rays_d, surf_depth, g_render_alpha, g_render_normal, g_render_dist, g_surf_depth, g_surf_normal, g_allmap);
+    MapsGrads Gr = {};
+    Gr.sd = surf_depth; Gr.g_alpha = g_render_alpha; Gr.g_rn = g_render_normal; Gr.g_dist = g_render_dist;
+    Gr.g_sd = g_surf_depth; Gr.g_sn = g_surf_normal;
+    maps_backward_kernel<false><<<dim3((W + 63) / 64, (H + 3) / 4), 256, 0, stream>>>(a, allmap, rays_d, Gr, nullptr, 0.0f, 0.0f,
+                                                                                       g_allmap);
   }
   SCORP_KERNEL_CHECK("surfel_maps_backward", 0, stream);
+  return SCORP_OK;
+}
+
+static inline int reg_blocks(int W, int H) { return ((W + 63) / 64) * ((H + 3) / 4); }
+
+extern "C" size_t scorp_gs2d_regularizers_workspace_bytes(int32_t W, int32_t H) {
+  return align_up((size_t)reg_blocks(W > 0 ? W : 1, H > 0 ? H : 1) * 8, 256);
+}
+
+extern "C" int scorp_gs2d_regularizers_forward(int32_t W, int32_t H, const float *allmap, const float *viewmatrix,
+                                               const float *rays_d, const float *rays_o, float depth_ratio,
+                                               float lambda_normal, float lambda_dist, float *out2, void *workspace,
+                                               size_t workspace_bytes, scorp_stream_t stream_) {
+  MapsDev a;
+  if (int e = fill_args(a, W, H, viewmatrix, rays_o, depth_ratio)) return e;
+  if (!allmap || !rays_d || !out2 || !workspace) { set_error("NULL pointer in scorp_gs2d_regularizers_forward"); return SCORP_ERR_INVALID; }
+  if (workspace_bytes < scorp_gs2d_regularizers_workspace_bytes(W, H)) { set_error("regulariser workspace too small"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  {
+    ProfScope prof(kKMapsForward2d, stream);
+    reg_forward_kernel<<<dim3((W + 63) / 64, (H + 3) / 4), 256, 0, stream>>>(a, allmap, rays_d, (float *)workspace);
+  }
+  SCORP_KERNEL_CHECK("surfel_regularizers_forward", 0, stream);
+  reg_finalize_kernel<<<1, 256, 0, stream>>>((const float *)workspace, reg_blocks(W, H), 1.0 / ((double)W * H), lambda_normal,
+                                             lambda_dist, out2);
+  SCORP_KERNEL_CHECK("surfel_regularizers_finalize", 0, stream);
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs2d_regularizers_backward(int32_t W, int32_t H, const float *allmap, const float *viewmatrix,
+                                                const float *rays_d, const float *rays_o, float depth_ratio,
+                                                float lambda_normal, float lambda_dist, const float *g_out2,
+                                                float *g_allmap, scorp_stream_t stream_) {
+  MapsDev a;
+  if (int e = fill_args(a, W, H, viewmatrix, rays_o, depth_ratio)) return e;
+  if (!allmap || !rays_d || !g_allmap) { set_error("NULL pointer in scorp_gs2d_regularizers_backward"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  {
+    ProfScope prof(kKMapsBackward2d, stream);
+    MapsGrads Gr = {};
+    maps_backward_kernel<true><<<dim3((W + 63) / 64, (H + 3) / 4), 256, 0, stream>>>(a, allmap, rays_d, Gr, g_out2, lambda_normal,
+                                                                                      lambda_dist, g_allmap);
+  }
+  SCORP_KERNEL_CHECK("surfel_regularizers_backward", 0, stream);
   return SCORP_OK;
 }

@@ -202,3 +202,42 @@ def surfel_maps(allmap, viewmatrix, rays_d, rays_o, depth_ratio):
         raise RuntimeError("surfel_maps needs CUDA/HIP tensors: scorp_amd has no CPU fallback")
     return _SurfelMaps.apply(allmap, _prep(viewmatrix, "viewmatrix"), _prep(rays_d, "rays_d"), _prep(rays_o, "rays_o"),
                              depth_ratio)
+
+
+class _SurfelRegularizers(torch.autograd.Function):
+    """(normal_loss, dist_loss) of train_2dgs.py:142-150 straight from allmap: scorp_gs2d_regularizers_forward/backward."""
+
+    @staticmethod
+    def forward(ctx, allmap, viewmatrix, rays_d, rays_o, depth_ratio, lambda_normal, lambda_dist):
+        L = _C.lib()
+        allmap = _prep(allmap, "allmap")
+        _, H, W = allmap.shape
+        out = torch.empty(2, dtype=torch.float32, device=allmap.device)
+        wb = L.scorp_gs2d_regularizers_workspace_bytes(W, H)
+        ws = torch.empty(wb, dtype=torch.uint8, device=allmap.device)
+        _C.check(L.scorp_gs2d_regularizers_forward(W, H, _ptr(allmap), _ptr(viewmatrix), _ptr(rays_d), _ptr(rays_o),
+                                                   float(depth_ratio), float(lambda_normal), float(lambda_dist), _ptr(out),
+                                                   _ptr(ws), wb, _stream()), "scorp_gs2d_regularizers_forward")
+        ctx.save_for_backward(allmap, viewmatrix, rays_d, rays_o)
+        ctx.consts = (float(depth_ratio), float(lambda_normal), float(lambda_dist))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        L = _C.lib()
+        allmap, viewmatrix, rays_d, rays_o = ctx.saved_tensors
+        _, H, W = allmap.shape
+        g_out = _prep(g_out, "grad")
+        g_allmap = torch.empty_like(allmap)
+        dr, ln, ld = ctx.consts
+        _C.check(L.scorp_gs2d_regularizers_backward(W, H, _ptr(allmap), _ptr(viewmatrix), _ptr(rays_d), _ptr(rays_o), dr, ln, ld,
+                                                    _ptr(g_out), _ptr(g_allmap), _stream()), "scorp_gs2d_regularizers_backward")
+        return g_allmap, None, None, None, None, None, None
+
+
+def surfel_regularizer_losses(allmap, viewmatrix, rays_d, rays_o, depth_ratio, lambda_normal, lambda_dist):
+    """tensor[2] = (lambda_normal * mean(1 - render_normal . surf_normal), lambda_dist * mean(render_dist))."""
+    if not allmap.is_cuda:
+        raise RuntimeError("surfel_regularizer_losses needs CUDA/HIP tensors: scorp_amd has no CPU fallback")
+    return _SurfelRegularizers.apply(allmap, _prep(viewmatrix, "viewmatrix"), _prep(rays_d, "rays_d"), _prep(rays_o, "rays_o"),
+                                     depth_ratio, lambda_normal, lambda_dist)

@@ -278,3 +278,36 @@ def test_surfel_maps_match_torch_restatement(dev, hw, depth_ratio):
     (o2[4] * ws[4]).sum().backward()
     sel = torch.isfinite(am2.grad)
     assert (am.grad[sel] - am2.grad[sel]).abs().max() <= 2e-5 * am2.grad[sel].abs().max() + 1e-7
+
+
+@pytest.mark.parametrize("depth_ratio", [1.0, 0.0])
+def test_fused_surfel_regularizers_match_the_torch_formulation(dev, depth_ratio):
+    """fused_surfel_regularizers (one kernel each way, straight from allmap) == surfel_regularizers on the maps that
+    render() returns (train_2dgs.py:142-150): loss values and the gradients that reach every Gaussian parameter."""
+    from scorp_amd.renderer2d import GaussianModel2D, fused_surfel_regularizers, render, surfel_regularizers
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+
+    class Pipe:
+        convert_SHs_python = False
+        compute_cov3D_python = False
+        debug = False
+        fused_activations = True
+    Pipe.depth_ratio = depth_ratio
+    raw = make_gaussians(4000 + 3, 2, 17, log_scale_mean=math.log(0.05), scale_dims=2)
+    cam = ring_cameras(3, 141, 97, 5, device=dev)[1]
+    bg = torch.tensor([0.0, 0.0, 0.0], device=dev)
+    res = []
+    for fused in (False, True):
+        pc = GaussianModel2D.from_raw(raw, 2, device=dev)
+        r = render(cam, pc, Pipe(), bg)
+        assert set(r) == {"render", "viewspace_points", "visibility_filter", "radii", "render_alpha", "render_normal",
+                          "render_dist", "render_depth", "surf_normal"}
+        nl, dl = (fused_surfel_regularizers if fused else surfel_regularizers)(r, 0.05, 100.0)
+        (2.0 * nl + 0.5 * dl).backward()
+        res.append((float(nl.detach()), float(dl.detach()), pc))
+    (nl0, dl0, p0), (nl1, dl1, p1) = res
+    assert abs(nl0 - nl1) <= 1e-6 * max(1.0, abs(nl0)) and abs(dl0 - dl1) <= 1e-6 * max(1.0, abs(dl0))
+    for name in ("_xyz", "_opacity", "_scaling", "_rotation"):
+        a, b = getattr(p0, name).grad, getattr(p1, name).grad
+        assert torch.isfinite(b).all()
+        assert (a - b).abs().max() <= 2e-4 * a.abs().max() + 1e-12, name
