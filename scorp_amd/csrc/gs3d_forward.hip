@@ -27,8 +27,17 @@ scan_tiles_kernel(const uint32_t *__restrict__ tile_count, uint32_t *__restrict_
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int per = (tiles + 1023) / 1024;
   const int lo = min(tiles, t * per), hi = min(tiles, lo + per);
+  // the thread's counts stay in registers between the two passes when they fit (per <= 8: up to 8192 tiles)
+  uint32_t cnt[8];
   uint32_t sum = 0;
-  for (int k = lo; k < hi; k++) sum += tile_count[k];
+  if (per <= 8) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) cnt[j] = lo + j < hi ? tile_count[lo + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) sum += cnt[j];
+  } else {
+    for (int k = lo; k < hi; k++) sum += tile_count[k];
+  }
   // inclusive scan over the 1024 partials: shuffles inside each wave, the 16 wave totals through LDS (two barriers
   // instead of the twenty of a Hillis-Steele over LDS)
   uint32_t incl = sum;
@@ -52,9 +61,17 @@ scan_tiles_kernel(const uint32_t *__restrict__ tile_count, uint32_t *__restrict_
   incl += wave > 0 ? s_wave[wave - 1] : 0u;
   const uint32_t total = s_wave[15];
   uint32_t run = incl - sum;
-  for (int k = lo; k < hi; k++) {
-    tile_start[k] = run;
-    run += tile_count[k];
+  if (per <= 8) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (lo + j < hi) tile_start[lo + j] = run;
+      run += cnt[j];
+    }
+  } else {
+    for (int k = lo; k < hi; k++) {
+      tile_start[k] = run;
+      run += tile_count[k];
+    }
   }
   if (t == 1023) {
     tile_start[tiles] = total;

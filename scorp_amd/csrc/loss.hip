@@ -153,14 +153,22 @@ ssim_l1_forward_kernel(const float *__restrict__ img, const float *__restrict__ 
   }
 }
 
-__global__ void __launch_bounds__(256)
+// 1024 threads, float2 loads four at a time in flight, then a fixed-order tree in double: a launch-latency-sized kernel
+__global__ void __launch_bounds__(1024)
 loss_finalize_kernel(const float *__restrict__ partials, int nblocks, double n_elems, float lambda, float *__restrict__ out) {
-  __shared__ double s_a[256], s_b[256];
+  __shared__ double s_a[1024], s_b[1024];
+  const float2 *p2 = reinterpret_cast<const float2 *>(partials);
   double a = 0, b = 0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  for (int i0 = threadIdx.x; i0 < nblocks; i0 += 4 * 1024) {
+    float2 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int i = i0 + 1024 * j; v[j] = i < nblocks ? p2[i] : make_float2(0.0f, 0.0f); }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { a += v[j].x; b += v[j].y; }
+  }
   s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
   __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
+  for (int off = 512; off >= 1; off >>= 1) {
     if ((int)threadIdx.x < off) { s_a[threadIdx.x] += s_a[threadIdx.x + off]; s_b[threadIdx.x] += s_b[threadIdx.x + off]; }
     __syncthreads();
   }
@@ -290,7 +298,7 @@ extern "C" int scorp_loss_l1_ssim_forward(const float *img, const float *gt, con
     ssim_l1_forward_kernel<<<grid, 256, 0, stream>>>(img, gt, mask, C, H, W, win, need_backward ? dmaps : nullptr, partials);
   }
   SCORP_KERNEL_CHECK("ssim_l1_forward", 0, stream);
-  loss_finalize_kernel<<<1, 256, 0, stream>>>(partials, loss_blocks(C, H, W), (double)C * H * W, lambda_dssim, out_loss3);
+  loss_finalize_kernel<<<1, 1024, 0, stream>>>(partials, loss_blocks(C, H, W), (double)C * H * W, lambda_dssim, out_loss3);
   SCORP_KERNEL_CHECK("loss_finalize", 0, stream);
   return SCORP_OK;
 }
