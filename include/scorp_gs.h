@@ -163,6 +163,14 @@ int scorp_gs2d_debug_tiles(const void *state, const void *pairs, uint64_t capaci
                            int32_t image_width, int32_t image_height, uint32_t *tile_start, uint32_t *point_list,
                            scorp_stream_t stream);
 
+/* ---- what render() does to the rasterizer's outputs (gs3dgs/gaussian_renderer/__init__.py:113-120), one launch:
+ * out_depth[HW] = nan_to_num(depth / alpha, nan=0, posinf=0); out_visible[N] (bytes, 0/1) = radii > 0.
+ * The backward gives dL/ddepth, dL/dalpha for an upstream gradient on out_depth (zeros where alpha = 0). */
+int scorp_gs3d_render_tail(const float *depth, const float *alpha, int64_t num_pixels, const int32_t *radii,
+                           int32_t num_gaussians, float *out_depth, uint8_t *out_visible, scorp_stream_t stream);
+int scorp_gs3d_render_tail_backward(const float *g_out_depth, const float *depth, const float *alpha, int64_t num_pixels,
+                                    float *g_depth, float *g_alpha, scorp_stream_t stream);
+
 /* ---- per-pixel tail of the 2DGS render(): gs2dgs/gaussian_renderer/__init__.py:131-160 over
  * gs2dgs/utils/point_utils.py:9-40 (depths_to_points, depth_to_normal) ----
  * allmap[7,H,W] -> render_alpha[1,H,W], render_normal[3,H,W] (rotated to world space by viewmatrix[:3,:3]),

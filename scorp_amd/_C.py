@@ -40,7 +40,7 @@ EXPORTS = [
     "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
-    "scorp_knn_dist2", "scorp_adam_step",
+    "scorp_knn_dist2", "scorp_adam_step", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
     "scorp_gs2d_backward", "scorp_gs2d_debug_geom", "scorp_gs2d_debug_tiles", "scorp_gs2d_maps_forward",
     "scorp_gs2d_maps_backward", "scorp_gs2d_regularizers_workspace_bytes", "scorp_gs2d_regularizers_forward",
@@ -84,6 +84,8 @@ def lib():
     L.scorp_loss_workspace_bytes.argtypes = [i32, i32, i32]
     L.scorp_loss_l1_ssim_forward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, sz, i32, vp]
     L.scorp_loss_l1_ssim_backward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, vp, vp]
+    L.scorp_gs3d_render_tail.argtypes = [vp, vp, ctypes.c_int64, vp, i32, vp, vp, vp]
+    L.scorp_gs3d_render_tail_backward.argtypes = [vp, vp, vp, ctypes.c_int64, vp, vp, vp]
     L.scorp_gs2d_state_bytes.restype = sz
     L.scorp_gs2d_state_bytes.argtypes = [i32, i32, i32]
     L.scorp_gs2d_backward_scratch_bytes.restype = sz

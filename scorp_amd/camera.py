@@ -67,8 +67,8 @@ class Camera:
         self._update()
 
     def _update(self):
-        self.world_view_transform = torch.tensor(getWorld2View2(self.R, self.T, self.trans, self.scale)).transpose(0, 1).to(self.device)
-        self.projection_matrix = getProjectionMatrix(self.znear, self.zfar, self.FoVx, self.FoVy).transpose(0, 1).to(self.device)
+        self.world_view_transform = torch.tensor(getWorld2View2(self.R, self.T, self.trans, self.scale)).transpose(0, 1).contiguous().to(self.device)   # contiguous: the rasterizer takes it without a per-view copy kernel
+        self.projection_matrix = getProjectionMatrix(self.znear, self.zfar, self.FoVx, self.FoVy).transpose(0, 1).contiguous().to(self.device)
         self.full_proj_transform = self.world_view_transform.unsqueeze(0).bmm(self.projection_matrix.unsqueeze(0)).squeeze(0)
         self.camera_center = self.world_view_transform.inverse()[3, :3].contiguous()
 

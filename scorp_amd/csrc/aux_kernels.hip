@@ -2,7 +2,10 @@
 //   scorp_knn_dist2 : replaces simple_knn._C.distCUDA2 (gs3dgs/scene/gaussian_model.py:22,177) — mean squared
 //                     distance of every point to its 3 nearest neighbours, used once to initialise the scales;
 //   scorp_adam_step : the per-iteration Adam update of all parameter groups in ONE launch (replaces the six-group
-//                     torch.optim.Adam(eps=1e-15) step of gaussian_model.py:197-206 / train_3dgs.py:191-193).
+//                     torch.optim.Adam(eps=1e-15) step of gaussian_model.py:197-206 / train_3dgs.py:191-193);
+//   scorp_gs3d_render_tail : what render() does to the rasterizer's outputs (gaussian_renderer/__init__.py:113-120:
+//                     render_depth = nan_to_num(depth / alpha, 0, 0), visibility_filter = radii > 0) in one launch —
+//                     three 5-microsecond torch kernels per view otherwise.
 #include "common.hpp"
 
 namespace scorp {
@@ -148,5 +151,61 @@ extern "C" int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t n, double
                                             (float)bc1, (float)(1.0 / sqrt(bc2)));
   }
   SCORP_KERNEL_CHECK("adam", 0, stream);
+  return SCORP_OK;
+}
+
+namespace scorp {
+namespace {
+__device__ __forceinline__ float nan_to_num00(float x) {   // torch.nan_to_num(x, 0, 0)
+  if (x != x) return 0.0f;
+  if (x == __builtin_inff()) return 0.0f;
+  if (x == -__builtin_inff()) return -3.402823466e+38f;
+  return x;
+}
+__global__ void __launch_bounds__(256)
+render_tail_kernel(const float *__restrict__ depth, const float *__restrict__ alpha, size_t HW, const int32_t *__restrict__ radii,
+                   int N, float *__restrict__ out_depth, uint8_t *__restrict__ out_visible) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < HW) out_depth[i] = nan_to_num00(depth[i] / alpha[i]);
+  if (i < (size_t)N) out_visible[i] = radii[i] > 0 ? 1 : 0;
+}
+__global__ void __launch_bounds__(256)
+render_tail_backward_kernel(const float *__restrict__ g_out, const float *__restrict__ depth, const float *__restrict__ alpha,
+                            size_t HW, float *__restrict__ g_depth, float *__restrict__ g_alpha) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  const float d = depth[i], a = alpha[i], q = d / a;
+  // nan_to_num passes the gradient only where its input was finite; PyTorch then still forms 0 / 0 = NaN at the
+  // empty pixels (alpha = 0), which the rasterizer never reads: plain zeros here
+  const bool pass = a != 0.0f && q == q && fabsf(q) != __builtin_inff();
+  const float g = pass ? g_out[i] : 0.0f;
+  g_depth[i] = pass ? g / a : 0.0f;
+  g_alpha[i] = pass ? -g * d / (a * a) : 0.0f;
+}
+}  // namespace
+}  // namespace scorp
+
+extern "C" int scorp_gs3d_render_tail(const float *depth, const float *alpha, int64_t HW, const int32_t *radii, int32_t N,
+                                      float *out_depth, uint8_t *out_visible, scorp_stream_t stream_) {
+  if (HW < 0 || N < 0 || (HW > 0 && (!depth || !alpha || !out_depth)) || (N > 0 && (!radii || !out_visible))) {
+    set_error("bad argument to scorp_gs3d_render_tail"); return SCORP_ERR_INVALID;
+  }
+  const size_t n = (size_t)HW > (size_t)N ? (size_t)HW : (size_t)N;
+  if (n == 0) return SCORP_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  render_tail_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(depth, alpha, (size_t)HW, radii, N, out_depth, out_visible);
+  SCORP_KERNEL_CHECK("render_tail", 0, stream);
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs3d_render_tail_backward(const float *g_out, const float *depth, const float *alpha, int64_t HW,
+                                               float *g_depth, float *g_alpha, scorp_stream_t stream_) {
+  if (HW < 0 || (HW > 0 && (!g_out || !depth || !alpha || !g_depth || !g_alpha))) {
+    set_error("bad argument to scorp_gs3d_render_tail_backward"); return SCORP_ERR_INVALID;
+  }
+  if (HW == 0) return SCORP_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  render_tail_backward_kernel<<<(unsigned)(((size_t)HW + 255) / 256), 256, 0, stream>>>(g_out, depth, alpha, (size_t)HW, g_depth, g_alpha);
+  SCORP_KERNEL_CHECK("render_tail_backward", 0, stream);
   return SCORP_OK;
 }

@@ -283,3 +283,37 @@ class GaussianRasterizer(nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings)
+
+
+class _RenderTail(torch.autograd.Function):
+    """(render_depth, visibility_filter) from (depth, alpha, radii) in one launch: gaussian_renderer/__init__.py:113-120."""
+
+    @staticmethod
+    def forward(ctx, depth, alpha, radii):
+        L = _C.lib()
+        depth, alpha = _prep(depth, "depth"), _prep(alpha, "alpha")
+        radii = radii.contiguous()
+        out = torch.empty_like(depth)
+        vis = torch.empty(radii.shape, dtype=torch.bool, device=radii.device)
+        _C.check(L.scorp_gs3d_render_tail(_ptr(depth), _ptr(alpha), depth.numel(), _ptr(radii), radii.numel(), _ptr(out),
+                                          _ptr(vis), _stream()), "scorp_gs3d_render_tail")
+        ctx.save_for_backward(depth, alpha)
+        ctx.mark_non_differentiable(vis)
+        return out, vis
+
+    @staticmethod
+    def backward(ctx, g_out, _g_vis):
+        L = _C.lib()
+        depth, alpha = ctx.saved_tensors
+        g_out = _prep(g_out, "grad")
+        g_depth, g_alpha = torch.empty_like(depth), torch.empty_like(alpha)
+        _C.check(L.scorp_gs3d_render_tail_backward(_ptr(g_out), _ptr(depth), _ptr(alpha), depth.numel(), _ptr(g_depth),
+                                                   _ptr(g_alpha), _stream()), "scorp_gs3d_render_tail_backward")
+        return g_depth, g_alpha, None
+
+
+def render_tail(depth, alpha, radii):
+    """render_depth = nan_to_num(depth / alpha, 0, 0) and visibility_filter = radii > 0, fused."""
+    if radii.dtype != torch.int32 or not depth.is_cuda:
+        return torch.nan_to_num(depth / alpha, 0, 0), radii > 0
+    return _RenderTail.apply(depth, alpha, radii)

@@ -8,7 +8,7 @@ import math
 
 import torch
 
-from .rasterizer3d import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
+from .rasterizer3d import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw, render_tail
 from .sh import eval_sh
 
 
@@ -35,8 +35,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw = pc.raw_leaves()
         rendered_image, radii, rendered_depth, rendered_alpha = rasterize_gaussians_raw(
             xyz, screenspace_points, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings)
-        rendered_depth = torch.nan_to_num(rendered_depth / rendered_alpha, 0, 0)
-        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+        rendered_depth, visible = render_tail(rendered_depth, rendered_alpha, radii)   # D / A with NaN -> 0, radii > 0
+        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": visible,
                 "radii": radii, "render_depth": rendered_depth, "render_alpha": rendered_alpha}
 
     means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
@@ -62,11 +62,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     rendered_image, radii, rendered_depth, rendered_alpha = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-    rendered_depth = torch.nan_to_num(rendered_depth / rendered_alpha, 0, 0)
+    rendered_depth, visible = render_tail(rendered_depth, rendered_alpha, radii)
     return {
         "render": rendered_image,
         "viewspace_points": screenspace_points,
-        "visibility_filter": radii > 0,
+        "visibility_filter": visible,
         "radii": radii,
         "render_depth": rendered_depth,
         "render_alpha": rendered_alpha,

@@ -184,3 +184,29 @@ def test_rotation_sweep_recovers_the_planted_rotation(dev):
     assert (fit - fit_e).abs().max() < 1e-6
     # the model itself is untouched by the sweep
     assert torch.equal(tgt_model._features_dc, m._features_dc)
+
+
+def test_render_tail_matches_torch(dev):
+    """scorp_gs3d_render_tail (render_depth = nan_to_num(depth / alpha, 0, 0), visibility = radii > 0) and its backward
+    against the torch ops of gs3dgs/gaussian_renderer/__init__.py:113-120, including empty pixels (0 / 0)."""
+    from scorp_amd.rasterizer3d import render_tail
+    g = torch.Generator(device=dev).manual_seed(3)
+    H, W, N = 37, 61, 1000
+    alpha = torch.rand(1, H, W, device=dev, generator=g)
+    depth = (2.0 + torch.rand(1, H, W, device=dev, generator=g)) * alpha
+    empty = torch.rand(1, H, W, device=dev, generator=g) < 0.2
+    alpha[empty] = 0.0
+    depth[empty] = 0.0
+    radii = torch.randint(0, 5, (N,), device=dev, dtype=torch.int32, generator=g)
+    w = torch.randn(1, H, W, device=dev, generator=g)
+    d0, a0 = depth.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    ref = torch.nan_to_num(d0 / a0, 0, 0)
+    (ref * w).sum().backward()
+    d1, a1 = depth.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    out, vis = render_tail(d1, a1, radii)
+    (out * w).sum().backward()
+    assert torch.equal(vis, radii > 0) and vis.dtype == torch.bool
+    assert torch.equal(out, ref)
+    ok = ~empty
+    assert torch.allclose(d1.grad[ok], d0.grad[ok], rtol=1e-6, atol=0) and torch.allclose(a1.grad[ok], a0.grad[ok], rtol=1e-6, atol=0)
+    assert bool((d1.grad[empty] == 0).all()) and bool((a1.grad[empty] == 0).all())   # torch leaves NaN there
