@@ -12,12 +12,27 @@ from .rasterizer3d import GaussianRasterizationSettings, GaussianRasterizer, ras
 from .sh import eval_sh
 
 
+_ZEROS = {}
+
+
+def _grad_sink(xyz):
+    """A fresh leaf of zeros shaped like xyz (the screen-space gradient sink) over a cached, never-written storage."""
+    key = (xyz.shape[0], xyz.dtype, xyz.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        if len(_ZEROS) > 8:
+            _ZEROS.clear()
+        z = _ZEROS[key] = torch.zeros_like(xyz, requires_grad=False)
+    return z.detach().requires_grad_(True)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
     xyz = pc.get_xyz
     # gradient sink for the screen-space means; the reference builds it as `zeros_like(...) + 0` with retain_grad()
     # (gaussian_renderer/__init__.py:39-43) — a leaf with requires_grad gives the caller the same `.grad` without the
-    # extra 12 MB add kernel per view
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
+    # extra 12 MB add kernel per view; the zeros themselves are shared between views (nothing ever writes them), so
+    # not even a fill kernel runs: every view gets a fresh leaf over the same storage
+    screenspace_points = _grad_sink(xyz)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     w, h = viewpoint_camera.resolution
