@@ -106,9 +106,9 @@ __device__ __forceinline__ void for_each_tile(int x0, int y0, int x1, int y1, ui
 
 // Forward state layout (one caller-owned blob, 256-byte aligned sub-buffers).
 constexpr int kMaxLdsTiles = 16384;   // per-block tile histograms live in LDS up to this many tiles (64 KiB)
-constexpr int kBinBlocksMax = 512;    // blocks of the LDS-histogram binning (each owns a contiguous Gaussian range)
+constexpr int kBinBlocksMax = 256;    // blocks of the LDS-histogram binning (each owns a contiguous Gaussian range)
 
-inline int bin_blocks(int N) { int b = (N + 1023) / 1024; return b < 1 ? 1 : (b > kBinBlocksMax ? kBinBlocksMax : b); }
+inline int bin_blocks(int N) { int b = (N + 4095) / 4096; return b < 1 ? 1 : (b > kBinBlocksMax ? kBinBlocksMax : b); }
 
 struct StateLayout {
   size_t header, rec, bin, tile_mask, tile_count, tile_start, final_T, n_contrib, block_hist, total;
