@@ -80,6 +80,21 @@ class OptimizationParams:
     densify_until_iter = 25_000
     densify_grad_threshold = 0.0002
     random_background = True
+    # depth / regularisation terms (gs3dgs/arguments/__init__.py:91-99)
+    lambda_depth_sensor = 1.5
+    lambda_isotropic = 0.0005
+    depth_from_iter = 7000
+    dn_l1_weight_init = 0.25
+    dn_l1_weight_final = 0.075
+
+
+class OptimizationParams2D(OptimizationParams):
+    """Where gs2dgs/arguments/__init__.py:94-107 differs: the surfel regularisers and the depth-term weights."""
+    lambda_dist = 0.0
+    lambda_normal = 0.05
+    lambda_isotropic = 0.0001
+    dn_l1_weight_init = 0.2
+    dn_l1_weight_final = 0.05
 
 
 class GaussianModel:

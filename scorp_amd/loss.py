@@ -63,3 +63,32 @@ def psnr(img1, img2):
 def photometric_loss(image, gt, lambda_dssim=0.2):
     """(1-lambda) L1 + lambda (1-SSIM), train_3dgs.py:106-107."""
     return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+
+
+def isotropic_loss(scaling):
+    """Mean |s - mean_axis(s)| over all Gaussians and axes (gs3dgs/utils/loss_utils.py:75-85)."""
+    return torch.abs(scaling - scaling.mean(dim=1, keepdim=True)).mean()
+
+
+def depth_normalize_(depth):
+    """Min-max normalisation with detached extrema (gs3dgs/utils/image_utils.py:87-91)."""
+    min_val, max_val = torch.min(depth).detach(), torch.max(depth).detach()
+    return (depth - min_val) / (max_val - min_val)
+
+
+def depth_losses(rend_depth, iteration, opt, gt_depth=None, gt_depth_est=None):
+    """The depth terms of train_3dgs.py:109-133 / train_2dgs.py:95-133 (active after opt.depth_from_iter): L1 against a
+    sensor depth inside (0.3, 7) where something was rendered, and L1 between min-max-normalised rendered and estimated
+    (monocular) depth with the exponentially decaying weight 10 * dn_l1_weight(iteration)."""
+    from .gaussian_model import get_expon_lr_func
+    loss = torch.zeros((), device=rend_depth.device)
+    if iteration <= opt.depth_from_iter:
+        return loss
+    if gt_depth is not None:
+        mask = (gt_depth > 0.3) & (gt_depth < 7) & (rend_depth > 0.0)
+        loss = loss + opt.lambda_depth_sensor * l1_loss(rend_depth[mask], gt_depth[mask])
+    if gt_depth_est is not None:
+        w = get_expon_lr_func(opt.dn_l1_weight_init, opt.dn_l1_weight_final, max_steps=opt.iterations)(iteration)
+        mask = (rend_depth > 0.0) & (gt_depth_est > 0.0)
+        loss = loss + 10 * w * l1_loss(depth_normalize_(rend_depth[mask]), depth_normalize_(gt_depth_est[mask]))
+    return loss

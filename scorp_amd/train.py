@@ -1,7 +1,10 @@
 """The build's counterparts of the reference's optimisation loops, on synthetic or caller-supplied views:
 
   training_iteration(...)  one iteration of train_3dgs.py:56-193 (LR schedule, SH-degree schedule, random background,
-                           render, 0.8*L1 + 0.2*(1-SSIM), backward, densification bookkeeping, Adam step)
+                           render, 0.8*L1 + 0.2*(1-SSIM), the depth terms and the isotropic regulariser after
+                           depth_from_iter, backward, densification bookkeeping, Adam step); `surfels=True` with
+                           render_fn=scorp_amd.renderer2d.render is train_2dgs.py's iteration (normal-consistency
+                           and distortion regularisers on their 7000 / 3000 iteration schedule)
   post_refine(...)         the 800-iteration appearance refinement of post_refine_gs.py:30-203: everything frozen
                            but the colours, masked L1 + SSIM
 
@@ -19,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from .fused_loss import fused_l1_ssim_loss
-from .loss import psnr
+from .loss import depth_losses, isotropic_loss, psnr
 from .parallel import average_gradients, world
 from .renderer import render
 
@@ -43,7 +46,8 @@ def _sync_densification_stats(gaussians):
 
 
 def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteration, scene_extent=4.0, densify=True,
-                       render_fn=render, loss_fn=fused_l1_ssim_loss, data_parallel=False):
+                       render_fn=render, loss_fn=fused_l1_ssim_loss, data_parallel=False, gt_depth=None, gt_depth_est=None,
+                       surfels=False):
     """Returns (loss tensor, render package). Mirrors train_3dgs.py:74-193 for one camera.  With `data_parallel` the
     caller hands each rank a different camera; gradients are averaged over ranks before the optimizer step and the
     densification statistics are reduced before they are used, so the replicas stay bit-identical."""
@@ -53,6 +57,20 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
     bg = torch.rand(3, device=background.device) if opt.random_background else background
     pkg = render_fn(cam, gaussians, pipe, bg)
     loss = loss_fn(pkg["render"], gt_image, opt.lambda_dssim)
+    # depth terms and the isotropic regulariser start together (train_3dgs.py:109-150, train_2dgs.py:95-140)
+    if iteration > getattr(opt, "depth_from_iter", 1 << 30):
+        if gt_depth is not None or gt_depth_est is not None:
+            loss = loss + depth_losses(pkg["render_depth"], iteration, opt, gt_depth, gt_depth_est)
+        if getattr(opt, "lambda_isotropic", 0.0) > 0:
+            loss = loss + opt.lambda_isotropic * isotropic_loss(gaussians.get_scaling)
+    if surfels:   # train_2dgs.py:142-150: normal consistency after 7000 iterations, depth distortion after 3000
+        from .renderer2d import fused_surfel_regularizers, surfel_regularizers
+        lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
+        lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
+        if lambda_normal > 0 or lambda_dist > 0:
+            reg = fused_surfel_regularizers if getattr(pkg, "allmap", None) is not None else surfel_regularizers
+            normal_loss, dist_loss = reg(pkg, lambda_normal, lambda_dist)
+            loss = loss + normal_loss + dist_loss
     loss.backward()
     with torch.no_grad():
         if data_parallel:

@@ -66,3 +66,52 @@ def test_post_refine_only_moves_colours(dev):
     for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
         assert torch.equal(getattr(student, n).detach(), before[n]), n
     assert not torch.equal(student._features_dc.detach(), before["_features_dc"])
+
+
+def test_late_iteration_loss_terms_3d_and_2d(dev):
+    """After depth_from_iter the iteration adds the sensor-depth L1, the normalised monocular-depth L1 and the isotropic
+    regulariser (train_3dgs.py:109-150); a surfel iteration adds the normal / distortion regularisers on their
+    schedule (train_2dgs.py:142-150).  The loss returned equals the terms assembled by hand from the same render, and
+    an optimizer step runs."""
+    from scorp_amd.fused_loss import fused_l1_ssim_loss
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams, OptimizationParams2D, get_expon_lr_func
+    from scorp_amd.loss import depth_normalize_, isotropic_loss, l1_loss
+    from scorp_amd.renderer import render
+    from scorp_amd.renderer2d import GaussianModel2D, render as render2d, surfel_regularizers
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams, training_iteration
+    cam = ring_cameras(3, 96, 80, 4, radius=3.0, device=dev)[0]
+    g = torch.Generator(device=dev).manual_seed(1)
+    gt = torch.rand(3, 80, 96, device=dev, generator=g)
+    sensor = 2.0 + 2.0 * torch.rand(1, 80, 96, device=dev, generator=g)
+    mono = torch.rand(1, 80, 96, device=dev, generator=g)
+    bg = torch.zeros(3, device=dev)
+    it = 7500
+    for surfels in (False, True):
+        raw = make_gaussians(3000, 1, 21, extent=1.0, log_scale_mean=math.log(0.05), scale_dims=2 if surfels else 3)
+        opt = OptimizationParams2D() if surfels else OptimizationParams()
+        opt.random_background = False
+        opt.lambda_dist = 100.0 if surfels else 0.0
+        Model, rfn = (GaussianModel2D, render2d) if surfels else (GaussianModel, render)
+        pipe = PipelineParams()
+        pipe.depth_ratio = 1.0
+        m = Model.from_raw(raw, 1, device=dev)
+        m.training_setup(opt)
+        with torch.no_grad():
+            pkg = rfn(cam, m, pipe, bg)
+            expect = fused_l1_ssim_loss(pkg["render"], gt, opt.lambda_dssim)
+            rd = pkg["render_depth"]
+            mask = (sensor > 0.3) & (sensor < 7) & (rd > 0)
+            expect = expect + opt.lambda_depth_sensor * l1_loss(rd[mask], sensor[mask])
+            w = get_expon_lr_func(opt.dn_l1_weight_init, opt.dn_l1_weight_final, max_steps=opt.iterations)(it)
+            mask = (rd > 0) & (mono > 0)
+            expect = expect + 10 * w * l1_loss(depth_normalize_(rd[mask]), depth_normalize_(mono[mask]))
+            expect = expect + opt.lambda_isotropic * isotropic_loss(m.get_scaling)
+            if surfels:
+                nl, dl = surfel_regularizers(pkg, opt.lambda_normal, opt.lambda_dist)
+                expect = expect + nl + dl
+        before = m._xyz.detach().clone()
+        loss, _ = training_iteration(m, cam, gt, opt, pipe, bg, it, densify=False, render_fn=rfn, gt_depth=sensor,
+                                     gt_depth_est=mono, surfels=surfels)
+        assert abs(float(loss.detach()) - float(expect)) <= 1e-5 * max(1.0, abs(float(expect))), (surfels, float(loss.detach()), float(expect))
+        assert torch.isfinite(m._xyz).all() and not torch.equal(m._xyz.detach(), before)
