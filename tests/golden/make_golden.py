@@ -2,7 +2,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
     PYTHONPATH=/root/reference python tests/golden/make_golden.py
-Only inputs and outputs are stored (SURVEY.md §8c, G1–G5/G7); no reference source text is copied.
+Only inputs and outputs are stored (SURVEY.md §8c, G1–G8); no reference source text is copied.
 The renderer itself cannot be captured: `diff_gaussian_rasterization` is absent from the reference tree.
 """
 import os
@@ -14,10 +14,11 @@ import torch
 sys.path.insert(0, "/root/reference")
 from gs3dgs.utils.sh_utils import eval_sh, RGB2SH, SH2RGB  # noqa: E402
 from gs3dgs.utils.graphics_utils import getProjectionMatrix, getWorld2View2, fov2focal, focal2fov  # noqa: E402
-from gs3dgs.utils.loss_utils import l1_loss, ssim  # noqa: E402
-from gs3dgs.utils.image_utils import psnr  # noqa: E402
+from gs3dgs.utils.loss_utils import l1_loss, ssim, isotropic_loss  # noqa: E402
+from gs3dgs.utils.image_utils import psnr, depth_normalize_  # noqa: E402
 from gs3dgs.utils.general_utils import get_expon_lr_func, inverse_sigmoid  # noqa: E402
 from utils.geometry import quaternion_to_matrix_tensor  # noqa: E402
+from utils.solution import kabsch_algorithm_np, umeyama_algorithm_np  # noqa: E402
 
 out = {}
 rng = np.random.default_rng(20260630)
@@ -69,6 +70,29 @@ out["g4_inv_sigmoid"] = inverse_sigmoid(torch.tensor([0.1, 0.5, 0.9])).numpy()
 q = rng.normal(0, 1, (32, 4)).astype(np.float32)
 out["g5_q"] = q
 out["g5_R"] = quaternion_to_matrix_tensor(torch.tensor(q)).numpy()
+
+# G6: Kabsch / Umeyama fits of seeded 50-point sets (a planted similarity + noise; one pair with a reflection-prone SVD)
+src = rng.normal(0, 1, (4, 50, 3))
+tgt = np.empty_like(src)
+for i in range(4):
+    A = rng.normal(0, 1, (3, 3))
+    U, _, Vt = np.linalg.svd(A)
+    R0 = U @ Vt
+    if np.linalg.det(R0) < 0:
+        R0[:, 0] *= -1
+    tgt[i] = (0.5 + i) * (src[i] @ R0.T) + rng.normal(0, 1, 3) + rng.normal(0, 0.02 * (1 + 20 * (i == 3)), (50, 3))
+out["g6_src"], out["g6_tgt"] = src, tgt
+ks = [kabsch_algorithm_np(src[i], tgt[i]) for i in range(4)]
+us = [umeyama_algorithm_np(src[i], tgt[i]) for i in range(4)]
+out["g6_kabsch_R"], out["g6_kabsch_t"] = np.stack([k[0] for k in ks]), np.stack([k[1] for k in ks])
+out["g6_umeyama_R"], out["g6_umeyama_t"] = np.stack([u[0] for u in us]), np.stack([u[1] for u in us])
+out["g6_umeyama_s"] = np.array([u[2] for u in us])
+
+# G8: the regularisation helpers of the late training iterations
+sc = np.exp(rng.normal(-4, 0.5, (200, 3))).astype(np.float32)
+out["g8_scaling"], out["g8_isotropic"] = sc, isotropic_loss(torch.tensor(sc)).item()
+dm = rng.uniform(0.5, 6.0, (300,)).astype(np.float32)
+out["g8_depth"], out["g8_depth_normalized"] = dm, depth_normalize_(torch.tensor(dm)).numpy()
 
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_helpers.npz")
 np.savez_compressed(dst, **out)

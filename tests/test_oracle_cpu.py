@@ -251,3 +251,30 @@ def test_ply_round_trip_and_reference_layout(tmp_path):
     assert mm.load_multi_ply([pa, pb]) == [10, 7]
     assert mm.get_xyz.shape == (17, 3) and mm._features_rest.shape == (17, 0, 3)
     assert torch.equal(mm._xyz[10:].detach(), b._xyz.detach())
+
+
+def test_point_set_fits_match_reference(golden):
+    """G6: scorp_amd.solve.kabsch / umeyama against utils/solution.py's numpy solvers on seeded 50-point sets, single
+    and batched; the fit actually maps source onto target."""
+    from scorp_amd.solve import kabsch, umeyama
+    src, tgt = torch.tensor(golden["g6_src"]), torch.tensor(golden["g6_tgt"])
+    R, t, s = umeyama(src, tgt)                                    # batched over the four pairs
+    np.testing.assert_allclose(R.numpy(), golden["g6_umeyama_R"], atol=1e-12)
+    np.testing.assert_allclose(t.numpy(), golden["g6_umeyama_t"], atol=1e-12)
+    np.testing.assert_allclose(s.numpy(), golden["g6_umeyama_s"], atol=1e-12)
+    for i in range(4):
+        Rk, tk, sk = kabsch(src[i], tgt[i])
+        np.testing.assert_allclose(Rk.numpy(), golden["g6_kabsch_R"][i], atol=1e-12)
+        np.testing.assert_allclose(tk.numpy(), golden["g6_kabsch_t"][i], atol=1e-12)
+        assert float(sk) == 1.0 and abs(float(torch.linalg.det(Rk)) - 1.0) < 1e-12
+    res = (s[:3, None, None] * (src[:3] @ R[:3].transpose(1, 2)) + t[:3, None, :] - tgt[:3]).abs().max()
+    assert float(res) < 0.1                                        # planted similarity + 0.02 noise
+    with pytest.raises(ValueError):
+        kabsch(src[0][:0], tgt[0][:0])
+
+
+def test_late_iteration_regularisers_match_reference(golden):
+    """G8: isotropic_loss (loss_utils.py:75-85) and depth_normalize_ (image_utils.py:87-91)."""
+    from scorp_amd.loss import depth_normalize_, isotropic_loss
+    assert abs(float(isotropic_loss(torch.tensor(golden["g8_scaling"]))) - float(golden["g8_isotropic"])) < 1e-9
+    np.testing.assert_allclose(depth_normalize_(torch.tensor(golden["g8_depth"])).numpy(), golden["g8_depth_normalized"], atol=1e-7)
