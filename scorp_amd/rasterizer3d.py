@@ -314,6 +314,6 @@ class _RenderTail(torch.autograd.Function):
 
 def render_tail(depth, alpha, radii):
     """render_depth = nan_to_num(depth / alpha, 0, 0) and visibility_filter = radii > 0, fused."""
-    if radii.dtype != torch.int32 or not depth.is_cuda:
-        return torch.nan_to_num(depth / alpha, 0, 0), radii > 0
-    return _RenderTail.apply(depth, alpha, radii)
+    if not depth.is_cuda:
+        raise RuntimeError("render_tail needs GPU tensors (scorp_amd has no CPU path)")
+    return _RenderTail.apply(depth, alpha, radii.int())
