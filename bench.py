@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 and collectives go through CPU copies (use with --backend gloo)")
     ap.add_argument("--unfused", action="store_true", help="reference call-site convention: torch activations + cat per view")
-    ap.add_argument("--spatial-sort", action="store_true", help="experiment: store the Gaussians along a Z-order curve first")
+    ap.add_argument("--spatial-sort", action="store_true", help="GaussianModel.sort_spatially() first: Gaussians stored along a Z-order curve (not the default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,14 +157,6 @@ def main():
     K = (deg + 1) ** 2
     # rank 0 draws the scene; the others receive it over RCCL (the one collective of this workload, outside the timed region)
     raw = make_gaussians(N, deg, seed, scale_dims=2 if surfels else 3) if rank == 0 else None
-    if raw is not None and args.spatial_sort:
-        q = np.clip(((raw["xyz"] + 1.5) / 3.0 * 1023).astype(np.int64), 0, 1023)
-        def spread(v):
-            v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F
-            v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249
-            return v
-        order = np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind="stable")
-        raw = {k: v[order] for k, v in raw.items()}
     if world > 1:
         shapes = dict(xyz=(N, 3), scaling=(N, 2 if surfels else 3), rotation=(N, 4), opacity=(N, 1), features_dc=(N, 1, 3), features_rest=(N, K - 1, 3))
         recv = {}
@@ -179,6 +171,8 @@ def main():
     else:
         model = GaussianModel.from_raw(raw, deg, device=dev)
     model.active_sh_degree = deg
+    if args.spatial_sort:
+        model.sort_spatially()
     params = [model._xyz, model._features_dc, model._features_rest, model._scaling, model._rotation, model._opacity]
 
     all_cams = ring_cameras(ncam_total, W, H, seed, device=dev)

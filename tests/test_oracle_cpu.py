@@ -278,3 +278,37 @@ def test_late_iteration_regularisers_match_reference(golden):
     from scorp_amd.loss import depth_normalize_, isotropic_loss
     assert abs(float(isotropic_loss(torch.tensor(golden["g8_scaling"]))) - float(golden["g8_isotropic"])) < 1e-9
     np.testing.assert_allclose(depth_normalize_(torch.tensor(golden["g8_depth"])).numpy(), golden["g8_depth_normalized"], atol=1e-7)
+
+
+def test_sort_spatially_is_a_consistent_permutation():
+    """GaussianModel.sort_spatially: parameters, Adam moments and densification statistics are permuted together, the
+    Morton codes come out sorted, and an optimizer step after the sort equals the permuted step without it."""
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.synthetic import make_gaussians
+    raw = make_gaussians(500, 1, 5)
+    ms = [GaussianModel.from_raw(raw, 1, device="cpu") for _ in range(2)]
+    g = torch.Generator().manual_seed(0)
+    grads = {a: torch.randn(getattr(ms[0], a).shape, generator=g) for a in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")}
+    for m in ms:
+        m.training_setup(OptimizationParams())
+        m.update_learning_rate(10)
+        for a, gr in grads.items():
+            getattr(m, a).grad = gr.clone()
+        m.optimizer.step()                                # creates the Adam moments
+        m.xyz_gradient_accum = torch.arange(500.0).reshape(500, 1)
+        m.max_radii2D = torch.arange(500.0)
+    order = ms[1].sort_spatially()
+    assert sorted(order.tolist()) == list(range(500))
+    for a in grads:
+        assert torch.equal(getattr(ms[1], a).detach(), getattr(ms[0], a).detach()[order])
+    assert torch.equal(ms[1].xyz_gradient_accum[:, 0], order.float()) and torch.equal(ms[1].max_radii2D, order.float())
+    for m, perm in ((ms[0], None), (ms[1], order)):       # a second step with (permuted) gradients
+        for a, gr in grads.items():
+            getattr(m, a).grad = (gr if perm is None else gr[perm]).clone()
+        m.optimizer.step()
+    for a in grads:
+        assert torch.allclose(getattr(ms[1], a).detach(), getattr(ms[0], a).detach()[order], rtol=0, atol=0)
+    # spatial coherence: neighbours in memory are close in space after the sort
+    d_sorted = (ms[1]._xyz.detach()[1:] - ms[1]._xyz.detach()[:-1]).norm(dim=1).mean()
+    d_orig = (ms[0]._xyz.detach()[1:] - ms[0]._xyz.detach()[:-1]).norm(dim=1).mean()
+    assert d_sorted < 0.5 * d_orig
