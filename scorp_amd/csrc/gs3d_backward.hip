@@ -4,7 +4,6 @@
 // train_3dgs.py:152; colour-only at post_refine_gs.py:53-56; w.r.t. colors_precomp at utils/mask.py:47-70).
 // Arithmetic follows oracle/gs3d_oracle.c::gs3d_oracle_backward.  The forward state and the pair buffer are
 // only read, so the backward can be replayed on one forward.
-#include <stdlib.h>
 
 #include <type_traits>
 
