@@ -20,7 +20,8 @@ namespace {
 // v_p = G * opacity * dL/dalpha, pixel coordinates relative to the tile centre) and  sum_p w_p * {dL/dr, dL/dg, dL/db,
 // dL/ddepth}_p  (w_p = alpha * T).  With a wave's 64 pixels as the K dimension that is D[16 splats][16] =
 // [V | W](16 x 128) * [basis_v ; basis_w](128 x 16): 32 exact-fp32 v_mfma_f32_16x16x4_f32 per 16 splats instead of
-// 60 cross-lane shuffles per splat.
+// 60 cross-lane shuffles per splat.  (A lane supplies one column of the basis, so the V and the W product run as two
+// independent chains over ONE basis register array and the lane keeps the result that belongs to its column.)
 //
 // Per wave and 16-splat group:
 //   1a (straight-line, no dependence between splats): alpha and G*opacity of the 16 splats at this lane's pixel;
@@ -30,9 +31,9 @@ namespace {
 //      collapse into ONE, because only their dot product with this pixel's upstream gradient is ever used:
 //      s = c.dL/dcolor + z*dL/ddepth + dL/dalpha,  R <- last_alpha * s_last + (1 - last_alpha) * R,
 //      dL/dalpha_i = (s - R) * T - T_final / (1 - alpha) * (bg . dL/dcolor);
-//   lane (= pixel) writes v, w into a wave-private LDS matrix [slot][pixel] (row stride 65 floats: the row writes and
-//   the transposed A-operand reads are both conflict-free); the per-pixel basis is loop-invariant and lives in 32
-//   registers as the B operand;
+//   lane (= pixel) writes v, w into a wave-private LDS matrix [slot][pixel] (row stride 68 floats: conflict-free row
+//   writes, 16-byte-aligned rows for the transposed A-operand reads); the per-pixel basis is loop-invariant and lives
+//   in 16 registers as the B operand;
 //   the 16x16 MFMA result holds block-frame moments, which sixteen lanes turn into the ten screen-space gradients;
 //   they are flushed with float atomics shaped as whole 40-byte row segments (lanes = consecutive floats).
 // ---------------------------------------------------------------------------------------------------------
@@ -46,7 +47,8 @@ constexpr float kLog2e = 1.4426950408889634f;
 // ---------------------------------------------------------------------------------------------------------
 // B1w: the replay with ONE WAVE PER 8x8 PIXEL BLOCK as the unit of work (64-thread workgroups, no workgroup
 // barriers, no waiting for the slowest wave of a tile).  A wave walks its tile's sorted list back to front 32 entries
-// at a time: each lane gathers one record and runs the exact ellipse-vs-block test on it, the survivors are
+// at a time: each lane reads the forward's verdict of the exact ellipse-vs-block test for one entry and gathers the
+// record only if it passed (flags, list entries and records are fetched two chunks ahead), the survivors are
 // compacted (ballot + popcount) into a 64-entry ring in the wave's own LDS, and whenever 16 are queued they go
 // through the 1a / 1b / MFMA pipeline described above.  The 16x16 result is converted from block-frame moments
 // to the ten gradients by lanes 0..15 and added to the per-Gaussian accumulators with float atomics (zero terms are
