@@ -81,6 +81,10 @@ __device__ __forceinline__ float conic_min_over_box(float cx, float cy, float A,
   return best;
 }
 
+// A float in the constant address space: uniform loads through such a pointer go to the scalar cache (s_load) instead of
+// occupying VMEM slots.  Only for data no kernel of the same launch writes (camera matrices).
+typedef __attribute__((address_space(4))) float CFloat;
+
 // v + (v moved across lanes by the DPP control CTRL): the building block of the in-row reductions (gs2d.hip).
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {

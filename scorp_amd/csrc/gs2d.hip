@@ -87,7 +87,7 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
   if (lin) stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
   float vm[16], pm[16];
 #pragma unroll
-  for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
+  for (int q = 0; q < 16; q++) { vm[q] = ((const CFloat *)a.view)[q]; pm[q] = ((const CFloat *)a.proj)[q]; }   // scalar cache
   BinRec br;
   br.x0 = br.y0 = br.x1 = br.y1 = 0; br.depth_bits = 0; br.radius = 0;
   bool vis = false;
@@ -191,7 +191,7 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
         __syncthreads();
       }
       if (vis) {
-        const float dx = p[0] - a.campos[0], dy = p[1] - a.campos[1], dz = p[2] - a.campos[2];
+        const float dx = p[0] - ((const CFloat *)a.campos)[0], dy = p[1] - ((const CFloat *)a.campos)[1], dz = p[2] - ((const CFloat *)a.campos)[2];
         const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         sh_row_to_rgb<DEG>(sh_row(s_sh, threadIdx.x, lin), dx * inv, dy * inv, dz * inv, rgb);
 #pragma unroll
@@ -652,7 +652,7 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
   float shx = 0, shy = 0, shz = 0, shinv = 0, gr3[3] = {0, 0, 0};
   float vm[16], pm[16];
 #pragma unroll
-  for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
+  for (int q = 0; q < 16; q++) { vm[q] = ((const CFloat *)a.view)[q]; pm[q] = ((const CFloat *)a.proj)[q]; }   // scalar cache
   float gm[3] = {0, 0, 0}, gs[2] = {0, 0}, gq[4] = {0, 0, 0, 0}, gT[9], gm2[2] = {0, 0}, grgb[3] = {0, 0, 0}, g_op = 0;
 #pragma unroll
   for (int q = 0; q < 9; q++) gT[q] = 0.0f;
@@ -740,7 +740,7 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
       }
     }
     if (a.shs) {   // the SH part itself runs after the rows have landed in LDS (below)
-      const float d0 = p0 - a.campos[0], d1 = p1 - a.campos[1], d2_ = p2 - a.campos[2];
+      const float d0 = p0 - ((const CFloat *)a.campos)[0], d1 = p1 - ((const CFloat *)a.campos)[1], d2_ = p2 - ((const CFloat *)a.campos)[2];
       shinv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2_ * d2_);
       shx = d0 * shinv; shy = d1 * shinv; shz = d2_ * shinv;
 #pragma unroll

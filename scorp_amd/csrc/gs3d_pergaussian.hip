@@ -16,6 +16,7 @@
 //     torch.cat and five elementwise kernels (and their autograd mirrors) from every view.
 // Arithmetic follows oracle/gs3d_oracle.c.  Contraction is off in the forward so discrete decisions round like the
 // oracle.
+#include <cstdlib>
 #include "pergaussian.hpp"
 
 namespace scorp {
@@ -29,42 +30,25 @@ struct PgArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-template <int DEG, bool SPLIT>
-__global__ void __launch_bounds__(256)
-preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
-                  int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
+struct SplatGeom {
+  bool vis;
+  float tz, sx, sy, cA, cB, cC, op, kcut;
+  uint64_t mask;
+  int x0, y0, x1, y1, radius;
+};
+
+// Projection, EWA covariance -> conic, radius, tile rectangle and the exact tile mask of one Gaussian.
+__device__ __forceinline__ SplatGeom splat_geometry(const PgArgs &a, const float *vm, const float *pm, int i, float px_,
+                                                    float py_, float pz_, float4 q_raw, const float *sc_raw, float op_raw,
+                                                    const float *cov3D_precomp) {
 #pragma clang fp contract(off)
-  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool active = i < a.N;
-  // Full blocks of the split K = 16 layout start their SH rows on the way to LDS right now (direct global -> LDS
-  // loads), so the 48 KiB stream overlaps the projection maths instead of following it.
-  constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
-  const size_t i0 = (size_t)blockIdx.x * 256;
-  const int nrows_f = min(256, a.N - (int)i0);
-  const bool lin = SPLIT && NFL == 48 && a.shs != nullptr && a.K == 16 && nrows_f == 256;
-  if (lin) stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
-  float vm[16], pm[16];
-#pragma unroll
-  for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
-  BinRec br;
-  br.x0 = br.y0 = br.x1 = br.y1 = 0; br.depth_bits = 0; br.radius = 0;
-  int radius_out = 0;
   bool vis = false;
-  float px_ = 0, py_ = 0, pz_ = 0, tz = 0, sx = 0, sy = 0, cA = 0, cB = 0, cC = 0, op = 0, kcut = 0;
+  float tz = 0, sx = 0, sy = 0, cA = 0, cB = 0, cC = 0, op = 0, kcut = 0;
   uint64_t mask = 0;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0, radius = 0;
-  if (active) {
-    px_ = a.means3D[3 * (size_t)i]; py_ = a.means3D[3 * (size_t)i + 1]; pz_ = a.means3D[3 * (size_t)i + 2];
-    // all parameter loads leave together (one memory latency instead of means -> cull -> the rest); ~4 % of the
-    // Gaussians turn out invisible and waste theirs
-    float4 q_raw = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-    float sc_raw[3] = {0.0f, 0.0f, 0.0f};
-    if (!a.cov3D_precomp) {
-      q_raw = reinterpret_cast<const float4 *>(a.rotations)[i];
-      sc_raw[0] = a.scales[3 * (size_t)i]; sc_raw[1] = a.scales[3 * (size_t)i + 1]; sc_raw[2] = a.scales[3 * (size_t)i + 2];
-    }
-    const float op_raw = a.opacities[i];
+  {
+    // (all parameter loads left together at the top: one memory latency instead of means -> cull -> the rest; ~4 % of
+    // the Gaussians turn out invisible and waste theirs)
     const float tx = vm[0] * px_ + vm[4] * py_ + vm[8] * pz_ + vm[12];
     const float ty = vm[1] * px_ + vm[5] * py_ + vm[9] * pz_ + vm[13];
     tz = __builtin_fmaf(vm[10], pz_, __builtin_fmaf(vm[6], py_, __builtin_fmaf(vm[2], px_, vm[14])));
@@ -75,9 +59,9 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
       const float pw = 1.0f / (hw + kWEps);
       const float ndcx = hx * pw, ndcy = hy * pw;
       float c6[6];
-      if (a.cov3D_precomp) {
+      if (cov3D_precomp) {
 #pragma unroll
-        for (int q = 0; q < 6; q++) c6[q] = a.cov3D_precomp[6 * (size_t)i + q];
+        for (int q = 0; q < 6; q++) c6[q] = cov3D_precomp[6 * (size_t)i + q];
       } else {
         float invn;
         const float4 q4 = act_quat(q_raw, a.raw, &invn);
@@ -148,6 +132,85 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
       }
     }
   }
+  SplatGeom r;
+  r.vis = vis; r.tz = tz; r.sx = sx; r.sy = sy; r.cA = cA; r.cB = cB; r.cC = cC; r.op = op; r.kcut = kcut;
+  r.mask = mask; r.x0 = x0; r.y0 = y0; r.x1 = x1; r.y1 = y1; r.radius = radius;
+  return r;
+}
+
+// Writes one Gaussian's records: SplatRec (visible only), BinRec, tile mask, radius.
+__device__ __forceinline__ void emit_splat(const PgArgs &a, int i, const SplatGeom &g, const float *rgb, int clamp_bits,
+                                           SplatRec *__restrict__ rec, BinRec *__restrict__ bin,
+                                           uint64_t *__restrict__ tile_mask, int32_t *__restrict__ radii,
+                                           uint32_t *__restrict__ tile_count) {
+  BinRec br;
+  br.x0 = br.y0 = br.x1 = br.y1 = 0; br.depth_bits = 0; br.radius = 0;
+  int radius_out = 0;
+  if (g.vis) {
+    float4 *dst = reinterpret_cast<float4 *>(rec + i);
+    dst[0] = make_float4(g.sx, g.sy, g.cA, g.cB);
+    dst[1] = make_float4(g.cC, g.op, rgb[0], rgb[1]);
+    dst[2] = make_float4(rgb[2], g.tz, g.kcut, 0.0f);
+    br.x0 = (uint16_t)g.x0; br.y0 = (uint16_t)g.y0; br.x1 = (uint16_t)g.x1; br.y1 = (uint16_t)g.y1;
+    br.depth_bits = __float_as_uint(g.tz);
+    br.radius = g.radius | (clamp_bits << kClampShift);
+    radius_out = g.radius;
+    if (a.count_with_atomics)  // fallback binning for images with more tiles than an LDS histogram holds
+      for_each_tile(g.x0, g.y0, g.x1, g.y1, g.mask, a.tiles_x, [&](int t) { atomicAdd(&tile_count[t], 1u); });
+  }
+  reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
+  tile_mask[i] = g.mask;
+  radii[i] = radius_out;
+}
+
+// LIN: a full block of the split K = 16 layout, whose SH rows go to LDS with direct global -> LDS loads.  It is a
+// separate instantiation so that the compiler sees ONE straight path "parameter loads, 12 LDS loads per wave, maths":
+// its wait for the parameters then is vmcnt(12) and the 48 KiB stream overlaps the projection maths (with the runtime
+// flag the paths merged and the wait was vmcnt(0): the maths started only after the whole stream had landed).
+template <int DEG, bool SPLIT, bool LIN>
+__device__ __forceinline__ void preprocess_body(const PgArgs &a, float *s_sh, SplatRec *__restrict__ rec,
+                                                BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
+                                                int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool active = LIN || i < a.N;
+  constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
+  const size_t i0 = (size_t)blockIdx.x * 256;
+  const int nrows_f = LIN ? 256 : min(256, a.N - (int)i0);
+  constexpr bool lin = LIN;
+  // The per-Gaussian parameters leave FIRST: vmcnt retires in order, so loads issued behind the 48 KiB SH stream would
+  // only be usable once all of it has landed; issued ahead of it, the projection maths overlaps the stream.
+  float px_ = 0, py_ = 0, pz_ = 0, op_raw = 0;
+  float4 q_raw = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+  float sc_raw[3] = {0.0f, 0.0f, 0.0f};
+  if constexpr (LIN) {   // (scales / rotations present: the caller checked)
+    RawParams r;
+    float p[11];
+    raw_issue_params(r, a.means3D + 3 * (size_t)i, a.rotations + 4 * (size_t)i, a.scales + 3 * (size_t)i, a.opacities + i);
+    stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    raw_take_params(r, p);
+    px_ = p[0]; py_ = p[1]; pz_ = p[2];
+    q_raw = make_float4(p[3], p[4], p[5], p[6]);
+    sc_raw[0] = p[7]; sc_raw[1] = p[8]; sc_raw[2] = p[9];
+    op_raw = p[10];
+  } else if (active) {
+    px_ = a.means3D[3 * (size_t)i]; py_ = a.means3D[3 * (size_t)i + 1]; pz_ = a.means3D[3 * (size_t)i + 2];
+    if (!a.cov3D_precomp) {
+      q_raw = reinterpret_cast<const float4 *>(a.rotations)[i];
+      sc_raw[0] = a.scales[3 * (size_t)i]; sc_raw[1] = a.scales[3 * (size_t)i + 1]; sc_raw[2] = a.scales[3 * (size_t)i + 2];
+    }
+    op_raw = a.opacities[i];
+  }
+  float vm[16], pm[16];
+  {  // camera matrices through the scalar cache (constant address space): no VMEM slots, no vmcnt dependence
+    const CFloat *cv = (const CFloat *)a.view, *cp = (const CFloat *)a.proj;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { vm[q] = cv[q]; pm[q] = cp[q]; }
+  }
+  SplatGeom g;
+  g.vis = false; g.mask = 0; g.radius = 0;
+  if (active) g = splat_geometry(a, vm, pm, i, px_, py_, pz_, q_raw, sc_raw, op_raw, a.cov3D_precomp);
+  const bool vis = active && g.vis;
   float rgb[3] = {0.0f, 0.0f, 0.0f};
   int clamp_bits = 0;
   if (a.shs) {
@@ -158,7 +221,7 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
         __syncthreads();
       }
       if (vis) {
-        const float dx = px_ - a.campos[0], dy = py_ - a.campos[1], dz = pz_ - a.campos[2];
+        const float dx = px_ - ((const CFloat *)a.campos)[0], dy = py_ - ((const CFloat *)a.campos)[1], dz = pz_ - ((const CFloat *)a.campos)[2];
         const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         sh_row_to_rgb<DEG>(sh_row(s_sh, threadIdx.x, lin), dx * inv, dy * inv, dz * inv, rgb);
 #pragma unroll
@@ -173,21 +236,21 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
     for (int q = 0; q < 3; q++) rgb[q] = a.colors_precomp[3 * (size_t)i + q];
   }
   if (!active) return;
-  if (vis) {
-    float4 *dst = reinterpret_cast<float4 *>(rec + i);
-    dst[0] = make_float4(sx, sy, cA, cB);
-    dst[1] = make_float4(cC, op, rgb[0], rgb[1]);
-    dst[2] = make_float4(rgb[2], tz, kcut, 0.0f);
-    br.x0 = (uint16_t)x0; br.y0 = (uint16_t)y0; br.x1 = (uint16_t)x1; br.y1 = (uint16_t)y1;
-    br.depth_bits = __float_as_uint(tz);
-    br.radius = radius | (clamp_bits << kClampShift);
-    radius_out = radius;
-    if (a.count_with_atomics)  // fallback binning for images with more tiles than an LDS histogram holds
-      for_each_tile(x0, y0, x1, y1, mask, a.tiles_x, [&](int t) { atomicAdd(&tile_count[t], 1u); });
+  emit_splat(a, i, g, rgb, clamp_bits, rec, bin, tile_mask, radii, tile_count);
+}
+
+template <int DEG, bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
+                  int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
+  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
+  if constexpr (SPLIT && DEG == 3) {
+    if (a.shs != nullptr && a.K == 16 && !a.cov3D_precomp && a.N - (int)blockIdx.x * 256 >= 256) {
+      preprocess_body<DEG, SPLIT, true>(a, s_sh, rec, bin, tile_mask, radii, tile_count);
+      return;
+    }
   }
-  reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
-  tile_mask[i] = mask;
-  radii[i] = radius_out;
+  preprocess_body<DEG, SPLIT, false>(a, s_sh, rec, bin, tile_mask, radii, tile_count);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -220,7 +283,7 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
   }
   float vm[16], pm[16];
 #pragma unroll
-  for (int q = 0; q < 16; q++) { vm[q] = a.view[q]; pm[q] = a.proj[q]; }
+  for (int q = 0; q < 16; q++) { vm[q] = ((const CFloat *)a.view)[q]; pm[q] = ((const CFloat *)a.proj)[q]; }   // scalar cache
   float gm[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gc6[6] = {0, 0, 0, 0, 0, 0};
   float shx = 0, shy = 0, shz = 0, shinv = 0, gr3[3] = {0, 0, 0};
   float a_[kAccStride];
@@ -332,7 +395,7 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
       g_op *= o * (1.0f - o);
     }
     if (a.shs) {   // the SH part itself runs after the rows have landed in LDS (below)
-      const float d0 = p0 - a.campos[0], d1 = p1 - a.campos[1], d2_ = p2 - a.campos[2];
+      const float d0 = p0 - ((const CFloat *)a.campos)[0], d1 = p1 - ((const CFloat *)a.campos)[1], d2_ = p2 - ((const CFloat *)a.campos)[2];
       shinv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2_ * d2_);
       shx = d0 * shinv; shy = d1 * shinv; shz = d2_ * shinv;
 #pragma unroll

@@ -151,6 +151,37 @@ __device__ __forceinline__ void stage_sh_linear_async(float *__restrict__ lds, c
 }
 __device__ __forceinline__ void stage_sh_wait() { __builtin_amdgcn_s_waitcnt(0); }
 
+// Loads the compiler does not track.  Its wait-count pass treats ordinary loads and LDS-DMA loads sharing vmcnt as
+// possibly out of order and puts vmcnt(0) in front of the first use of ANY loaded value, i.e. behind the whole SH stream.
+// Loads do retire in order among themselves, so the per-Gaussian parameters (means 3, rotation 4, scale 3, opacity 1
+// floats) fetched with raw_issue_params BEFORE stage_sh_linear_async are complete at vmcnt(12) (12 LDS loads per wave
+// follow them).  Between issue and raw_take_params NOTHING may touch the destination registers: the compiler believes
+// asm outputs ready at once and would happily copy them, so they are used exactly once, as plain inputs of the asm
+// that waits and then moves them into fresh registers.  (No stores may be pending either: stores can overtake loads.)
+struct RawParams { float v[11]; };
+__device__ __forceinline__ void raw_issue_params(RawParams &r, const float *means, const float *rot, const float *scl,
+                                                 const float *opa) {
+  asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %3, off offset:4\n\tglobal_load_dword %2, %3, off offset:8"
+               : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]) : "v"(means) : "memory");
+  asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:4\n\tglobal_load_dword %2, %4, off offset:8\n\t"
+               "global_load_dword %3, %4, off offset:12"
+               : "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]) : "v"(rot) : "memory");
+  asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %3, off offset:4\n\tglobal_load_dword %2, %3, off offset:8"
+               : "=&v"(r.v[7]), "=&v"(r.v[8]), "=&v"(r.v[9]) : "v"(scl) : "memory");
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(r.v[10]) : "v"(opa) : "memory");
+}
+__device__ __forceinline__ void raw_take_params(const RawParams &r, float *p) {
+  asm volatile("s_waitcnt vmcnt(12)\n\t"
+               "v_mov_b32 %0, %11\n\tv_mov_b32 %1, %12\n\tv_mov_b32 %2, %13\n\tv_mov_b32 %3, %14\n\t"
+               "v_mov_b32 %4, %15\n\tv_mov_b32 %5, %16\n\tv_mov_b32 %6, %17\n\tv_mov_b32 %7, %18\n\t"
+               "v_mov_b32 %8, %19\n\tv_mov_b32 %9, %20\n\tv_mov_b32 %10, %21"
+               : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]),
+                 "=&v"(p[8]), "=&v"(p[9]), "=&v"(p[10])
+               : "v"(r.v[0]), "v"(r.v[1]), "v"(r.v[2]), "v"(r.v[3]), "v"(r.v[4]), "v"(r.v[5]), "v"(r.v[6]), "v"(r.v[7]),
+                 "v"(r.v[8]), "v"(r.v[9]), "v"(r.v[10])
+               : "memory");
+}
+
 __device__ __forceinline__ void unstage_sh_linear(const float *__restrict__ lds, float *__restrict__ g_dc,
                                                   float *__restrict__ g_rest, size_t i0) {
   float4 *d4 = reinterpret_cast<float4 *>(g_dc + i0 * 3), *r4 = reinterpret_cast<float4 *>(g_rest + i0 * 45);
