@@ -254,24 +254,39 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int DEG, bool SPLIT>
-__global__ void __launch_bounds__(256)
-preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float *__restrict__ acc,
-                           ScorpGs3dGrads g) {
-  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
+// LIN as in the forward: full workgroups of the training layout (dc / rest split, K = 16, scales + rotations) fetch
+// everything a Gaussian needs - radius word, accumulator row, parameters: 22 dwords - with untracked loads AHEAD of
+// the SH stream and pick them up at vmcnt(12); otherwise the chain "radius -> visible? -> accumulators, parameters"
+// would sit behind the 48 KiB stream (the compiler waits with vmcnt(0) while LDS-DMA loads are pending).
+template <int DEG, bool SPLIT, bool LIN>
+__device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float *s_sh, const BinRec *__restrict__ bin,
+                                                         const float *__restrict__ acc, const ScorpGs3dGrads &g) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool active = i < a.N;
+  const bool active = LIN || i < a.N;
   const size_t i0 = (size_t)blockIdx.x * 256;
-  const int nrows = min(256, a.N - (int)i0);
+  const int nrows = LIN ? 256 : min(256, a.N - (int)i0);
   constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
-  const int32_t rad_bits = active ? bin[i].radius : 0;
+  float pre[11], pre_acc[11];   // LIN: means 0-2, rotation 3-6, scale 7-9, opacity 10 | accumulators 0-9, radius word 10
+  int32_t rad_bits = 0;
+  if constexpr (LIN) {
+    RawParams r, ra;
+    raw_issue_params(r, a.means3D + 3 * (size_t)i, a.rotations + 4 * (size_t)i, a.scales + 3 * (size_t)i, a.opacities + i);
+    static_assert(kAccStride == 12, "accumulator row: 12 floats, 10 used here");
+    const float *ap = acc + (size_t)i * kAccStride;
+    raw_issue_params(ra, ap, ap + 3, ap + 7, reinterpret_cast<const float *>(&bin[i].radius));
+    stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    raw_take_params(r, pre);
+    raw_take_params(ra, pre_acc);   // (its vmcnt(12) is already satisfied)
+    rad_bits = __float_as_int(pre_acc[10]);
+  } else {
+    rad_bits = active ? bin[i].radius : 0;
+  }
   const bool visible = (rad_bits & kRadiusMask) != 0;
   const bool want_sh_grad = a.shs != nullptr && g.shs != nullptr;
   bool staged = false;
-  const bool lin = SPLIT && NFL == 48 && a.K == 16 && nrows == 256;
+  constexpr bool lin = LIN;
   if (a.shs) {
-    if (lin) {  // direct global -> LDS loads, in flight while the geometry chain below runs
-      stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    if constexpr (lin) {
       staged = true;
     } else {
       if (__syncthreads_or(visible ? 1 : 0)) {
@@ -292,28 +307,45 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
   float g_op = 0.0f;
   const ShRow row = sh_row(s_sh, threadIdx.x, lin);
   if (visible) {
-    const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAccStride);
-    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-    a_[0] = a0.x; a_[1] = a0.y; a_[2] = a0.z; a_[3] = a0.w; a_[4] = a1.x; a_[5] = a1.y; a_[6] = a1.z; a_[7] = a1.w;
-    a_[8] = a2.x; a_[9] = a2.y;
-    const float p0 = a.means3D[3 * (size_t)i], p1 = a.means3D[3 * (size_t)i + 1], p2 = a.means3D[3 * (size_t)i + 2];
+    float p0, p1, p2;
+    if constexpr (LIN) {
+#pragma unroll
+      for (int q = 0; q < 10; q++) a_[q] = pre_acc[q];
+      p0 = pre[0]; p1 = pre[1]; p2 = pre[2];
+    } else {
+      const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAccStride);
+      const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+      a_[0] = a0.x; a_[1] = a0.y; a_[2] = a0.z; a_[3] = a0.w; a_[4] = a1.x; a_[5] = a1.y; a_[6] = a1.z; a_[7] = a1.w;
+      a_[8] = a2.x; a_[9] = a2.y;
+      p0 = a.means3D[3 * (size_t)i]; p1 = a.means3D[3 * (size_t)i + 1]; p2 = a.means3D[3 * (size_t)i + 2];
+    }
     const float tx = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
     const float ty = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
     const float tz = __builtin_fmaf(vm[10], p2, __builtin_fmaf(vm[6], p1, __builtin_fmaf(vm[2], p0, vm[14])));
     float c6[6];
     float R[9], sm[3] = {0, 0, 0}, sact[3] = {0, 0, 0}, inv_qn = 1.0f;
     float4 qn = make_float4(1, 0, 0, 0);
-    if (a.cov3D_precomp) {
+    if (!LIN && a.cov3D_precomp) {
 #pragma unroll
       for (int q = 0; q < 6; q++) c6[q] = a.cov3D_precomp[6 * (size_t)i + q];
     } else {
-      qn = act_quat(reinterpret_cast<const float4 *>(a.rotations)[i], a.raw, &inv_qn);
+      float4 q_in;
+      float s_in[3];
+      if constexpr (LIN) {
+        q_in = make_float4(pre[3], pre[4], pre[5], pre[6]);
+        s_in[0] = pre[7]; s_in[1] = pre[8]; s_in[2] = pre[9];
+      } else {
+        q_in = reinterpret_cast<const float4 *>(a.rotations)[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) s_in[k] = a.scales[3 * (size_t)i + k];
+      }
+      qn = act_quat(q_in, a.raw, &inv_qn);
       const float r = qn.x, x = qn.y, y = qn.z, z = qn.w;
       R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - r * z);     R[2] = 2 * (x * z + r * y);
       R[3] = 2 * (x * y + r * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - r * x);
       R[6] = 2 * (x * z - r * y);     R[7] = 2 * (y * z + r * x);     R[8] = 1 - 2 * (x * x + y * y);
 #pragma unroll
-      for (int k = 0; k < 3; k++) { sact[k] = act_scale(a.scales[3 * (size_t)i + k], a.raw); sm[k] = a.scale_mod * sact[k]; }
+      for (int k = 0; k < 3; k++) { sact[k] = act_scale(s_in[k], a.raw); sm[k] = a.scale_mod * sact[k]; }
       float L[9];
 #pragma unroll
       for (int r_ = 0; r_ < 3; r_++)
@@ -391,7 +423,7 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
                (pm[q * 4 + 1] * pw - pm[q * 4 + 3] * hy * pw * pw) * a_[1];
     g_op = a_[5];
     if (a.raw & 1) {
-      const float o = act_opacity(a.opacities[i], a.raw);
+      const float o = act_opacity(LIN ? pre[10] : a.opacities[i], a.raw);
       g_op *= o * (1.0f - o);
     }
     if (a.shs) {   // the SH part itself runs after the rows have landed in LDS (below)
@@ -460,6 +492,20 @@ preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float
     if (lin) unstage_sh_linear(s_sh, g.shs, g.shs_rest, i0);
     else unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
   }
+}
+
+template <int DEG, bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float *__restrict__ acc,
+                           ScorpGs3dGrads g) {
+  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
+  if constexpr (SPLIT && DEG == 3) {
+    if (a.shs != nullptr && a.K == 16 && !a.cov3D_precomp && a.N - (int)blockIdx.x * 256 >= 256) {
+      preprocess_backward_body<DEG, SPLIT, true>(a, s_sh, bin, acc, g);
+      return;
+    }
+  }
+  preprocess_backward_body<DEG, SPLIT, false>(a, s_sh, bin, acc, g);
 }
 
 PgArgs make_args(const ScorpGs3dInputs *in, const StateLayout &L) {

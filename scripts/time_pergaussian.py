@@ -33,7 +33,7 @@ for i in range(4):
     step(i)
 torch.cuda.synchronize()
 _C.prof_enable(True)
-for i in range(16):
+for i in range(48):
     step(i)
 torch.cuda.synchronize()
 k = _C.prof_collect()
