@@ -71,20 +71,26 @@ __device__ __forceinline__ void quat_R(float4 q, float *R) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int DEG, bool SPLIT>
-__global__ void __launch_bounds__(256)
-preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
-                    int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
+// LIN: full workgroups of the training layout (dc / rest split, K = 16, scales + rotations) - parameters fetched with
+// untracked loads AHEAD of the SH stream (direct global -> LDS loads) and picked up at vmcnt(12); see pergaussian.hpp.
+template <int DEG, bool SPLIT, bool LIN>
+__device__ __forceinline__ void preprocess2d_body(const Pg2Args &a, float *s_sh, Surfel *__restrict__ rec,
+                                                  BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
+                                                  int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
 #pragma clang fp contract(off)
-  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool active = i < a.N;
-  // full blocks of the split K = 16 layout start their SH rows on the way to LDS now (direct global -> LDS loads)
+  const bool active = LIN || i < a.N;
   constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
   const size_t i0 = (size_t)blockIdx.x * 256;
-  const int nrows_f = min(256, a.N - (int)i0);
-  const bool lin = SPLIT && NFL == 48 && a.shs != nullptr && a.K == 16 && nrows_f == 256;
-  if (lin) stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+  const int nrows_f = LIN ? 256 : min(256, a.N - (int)i0);
+  constexpr bool lin = LIN;
+  float pre[11];   // LIN: means 0-2, rotation 3-6, scale 7-8, opacity 10
+  if constexpr (LIN) {
+    RawParams r;
+    raw_issue_params<2>(r, a.means3D + 3 * (size_t)i, a.rotations + 4 * (size_t)i, a.scales + 2 * (size_t)i, a.opacities + i);
+    stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    raw_take_params(r, pre);
+  }
   float vm[16], pm[16];
 #pragma unroll
   for (int q = 0; q < 16; q++) { vm[q] = ((const CFloat *)a.view)[q]; pm[q] = ((const CFloat *)a.proj)[q]; }   // scalar cache
@@ -96,20 +102,22 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
   uint64_t mask = kMaskAll;
   int radius = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
   if (active) {
-    p[0] = a.means3D[3 * (size_t)i]; p[1] = a.means3D[3 * (size_t)i + 1]; p[2] = a.means3D[3 * (size_t)i + 2];
+    if constexpr (LIN) { p[0] = pre[0]; p[1] = pre[1]; p[2] = pre[2]; }
+    else { p[0] = a.means3D[3 * (size_t)i]; p[1] = a.means3D[3 * (size_t)i + 1]; p[2] = a.means3D[3 * (size_t)i + 2]; }
     const float pvx = vm[0] * p[0] + vm[4] * p[1] + vm[8] * p[2] + vm[12];
     const float pvy = vm[1] * p[0] + vm[5] * p[1] + vm[9] * p[2] + vm[13];
     depth = __builtin_fmaf(vm[10], p[2], __builtin_fmaf(vm[6], p[1], __builtin_fmaf(vm[2], p[0], vm[14])));
     if (depth > kNearZ) {
-      if (a.transmat) {
+      if (!LIN && a.transmat) {
 #pragma unroll
         for (int q = 0; q < 9; q++) T[q] = a.transmat[9 * (size_t)i + q];
       } else {
         float Q[3][4], R[9], invn;
         pixel_rows(pm, a.W, a.H, Q);
-        quat_R(act_quat(reinterpret_cast<const float4 *>(a.rotations)[i], a.raw, &invn), R);
-        const float sx = a.scale_mod * act_scale(a.scales[2 * (size_t)i], a.raw),
-                    sy = a.scale_mod * act_scale(a.scales[2 * (size_t)i + 1], a.raw);
+        const float4 q_in = LIN ? make_float4(pre[3], pre[4], pre[5], pre[6]) : reinterpret_cast<const float4 *>(a.rotations)[i];
+        quat_R(act_quat(q_in, a.raw, &invn), R);
+        const float sx = a.scale_mod * act_scale(LIN ? pre[7] : a.scales[2 * (size_t)i], a.raw),
+                    sy = a.scale_mod * act_scale(LIN ? pre[8] : a.scales[2 * (size_t)i + 1], a.raw);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
           T[r * 3 + 0] = sx * (Q[r][0] * R[0] + Q[r][1] * R[3] + Q[r][2] * R[6]);
@@ -138,7 +146,7 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
         y1 = min(a.tiles_y, max(0, (int)((cy + radius + kTile - 1) / kTile)));
         if ((x1 - x0) * (y1 - y0) > 0) {
           vis = true;
-          op = act_opacity(a.opacities[i], a.raw);
+          op = act_opacity(LIN ? pre[10] : a.opacities[i], a.raw);
           // footprint of {alpha >= 1/255} (see surfel_reaches_box), in the frame centred on (cx, cy)
           const float kk = 1.01f * 2.0f * logf(fmaxf(255.0f * op, 1.0f)) + 0.02f;
           lp2 = 0.5f * kk;
@@ -225,6 +233,20 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
   reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
   tile_mask[i] = mask;
   radii[i] = radius_out;
+}
+
+template <int DEG, bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
+                    int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
+  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
+  if constexpr (SPLIT && DEG == 3) {
+    if (a.shs != nullptr && a.K == 16 && !a.transmat && a.N - (int)blockIdx.x * 256 >= 256) {
+      preprocess2d_body<DEG, SPLIT, true>(a, s_sh, rec, bin, tile_mask, radii, tile_count);
+      return;
+    }
+  }
+  preprocess2d_body<DEG, SPLIT, false>(a, s_sh, rec, bin, tile_mask, radii, tile_count);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -622,24 +644,55 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int DEG, bool SPLIT>
-__global__ void __launch_bounds__(256)
-preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const BinRec *__restrict__ bin,
-                             const float *__restrict__ acc, ScorpGs3dGrads g) {
-  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
+// LIN: full workgroups of the training layout.  Everything a surfel needs (radius and depth words, the 20-float
+// accumulator row, the nine floats of its transform, its parameters) is requested unconditionally BEFORE the SH stream is
+// issued, so that one memory latency covers it all instead of the chain radius -> visible? -> rows -> parameters behind
+// the stream.  Plain 16-byte loads here: the 44 dwords as untracked one-dword loads (the forward's way, which would also
+// let the maths start before the stream has landed) cost more in the texture pipe than they gain (121 vs 118 us).
+template <int DEG, bool SPLIT, bool LIN>
+__device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, float *s_sh, const Surfel *__restrict__ rec,
+                                                           const BinRec *__restrict__ bin, const float *__restrict__ acc,
+                                                           const ScorpGs3dGrads &g) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool active = i < a.N;
+  const bool active = LIN || i < a.N;
   const size_t i0 = (size_t)blockIdx.x * 256;
-  const int nrows = min(256, a.N - (int)i0);
+  const int nrows = LIN ? 256 : min(256, a.N - (int)i0);
   constexpr int NFL = 3 * (DEG + 1) * (DEG + 1);
-  const int32_t rad_bits = active ? bin[i].radius : 0;
+  // LIN: pre = means 0-2, rotation 3-6, scale 7-8, opacity 10 | acc_lo = accumulators 0-10 | acc_hi = accumulators
+  // 11-19 in slots 0-8, radius word in slot 10 | rec_lo = transform 0-8, depth word in slot 10
+  float pre[11], acc_lo[11], acc_hi[11], rec_lo[11];
+  int32_t rad_bits = 0;
+  if constexpr (LIN) {
+    static_assert(kAcc2Stride == 20, "accumulator row of 20 floats");
+    const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAcc2Stride);
+    const float4 *rp = reinterpret_cast<const float4 *>(rec + i);
+    const uint4 bw = reinterpret_cast<const uint4 *>(bin)[i];
+    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4], r0 = rp[0], r1 = rp[1];
+    const float r2x = reinterpret_cast<const float *>(rp + 2)[0];
+    const float4 q_in = reinterpret_cast<const float4 *>(a.rotations)[i];
+    const float s_in0 = a.scales[2 * (size_t)i], s_in1 = a.scales[2 * (size_t)i + 1];
+    pre[0] = a.means3D[3 * (size_t)i]; pre[1] = a.means3D[3 * (size_t)i + 1]; pre[2] = a.means3D[3 * (size_t)i + 2];
+    pre[10] = a.opacities[i];
+    stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    pre[3] = q_in.x; pre[4] = q_in.y; pre[5] = q_in.z; pre[6] = q_in.w; pre[7] = s_in0; pre[8] = s_in1;
+    acc_lo[0] = a0.x; acc_lo[1] = a0.y; acc_lo[2] = a0.z; acc_lo[3] = a0.w; acc_lo[4] = a1.x; acc_lo[5] = a1.y; acc_lo[6] = a1.z;
+    acc_lo[7] = a1.w; acc_lo[8] = a2.x; acc_lo[9] = a2.y; acc_lo[10] = a2.z;
+    acc_hi[0] = a2.w; acc_hi[1] = a3.x; acc_hi[2] = a3.y; acc_hi[3] = a3.z; acc_hi[4] = a3.w; acc_hi[5] = a4.x; acc_hi[6] = a4.y;
+    acc_hi[7] = a4.z; acc_hi[8] = a4.w;
+    rec_lo[0] = r0.x; rec_lo[1] = r0.y; rec_lo[2] = r0.z; rec_lo[3] = r0.w; rec_lo[4] = r1.x; rec_lo[5] = r1.y; rec_lo[6] = r1.z;
+    rec_lo[7] = r1.w; rec_lo[8] = r2x;
+    rec_lo[10] = __uint_as_float(bw.z);   // BinRec: x0y0 | x1y1 | depth word | radius word
+    acc_hi[10] = __uint_as_float(bw.w);
+    rad_bits = __float_as_int(acc_hi[10]);
+  } else {
+    rad_bits = active ? bin[i].radius : 0;
+  }
   const bool visible = (rad_bits & kRadiusMask) != 0;
   const bool want_sh_grad = a.shs != nullptr && g.shs != nullptr;
   bool staged = false;
-  const bool lin = SPLIT && NFL == 48 && a.K == 16 && nrows == 256;
+  constexpr bool lin = LIN;
   if (a.shs) {
-    if (lin) {  // direct global -> LDS loads, in flight while the geometry chain below runs
-      stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    if constexpr (lin) {
       staged = true;
     } else {
       if (__syncthreads_or(visible ? 1 : 0)) {
@@ -658,15 +711,24 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
   for (int q = 0; q < 9; q++) gT[q] = 0.0f;
   const ShRow row = sh_row(s_sh, threadIdx.x, lin);
   if (visible) {
-    const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAcc2Stride);
-    const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4];
+    float4 a0, a1, a2, a3, a4, r0, r1, r2;
+    if constexpr (LIN) {
+      a0 = make_float4(acc_lo[0], acc_lo[1], acc_lo[2], acc_lo[3]); a1 = make_float4(acc_lo[4], acc_lo[5], acc_lo[6], acc_lo[7]);
+      a2 = make_float4(acc_lo[8], acc_lo[9], acc_lo[10], acc_hi[0]); a3 = make_float4(acc_hi[1], acc_hi[2], acc_hi[3], acc_hi[4]);
+      a4 = make_float4(acc_hi[5], acc_hi[6], acc_hi[7], acc_hi[8]);
+      r0 = make_float4(rec_lo[0], rec_lo[1], rec_lo[2], rec_lo[3]); r1 = make_float4(rec_lo[4], rec_lo[5], rec_lo[6], rec_lo[7]);
+      r2 = make_float4(rec_lo[8], 0.0f, 0.0f, 0.0f);
+    } else {
+      const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAcc2Stride);
+      a0 = ap[0]; a1 = ap[1]; a2 = ap[2]; a3 = ap[3]; a4 = ap[4];
+      const float4 *rp = reinterpret_cast<const float4 *>(rec + i);
+      r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+    }
     const float ga[3] = {a0.x, a0.y, a0.z}, gb[3] = {a0.w, a1.x, a1.y}, gc[3] = {a1.z, a1.w, a2.x};
     const float gD = a2.y, gTw2 = a2.z, gx = a2.w, gy = a3.x;
     const float gn[3] = {a3.y, a3.z, a3.w};
     g_op = a4.x;
     grgb[0] = a4.y; grgb[1] = a4.z; grgb[2] = a4.w;
-    const float4 *rp = reinterpret_cast<const float4 *>(rec + i);
-    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
     const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
     // the blend kernels differentiate the linear form p = x pa + y pb + pc, depth = D / p.z (see surfel_lin):
     // pa = Tv x Tw, pb = Tw x Tu, pc = Tu x Tv, D = Tu . pa; for c = u x v: dL/du = v x g, dL/dv = g x u
@@ -679,7 +741,7 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
       gT[6 + q] = (ga[j] * Tv[k] - ga[k] * Tv[j]) + (Tu[j] * gb[k] - Tu[k] * gb[j]) + gD * pc_q;    // d/dTw
     }
     gT[8] += gTw2;
-    const float depth = __uint_as_float(bin[i].depth_bits);
+    const float depth = LIN ? rec_lo[10] : __uint_as_float(bin[i].depth_bits);
     gm2[0] = gT[2] * depth * 0.5f * a.W;   // densification statistic (gs2dgs/scene/gaussian_model.py:495 consumes it)
     gm2[1] = gT[5] * depth * 0.5f * a.H;
     if (gx != 0.0f || gy != 0.0f) {        // the low-pass centre is the centre of the 3-sigma box, a function of T
@@ -700,16 +762,20 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
       for (int q = 0; q < 3; q++) gT[6 + q] += dLdd * 2.0f * t[q] * Tw[q];
     }
     if (a.raw & 1) {
-      const float o = act_opacity(a.opacities[i], a.raw);
+      const float o = act_opacity(LIN ? pre[10] : a.opacities[i], a.raw);
       g_op *= o * (1.0f - o);
     }
-    const float p0 = a.means3D[3 * (size_t)i], p1 = a.means3D[3 * (size_t)i + 1], p2 = a.means3D[3 * (size_t)i + 2];
-    if (!a.transmat) {
+    float p0, p1, p2;
+    if constexpr (LIN) { p0 = pre[0]; p1 = pre[1]; p2 = pre[2]; }
+    else { p0 = a.means3D[3 * (size_t)i]; p1 = a.means3D[3 * (size_t)i + 1]; p2 = a.means3D[3 * (size_t)i + 2]; }
+    if (LIN || !a.transmat) {
       float Q[3][4], R[9], inv_qn;
       pixel_rows(pm, a.W, a.H, Q);
-      const float4 qn = act_quat(reinterpret_cast<const float4 *>(a.rotations)[i], a.raw, &inv_qn);
+      const float4 q_in = LIN ? make_float4(pre[3], pre[4], pre[5], pre[6]) : reinterpret_cast<const float4 *>(a.rotations)[i];
+      const float4 qn = act_quat(q_in, a.raw, &inv_qn);
       quat_R(qn, R);
-      const float sa0 = act_scale(a.scales[2 * (size_t)i], a.raw), sa1 = act_scale(a.scales[2 * (size_t)i + 1], a.raw);
+      const float sa0 = act_scale(LIN ? pre[7] : a.scales[2 * (size_t)i], a.raw),
+                  sa1 = act_scale(LIN ? pre[8] : a.scales[2 * (size_t)i + 1], a.raw);
       const float sx = a.scale_mod * sa0, sy = a.scale_mod * sa1;
       float gh[3][3];
 #pragma unroll
@@ -774,6 +840,20 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
     if (lin) unstage_sh_linear(s_sh, g.shs, g.shs_rest, i0);
     else unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
   }
+}
+
+template <int DEG, bool SPLIT>
+__global__ void __launch_bounds__(256)
+preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const BinRec *__restrict__ bin,
+                             const float *__restrict__ acc, ScorpGs3dGrads g) {
+  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
+  if constexpr (SPLIT && DEG == 3) {
+    if (a.shs != nullptr && a.K == 16 && !a.transmat && a.N - (int)blockIdx.x * 256 >= 256) {
+      preprocess2d_backward_body<DEG, SPLIT, true>(a, s_sh, rec, bin, acc, g);
+      return;
+    }
+  }
+  preprocess2d_backward_body<DEG, SPLIT, false>(a, s_sh, rec, bin, acc, g);
 }
 
 Pg2Args make_args2(const ScorpGs3dInputs *in, const StateLayout &L) {

@@ -159,6 +159,9 @@ __device__ __forceinline__ void stage_sh_wait() { __builtin_amdgcn_s_waitcnt(0);
 // asm outputs ready at once and would happily copy them, so they are used exactly once, as plain inputs of the asm
 // that waits and then moves them into fresh registers.  (No stores may be pending either: stores can overtake loads.)
 struct RawParams { float v[11]; };
+// NS = floats in the third group (3: 3DGS scales / accumulators 7-9; 2: surfel scales, slot 9 then repeats slot 8 so that
+// nothing past the end of the array is read and the count of loads stays 11)
+template <int NS = 3>
 __device__ __forceinline__ void raw_issue_params(RawParams &r, const float *means, const float *rot, const float *scl,
                                                  const float *opa) {
   asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %3, off offset:4\n\tglobal_load_dword %2, %3, off offset:8"
@@ -166,8 +169,12 @@ __device__ __forceinline__ void raw_issue_params(RawParams &r, const float *mean
   asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:4\n\tglobal_load_dword %2, %4, off offset:8\n\t"
                "global_load_dword %3, %4, off offset:12"
                : "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]) : "v"(rot) : "memory");
-  asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %3, off offset:4\n\tglobal_load_dword %2, %3, off offset:8"
-               : "=&v"(r.v[7]), "=&v"(r.v[8]), "=&v"(r.v[9]) : "v"(scl) : "memory");
+  if constexpr (NS == 3)
+    asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %3, off offset:4\n\tglobal_load_dword %2, %3, off offset:8"
+                 : "=&v"(r.v[7]), "=&v"(r.v[8]), "=&v"(r.v[9]) : "v"(scl) : "memory");
+  else
+    asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %3, off offset:4\n\tglobal_load_dword %2, %3, off offset:4"
+                 : "=&v"(r.v[7]), "=&v"(r.v[8]), "=&v"(r.v[9]) : "v"(scl) : "memory");
   asm volatile("global_load_dword %0, %1, off" : "=&v"(r.v[10]) : "v"(opa) : "memory");
 }
 __device__ __forceinline__ void raw_take_params(const RawParams &r, float *p) {
