@@ -130,7 +130,17 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
 
   // head stays a multiple of kGroup (only a wave's final group is partial), so the slots of a group are head + i
   // without wrap-around: one LDS base per array, immediate offsets
+  float park_v[3] = {0.0f, 0.0f, 0.0f};      // a group's sums, parked until flush_sums
+  uint32_t park_o[3] = {0u, 0u, 0u};           // ... and their float offsets in acc (N * 12 < 2^32, checked at the entry point)
+  auto flush_sums = [&]() {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (park_v[k] != 0.0f) atomicAdd(acc + park_o[k], park_v[k]);
+      park_v[k] = 0.0f;
+    }
+  };
   auto process_group = [&](auto full, int nslots) {
+    flush_sums();   // (a second group of the same chunk: the first one's sums leave now)
     constexpr bool kFull = decltype(full)::value;   // full groups run straight-line; only a wave's last one is partial
     {
       int hv = head;
@@ -227,13 +237,18 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      // The 160 sums go out as three wave-wide atomic instructions - but not yet: they are parked in registers and
+      // issued after the next chunk's gathers have been picked up (flush_sums).  vmcnt counts loads and atomics alike
+      // and the compiler waits with vmcnt(0) for the gathers, so atomics issued right here would be waited for, at
+      // their full memory-side latency, at the top of the next chunk.
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const int f = lane + 64 * k;
         const int sl = f / 10, col = f - sl * 10;
+        park_v[k] = 0.0f;
         if (sl < nslots) {
-          const float v = dbuf[sl * kAccStride + col];
-          if (v != 0.0f) atomicAdd(acc + (size_t)q_id[head + sl] * kAccStride + col, v);
+          park_v[k] = dbuf[sl * kAccStride + col];
+          park_o[k] = q_id[head + sl] * (uint32_t)kAccStride + col;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -273,6 +288,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     bool hit2;
     uint32_t id2, pos1_2;
     fetch_idx(done_n + 2 * kChunk, hit2, id2, pos1_2);
+    flush_sums();
     const uint64_t m = __ballot(hit);
     if (hit) {
       const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (kRing - 1);
@@ -291,6 +307,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     hit = hit1; id = id1; pos1 = pos1_1; a = a1; b = b1; c = c1;
     hit1 = hit2; id1 = id2; pos1_1 = pos1_2;
   }
+  flush_sums();
 }
 
 }  // namespace
@@ -311,6 +328,10 @@ extern "C" int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state,
   hipStream_t stream = (hipStream_t)stream_;
   const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
   if (N <= 0) return SCORP_OK;
+  if ((uint64_t)N * kAccStride > 0xFFFFFFFFull) {   // the blend kernel addresses accumulators with 32-bit float offsets
+    set_error("num_gaussians %d above the %llu the backward supports", N, 0xFFFFFFFFull / kAccStride);
+    return SCORP_ERR_INVALID;
+  }
   const StateLayout L(N, W, H);
   const PairLayout P(capacity);
   const size_t need = scorp_gs3d_backward_scratch_bytes(N);
