@@ -224,6 +224,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+    t_host = time.perf_counter() - t0          # launches enqueued (diagnostic: ~ms_per_step means the host is the bottleneck)
     PairPolicy.drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -288,6 +289,7 @@ def main():
                        "pairs_per_view_D": round(D_mean), "D_over_N": round(D_mean / N, 3), "visible": round(Nvis_mean),
                        "parallelism": f"view-sharded replicas x{world}"},
             "roofline": roof,
+            "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
             "view_hbm": {"algorithmic_bytes_per_view": int(B_view), "achieved_GBs": round(value / world * B_view / 1e9, 1),
                          "frac_of_8TBs": round(value / world * B_view / 8e12, 5)},
             "kernels": kernels,

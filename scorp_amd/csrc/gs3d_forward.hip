@@ -320,6 +320,115 @@ sort_tiles_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// K4, lists of up to 1024 entries (nearly all of them): the same bitonic network with the keys IN REGISTERS.  Thread t
+// owns the four consecutive keys 4t .. 4t+3, a wave 256 consecutive keys.  Every comparator of the network pairs
+// element e with e ^ X (X = k - 1 for the flip step of level k, X = j for a half-cleaner), i.e. lane ^ (X / 4) with the
+// registers in the same (cleaner) or reversed (flip) order, and the lower index keeps the minimum:
+//   * X < 4                : inside a thread;
+//   * lane masks 1,2,3,7,8,15: one DPP move per dword (quad_perm / row_half_mirror / row_ror:8 / row_mirror), 4 = 7 o 3;
+//   * lane masks 16,31,32,63 : ds_bpermute (the LDS crossbar, no LDS memory);
+//   * X >= 256             : between waves, through LDS (2 stages of 45 for 512 keys, 5 of 55 for 1024).
+// No LDS round trip and no barrier for all the rest, which the LDS version paid per stage.  Waves whose keys are all
+// padding leave at once (the network of size P never touches indices >= P).
+// ---------------------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ uint32_t xor_lane32(uint32_t v, int bperm_addr) {
+  if constexpr (M == 1) return __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  else if constexpr (M == 3) return __builtin_amdgcn_update_dpp(0u, v, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+  else if constexpr (M == 7) return __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  else if constexpr (M == 15) return __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xF, 0xF, false); // row_mirror
+  else if constexpr (M == 8) return __builtin_amdgcn_update_dpp(0u, v, 0x128, 0xF, 0xF, false);  // row_ror:8
+  else if constexpr (M == 4) return xor_lane32<7>(xor_lane32<3>(v, 0), 0);
+  else return (uint32_t)__builtin_amdgcn_ds_bpermute(bperm_addr, (int)v);                          // 16, 31, 32, 63
+}
+template <int M>
+__device__ __forceinline__ uint64_t xor_lane64(uint64_t v, int bperm_addr) {
+  const uint32_t lo = xor_lane32<M>((uint32_t)v, bperm_addr), hi = xor_lane32<M>((uint32_t)(v >> 32), bperm_addr);
+  return ((uint64_t)hi << 32) | lo;
+}
+// one network stage between lanes: element (lane, r) against (lane ^ M, FLIP ? 3 - r : r); keep_min per lane
+template <int M, bool FLIP>
+__device__ __forceinline__ void lane_stage(uint64_t (&k)[4], bool keep_min, int lane) {
+  const int addr = ((lane ^ M) & 63) << 2;
+  uint64_t p[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) p[r] = xor_lane64<M>(k[FLIP ? 3 - r : r], addr);
+#pragma unroll
+  for (int r = 0; r < 4; r++) k[r] = ((p[r] < k[r]) == keep_min) ? p[r] : k[r];
+}
+// one network stage between waves, through LDS: element e against e ^ X (X >= 256; FLIP: X = K - 1)
+template <bool FLIP>
+__device__ __forceinline__ void cross_stage(uint64_t (&k)[4], uint64_t *s_x, uint32_t base, uint32_t X, bool keep_min) {
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  u64x2 *mine = reinterpret_cast<u64x2 *>(s_x + base);
+  u64x2 w0, w1;
+  w0.x = k[0]; w0.y = k[1]; w1.x = k[2]; w1.y = k[3];
+  mine[0] = w0; mine[1] = w1;
+  __syncthreads();
+  const u64x2 *theirs = reinterpret_cast<const u64x2 *>(s_x + (base ^ (X & ~3u)));
+  const u64x2 t0 = theirs[0], t1 = theirs[1];
+  const uint64_t q[4] = {t0.x, t0.y, t1.x, t1.y};
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint64_t p = q[FLIP ? 3 - r : r];
+    k[r] = ((p < k[r]) == keep_min) ? p : k[r];
+  }
+  __syncthreads();   // everyone has read before the next cross stage overwrites
+}
+__device__ __forceinline__ void thread_tail(uint64_t (&k)[4]) {   // j = 2, j = 1 of any level
+  ce(k[0], k[2]); ce(k[1], k[3]);
+  ce(k[0], k[1]); ce(k[2], k[3]);
+}
+// level K of the network (flip, half-cleaners down to j = 4, then the in-thread tail), lane masks as template constants
+template <int K>
+__device__ __forceinline__ void sort_level(uint64_t (&k)[4], uint64_t *s_x, uint32_t base, int lane) {
+  constexpr int FM = K / 4 - 1;   // lane mask of the flip
+  if constexpr (FM < 64) lane_stage<FM, true>(k, (lane & (K / 8)) == 0, lane);
+  else cross_stage<true>(k, s_x, base, (uint32_t)K - 1u, (base & (K / 2)) == 0);
+#define SCORP_CLEAN(J)                                                                                   \
+  if constexpr (K / 4 >= (J) && (J) >= 4) {                                                              \
+    if constexpr ((J) / 4 < 64) lane_stage<((J) / 4 < 64 ? (J) / 4 : 1), false>(k, (lane & ((J) / 4)) == 0, lane); \
+    else cross_stage<false>(k, s_x, base, (uint32_t)(J), (base & (J)) == 0);                             \
+  }
+  SCORP_CLEAN(256) SCORP_CLEAN(128) SCORP_CLEAN(64) SCORP_CLEAN(32) SCORP_CLEAN(16) SCORP_CLEAN(8) SCORP_CLEAN(4)
+#undef SCORP_CLEAN
+  thread_tail(k);
+}
+
+__global__ void __launch_bounds__(256)
+sort_tiles_reg_kernel(const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
+                      uint32_t *__restrict__ point_list, uint32_t capacity) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_x[1024];
+  const int tile = blockIdx.x;
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t n = end - beg;
+  if (n == 0 || n > 1024) return;
+  const uint32_t base = 4 * threadIdx.x;
+  uint32_t P = 4;
+  while (P < n) P <<= 1;
+  if (256u * (threadIdx.x >> 6) >= P) return;   // whole waves of padding leave (never single lanes: lanes exchange)
+  const int lane = threadIdx.x & 63;
+  constexpr uint64_t kInf = ~0ull;
+  uint64_t k[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) k[r] = base + r < n ? keys[beg + base + r] : kInf;
+  ce(k[0], k[1]); ce(k[2], k[3]);                          // k = 2
+  ce(k[0], k[3]); ce(k[1], k[2]); ce(k[0], k[1]); ce(k[2], k[3]);   // k = 4: flip, j = 1
+  if (P >= 8) sort_level<8>(k, s_x, base, lane);
+  if (P >= 16) sort_level<16>(k, s_x, base, lane);
+  if (P >= 32) sort_level<32>(k, s_x, base, lane);
+  if (P >= 64) sort_level<64>(k, s_x, base, lane);
+  if (P >= 128) sort_level<128>(k, s_x, base, lane);
+  if (P >= 256) sort_level<256>(k, s_x, base, lane);
+  if (P >= 512) sort_level<512>(k, s_x, base, lane);
+  if (P >= 1024) sort_level<1024>(k, s_x, base, lane);
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+    if (base + r < n) point_list[beg + base + r] = (uint32_t)k[r];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // K5: front-to-back blend with ONE WAVE PER 8x8 BLOCK as the unit (64-thread workgroups, no workgroup barriers), the
 // forward twin of blend_backward_wave_kernel: the wave walks the tile's list front to back 32 entries at a time, each
 // lane gathers one record and runs the exact conic-vs-block test, survivors are compacted into a per-wave LDS ring,
@@ -538,7 +647,7 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
   SCORP_KERNEL_CHECK("scatter_pairs", debug, stream);
   {
     ProfScope prof(kKSortTiles, stream);
-    sort_tiles_kernel<1024, 0><<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity, kSortLds);
+    sort_tiles_reg_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity);
     sort_tiles_kernel<kSortLds, 1024><<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity, kSortLds);
   }
   SCORP_KERNEL_CHECK("sort_tiles", debug, stream);

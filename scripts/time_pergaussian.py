@@ -52,4 +52,4 @@ torch.cuda.synchronize()
 k = _C.prof_collect()
 _C.prof_enable(False)
 print(scene, os.path.basename(os.environ.get("SCORP_GS_LIB", "default")),
-      {n: round(1e3 * ms / max(cnt, 1), 1) for n, (ms, cnt) in k.items() if "preprocess" in n and cnt})
+      {n: round(1e3 * ms / max(cnt, 1), 1) for n, (ms, cnt) in k.items() if ("preprocess" in n or "blend" in n) and cnt})

@@ -192,6 +192,30 @@ def test_stage_parity_geom_and_tile_lists(name, dev):
     assert dropped == o.num_pairs - r["n"]
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 9, 16, 17, 33, 64, 65, 100, 128, 129, 255, 256, 257, 511, 512, 513, 1000,
+                               1023, 1024, 1025, 1500])
+def test_tile_sort_every_network_size(n, dev):
+    """One 16x16 tile, n large splats all over it: the tile's list must be the splats ordered by (depth bits, index),
+    bit-exact, for every size of the sorting network (in registers up to 1024 entries, in LDS beyond)."""
+    kw, _ = make_case(n, 16, 16, 0, 100 + n, log_scale=math.log(0.5), log_scale_std=0.1, precomp_color=True)
+    kw["opacities"] = np.full_like(kw["opacities"], 0.9)
+    r = _raw_forward(kw, dev)
+    from scorp_amd import _C
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    N = r["N"]
+    xy = np.zeros((N, 2), np.float32); depth = np.zeros(N, np.float32); conic = np.zeros((N, 4), np.float32)
+    rgb = np.zeros((N, 3), np.float32); rect = np.zeros((N, 4), np.int32)
+    _C.check(r["L"].scorp_gs3d_debug_geom(r["state"].data_ptr(), N, 16, 16, p(xy), p(depth), p(conic), p(rgb), p(rect), r["stream"]), "debug_geom")
+    ts = np.zeros(2, np.uint32); pl = np.zeros(max(r["n"], 1), np.uint32)
+    _C.check(r["L"].scorp_gs3d_debug_tiles(r["state"].data_ptr(), r["pairs"].data_ptr(), r["cap"], N, 16, 16, p(ts), p(pl), r["stream"]), "debug_tiles")
+    mine = pl[ts[0]:ts[1]].astype(np.int64)
+    assert len(mine) == r["n"] and len(mine) >= 0.8 * n, (len(mine), n)      # nearly everything lands in the tile
+    key = (depth.view(np.uint32).astype(np.uint64) << np.uint64(32)) | np.arange(N, dtype=np.uint64)
+    assert len(np.unique(mine)) == len(mine)
+    np.testing.assert_array_equal(mine, mine[np.argsort(key[mine], kind="stable")])
+
+
+
 def test_empty_and_fully_culled(dev):
     # N = 0
     kw, _ = make_case(4, 48, 32, 0, 1, bg=(0.3, 0.6, 0.9))
