@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 and collectives go through CPU copies (use with --backend gloo)")
+    ap.add_argument("--autograd", action="store_true",
+                    help="step = render() + fused_l1_ssim_loss() + loss.backward() through torch autograd (the reference's call "
+                         "pattern) instead of the single-call scorp_gs3d_train_view; same kernels, more host work per view")
     ap.add_argument("--unfused", action="store_true", help="reference call-site convention: torch activations + cat per view")
     ap.add_argument("--spatial-sort", action="store_true", help="GaussianModel.sort_spatially() first: Gaussians stored along a Z-order curve (not the default)")
     args = ap.parse_args()
@@ -193,8 +196,17 @@ def main():
     Ds = list(R.LAST_NUM_PAIRS_LOG[-len(my_cams):])
     D_mean, Nvis_mean = float(np.mean(Ds)), float(np.mean(Nvis))
 
+    fused_view = not surfels and not args.autograd and not args.unfused
+    if fused_view:
+        from scorp_amd.train_view import train_view
+
     def step(i):
         cam, gt = my_cams[i % len(my_cams)], gts[i % len(my_cams)]
+        if fused_view:      # render + loss + backward enqueued by one library call (scorp_gs3d_train_view): same kernels
+            loss = train_view(cam, model, pipe, bg, gt, 0.2)["loss"]
+            for p in params:
+                p.grad = None
+            return loss
         out = render(cam, model, pipe, bg)
         loss = fused_l1_ssim_loss(out["render"], gt, 0.2)
         if surfels:                                   # train_2dgs.py:142-150: normal consistency + depth distortion
@@ -290,6 +302,7 @@ def main():
                        "parallelism": f"view-sharded replicas x{world}"},
             "roofline": roof,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
+            "step_call": "scorp_gs3d_train_view" if fused_view else "render + fused_l1_ssim_loss + autograd backward",
             "view_hbm": {"algorithmic_bytes_per_view": int(B_view), "achieved_GBs": round(value / world * B_view / 1e9, 1),
                          "frac_of_8TBs": round(value / world * B_view / 8e12, 5)},
             "kernels": kernels,

@@ -219,6 +219,43 @@ int scorp_loss_l1_ssim_backward(const float *img, const float *gt, const float *
                                 int32_t width, float lambda_dssim, const void *workspace, const float *grad_out,
                                 float *grad_img, scorp_stream_t stream);
 
+/* ---- one training view in one call (train_3dgs.py:88-150 minus the optimizer: render, photometric loss, backward) ----
+ * Enqueues, on `stream` and without any host synchronisation, exactly the sequence a caller of the entry points above
+ * would issue for one iteration of the reference's training loop:
+ *   scorp_gs3d_preprocess -> scorp_gs3d_render -> scorp_gs3d_render_tail -> scorp_loss_l1_ssim_forward ->
+ *   scorp_loss_l1_ssim_backward (upstream gradient 1) -> scorp_gs3d_backward (dL_ddepth = dL_dalpha = NULL).
+ * It exists because at ~1 ms of device work per view the host side (Python glue, autograd bookkeeping, a dozen FFI
+ * calls) is of the same size: one call keeps the GPU the bottleneck whatever the host is doing.  Every buffer is the
+ * caller's, sized as for the separate calls; `capacity` pairs must have been reserved (check with
+ * scorp_gs3d_check_overflow afterwards, as for scorp_gs3d_render without scorp_gs3d_num_pairs).
+ * out_depth_raw is the rasterizer's un-normalised depth, out_depth = nan_to_num(depth / alpha) as render() returns
+ * it; out_depth / out_visible may both be NULL (the tail is skipped then). */
+typedef struct ScorpGs3dTrainView {
+  const ScorpGs3dInputs *in;
+  int32_t *out_radii;            /* [N] */
+  void *state;                   /* scorp_gs3d_state_bytes(), 256-byte aligned */
+  size_t state_bytes;
+  void *pairs;                   /* scorp_gs3d_pairs_bytes(capacity) */
+  uint64_t capacity;
+  float *out_color;              /* [3,H,W] */
+  float *out_depth_raw;          /* [H,W] */
+  float *out_alpha;              /* [H,W] */
+  float *out_depth;              /* [H,W] or NULL */
+  uint8_t *out_visible;          /* [N] bytes or NULL */
+  const float *gt;               /* [3,H,W] */
+  const float *mask;             /* [H,W] or NULL */
+  float lambda_dssim;
+  float _pad;
+  float *out_loss3;              /* device: {loss, l1, ssim} */
+  void *loss_workspace;          /* scorp_loss_workspace_bytes(3, H, W) */
+  size_t loss_workspace_bytes;
+  float *grad_color;             /* [3,H,W] scratch: d loss / d color */
+  const ScorpGs3dGrads *grads;   /* gradients w.r.t. the inputs, as for scorp_gs3d_backward */
+  void *backward_scratch;        /* scorp_gs3d_backward_scratch_bytes(N) */
+  size_t backward_scratch_bytes;
+} ScorpGs3dTrainView;
+int scorp_gs3d_train_view(const ScorpGs3dTrainView *view, scorp_stream_t stream);
+
 /* ---- simple_knn replacement ----
  * out[i] = mean of the squared distances from point i to its 3 nearest other points, as
  * `simple_knn._C.distCUDA2(points)` (gs3dgs/scene/gaussian_model.py:177).  xyz[N,3], out[N]. */

@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 
 from .fused_loss import fused_l1_ssim_loss
+from .rasterizer3d import PairPolicy
 from .loss import depth_losses, isotropic_loss, psnr
 from .parallel import average_gradients, world
 from .renderer import render
@@ -47,7 +48,7 @@ def _sync_densification_stats(gaussians):
 
 def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteration, scene_extent=4.0, densify=True,
                        render_fn=render, loss_fn=fused_l1_ssim_loss, data_parallel=False, gt_depth=None, gt_depth_est=None,
-                       surfels=False):
+                       surfels=False, fused_view=False):
     """Returns (loss tensor, render package). Mirrors train_3dgs.py:74-193 for one camera.  With `data_parallel` the
     caller hands each rank a different camera; gradients are averaged over ranks before the optimizer step and the
     densification statistics are reduced before they are used, so the replicas stay bit-identical."""
@@ -55,23 +56,33 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
     bg = torch.rand(3, device=background.device) if opt.random_background else background
-    pkg = render_fn(cam, gaussians, pipe, bg)
-    loss = loss_fn(pkg["render"], gt_image, opt.lambda_dssim)
-    # depth terms and the isotropic regulariser start together (train_3dgs.py:109-150, train_2dgs.py:95-140)
-    if iteration > getattr(opt, "depth_from_iter", 1 << 30):
-        if gt_depth is not None or gt_depth_est is not None:
-            loss = loss + depth_losses(pkg["render_depth"], iteration, opt, gt_depth, gt_depth_est)
-        if getattr(opt, "lambda_isotropic", 0.0) > 0:
-            loss = loss + opt.lambda_isotropic * isotropic_loss(gaussians.get_scaling)
-    if surfels:   # train_2dgs.py:142-150: normal consistency after 7000 iterations, depth distortion after 3000
-        from .renderer2d import fused_surfel_regularizers, surfel_regularizers
-        lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
-        lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
-        if lambda_normal > 0 or lambda_dist > 0:
-            reg = fused_surfel_regularizers if getattr(pkg, "allmap", None) is not None else surfel_regularizers
-            normal_loss, dist_loss = reg(pkg, lambda_normal, lambda_dist)
-            loss = loss + normal_loss + dist_loss
-    loss.backward()
+    extra_terms = iteration > getattr(opt, "depth_from_iter", 1 << 30) and (
+        gt_depth is not None or gt_depth_est is not None or getattr(opt, "lambda_isotropic", 0.0) > 0)
+    if (fused_view and not surfels and not extra_terms and render_fn is render and loss_fn is fused_l1_ssim_loss
+            and getattr(pipe, "fused_activations", False)):
+        # plain photometric iteration: render + loss + backward enqueued by ONE library call (train_view.py); same
+        # kernels and results, no autograd graph.  The pair buffer is reserved, the caller drains (see train()).
+        from .train_view import train_view
+        pkg = train_view(cam, gaussians, pipe, bg, gt_image, opt.lambda_dssim)
+        loss = pkg["loss"]
+    else:
+        pkg = render_fn(cam, gaussians, pipe, bg)
+        loss = loss_fn(pkg["render"], gt_image, opt.lambda_dssim)
+        # depth terms and the isotropic regulariser start together (train_3dgs.py:109-150, train_2dgs.py:95-140)
+        if iteration > getattr(opt, "depth_from_iter", 1 << 30):
+            if gt_depth is not None or gt_depth_est is not None:
+                loss = loss + depth_losses(pkg["render_depth"], iteration, opt, gt_depth, gt_depth_est)
+            if getattr(opt, "lambda_isotropic", 0.0) > 0:
+                loss = loss + opt.lambda_isotropic * isotropic_loss(gaussians.get_scaling)
+        if surfels:   # train_2dgs.py:142-150: normal consistency after 7000 iterations, depth distortion after 3000
+            from .renderer2d import fused_surfel_regularizers, surfel_regularizers
+            lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
+            lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
+            if lambda_normal > 0 or lambda_dist > 0:
+                reg = fused_surfel_regularizers if getattr(pkg, "allmap", None) is not None else surfel_regularizers
+                normal_loss, dist_loss = reg(pkg, lambda_normal, lambda_dist)
+                loss = loss + normal_loss + dist_loss
+        loss.backward()
     with torch.no_grad():
         if data_parallel:
             average_gradients([g["params"][0] for g in gaussians.optimizer.param_groups])
@@ -116,6 +127,10 @@ def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, backgr
         loss, _ = training_iteration(gaussians, cameras[k], gt_images[k], opt, pipe, background, it,
                                      data_parallel=data_parallel and w > 1, **kw)
         losses.append(loss.detach())
+        if kw.get("fused_view") and it % 32 == 0:
+            PairPolicy.drain()   # fused views reserve their pair buffer: verify (raises on overflow, grows the reservation)
+    if kw.get("fused_view"):
+        PairPolicy.drain()
     return [float(l) for l in losses]
 
 

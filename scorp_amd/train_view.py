@@ -1,0 +1,98 @@
+"""One training view in one library call: `render()` + `0.8 L1 + 0.2 (1 - SSIM)` + `loss.backward()`.
+
+`train_view(camera, pc, pipe, bg, gt_image)` does what lines 88-150 of the reference's train_3dgs.py do for the plain
+photometric loss (render -> l1_loss / ssim -> loss.backward()), with the same kernels as `renderer.render` +
+`fused_loss.fused_l1_ssim_loss` + autograd, but enqueued by a single C call (`scorp_gs3d_train_view`): at ~1 ms of
+device work per view the Python glue, autograd bookkeeping and a dozen ctypes calls cost about as much host time as
+the GPU needs, and any hiccup of the host shows up as idle GPU.  No autograd graph is built; the gradients land in the
+`.grad` of the model's six raw leaves (accumulating, like backward()), the screen-space gradient in
+`out["viewspace_points"].grad` (what add_densification_stats reads, gaussian_model.py:603-605).
+
+The pair buffer is always "reserved" (no host synchronisation): sized from `PairPolicy.reserve`, verified by
+`PairPolicy.drain()` — call it before trusting a batch of views, as after `render()` in "reserve" mode.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _C
+from .rasterizer3d import GaussianRasterizationSettings, PairPolicy, _inputs_struct, _prep, _ptr, _stream
+
+
+def _accumulate(p, g):
+    if p.grad is None:
+        p.grad = g
+    else:
+        p.grad += g
+
+
+def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2, mask=None, scaling_modifier=1.0):
+    """Returns the dict of `renderer.render` plus "loss", "l1", "ssim" (0-d views of one device tensor); parameter
+    gradients are accumulated into `pc`'s leaves.  Needs the model's raw leaves (fused activations)."""
+    L = _C.lib()
+    xyz = pc.get_xyz
+    if not xyz.is_cuda:
+        raise RuntimeError("train_view needs GPU tensors (scorp_amd has no CPU path)")
+    f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw = pc.raw_leaves()
+    leaves = (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw)
+    dev = xyz.device
+    w, h = viewpoint_camera.resolution
+    W, H, N = int(w), int(h), xyz.shape[0]
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
+        tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False,
+        debug=bool(getattr(pipe, "debug", False)))
+    t = [_prep(x.detach(), n) for x, n in zip(leaves, ("means3D", "features_dc", "features_rest", "opacity", "scaling", "rotation"))]
+    keep = []
+    args = _inputs_struct(settings, t[0], t[1], None, t[3], t[4], t[5], None, keep, t[2], 7)
+    gt = _prep(gt_image, "gt_image")
+    if mask is not None:
+        mask = _prep(mask.expand(1, H, W), "mask")
+    new = lambda shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=dev)
+    color, depth_raw, alpha, depth = new((3, H, W)), new((1, H, W)), new((1, H, W)), new((1, H, W))
+    radii, visible = new((N,), torch.int32), new((N,), torch.uint8)
+    loss3, grad_color = new((3,)), new((3, H, W))
+    state_bytes = L.scorp_gs3d_state_bytes(N, W, H)
+    state = new((state_bytes,), torch.uint8)
+    if PairPolicy.reserve <= 0:
+        PairPolicy.reserve = max(4 * N, 1 << 20)
+    capacity = PairPolicy.reserve
+    PairPolicy._pending.append(state)
+    pairs = new((L.scorp_gs3d_pairs_bytes(capacity),), torch.uint8)
+    ws_bytes = L.scorp_loss_workspace_bytes(3, H, W)
+    ws = new((ws_bytes,), torch.uint8)
+    scratch_bytes = L.scorp_gs3d_backward_scratch_bytes(N)
+    scratch = new((scratch_bytes,), torch.uint8)
+    need = [p.requires_grad for p in leaves]          # frozen leaves (post-refine) get no gradient buffer: NULL = not wanted
+    need[1] = need[2] = need[1] or need[2]            # the SH gradient is written as a whole
+    g = [torch.empty_like(x) if n else None for x, n in zip(t, need)]
+    g_means2D = new((N, 3))
+    grads = _C.ScorpGs3dGrads()
+    grads.means3D, grads.means2D, grads.shs, grads.shs_rest = _ptr(g[0]), _ptr(g_means2D), _ptr(g[1]), _ptr(g[2])
+    grads.opacities, grads.scales, grads.rotations = _ptr(g[3]), _ptr(g[4]), _ptr(g[5])
+    v = _C.ScorpGs3dTrainView()
+    v.inputs = ctypes.addressof(args)
+    v.out_radii, v.state, v.state_bytes, v.pairs, v.capacity = radii.data_ptr(), state.data_ptr(), state_bytes, pairs.data_ptr(), capacity
+    v.out_color, v.out_depth_raw, v.out_alpha = color.data_ptr(), depth_raw.data_ptr(), alpha.data_ptr()
+    v.out_depth, v.out_visible = depth.data_ptr(), visible.data_ptr()
+    v.gt, v.mask, v.lambda_dssim = gt.data_ptr(), (None if mask is None else mask.data_ptr()), float(lambda_dssim)
+    v.out_loss3, v.loss_workspace, v.loss_workspace_bytes = loss3.data_ptr(), ws.data_ptr(), ws_bytes
+    v.grad_color, v.grads = grad_color.data_ptr(), ctypes.addressof(grads)
+    v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes
+    _C.check(L.scorp_gs3d_train_view(ctypes.byref(v), _stream()), "scorp_gs3d_train_view")
+    for p, gp in zip(leaves, g):
+        if p.requires_grad:
+            _accumulate(p, gp.view_as(p))
+    return {"render": color, "viewspace_points": _ViewspaceGrad(g_means2D), "visibility_filter": visible.view(torch.bool),
+            "radii": radii, "render_depth": depth, "render_alpha": alpha, "loss": loss3[0], "l1": loss3[1], "ssim": loss3[2]}
+
+
+class _ViewspaceGrad:
+    """What the training loop uses of `viewspace_points`: its `.grad` ([N,3], gaussian_model.py:603-605)."""
+    __slots__ = ("grad",)
+
+    def __init__(self, grad):
+        self.grad = grad
