@@ -43,7 +43,7 @@ class PairPolicy:
     mode = "exact"
     slack = 1.25
     reserve = 0          # pairs
-    _pending = []        # state tensors whose overflow flag has not been read yet
+    _pending = []        # copies of the 64-byte state headers whose overflow flag has not been read yet
 
     @classmethod
     def drain(cls):
@@ -195,10 +195,13 @@ def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opaciti
         if PairPolicy.reserve <= 0:
             PairPolicy.reserve = max(4 * N, 1 << 20)
         capacity = PairPolicy.reserve
-        PairPolicy._pending.append(state)
     pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
     _C.check(L.scorp_gs3d_render(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(depth),
                                  _ptr(alpha), stream), "scorp_gs3d_render")
+    if PairPolicy.mode != "exact":
+        # what drain() will look at: a copy of the 64-byte StateHeader the render just filled in (pair count, overflow
+        # flag) - not the state itself, or every pending view would pin ~100 MB of device memory until the drain
+        PairPolicy._pending.append(state[:64].clone())
     ctx.settings, ctx.capacity = settings, capacity
     ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward: the kernels skip those terms
     return color, radii, depth, alpha, state, pairs, keep

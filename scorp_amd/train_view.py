@@ -60,7 +60,6 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     if PairPolicy.reserve <= 0:
         PairPolicy.reserve = max(4 * N, 1 << 20)
     capacity = PairPolicy.reserve
-    PairPolicy._pending.append(state)
     pairs = new((L.scorp_gs3d_pairs_bytes(capacity),), torch.uint8)
     ws_bytes = L.scorp_loss_workspace_bytes(3, H, W)
     ws = new((ws_bytes,), torch.uint8)
@@ -83,6 +82,7 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     v.grad_color, v.grads = grad_color.data_ptr(), ctypes.addressof(grads)
     v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes
     _C.check(L.scorp_gs3d_train_view(ctypes.byref(v), _stream()), "scorp_gs3d_train_view")
+    PairPolicy._pending.append(state[:64].clone())    # the StateHeader only (see rasterizer3d._forward_common)
     for p, gp in zip(leaves, g):
         if p.requires_grad:
             _accumulate(p, gp.view_as(p))
