@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 and collectives go through CPU copies (use with --backend gloo)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="views in flight per GPU, each on its own HIP stream (default 1 = one view at a time, as the reference trains)")
     ap.add_argument("--autograd", action="store_true",
                     help="step = render() + fused_l1_ssim_loss() + loss.backward() through torch autograd (the reference's call "
                          "pattern) instead of the single-call scorp_gs3d_train_view; same kernels, more host work per view")
@@ -200,8 +202,18 @@ def main():
     if fused_view:
         from scorp_amd.train_view import train_view
 
+    # --streams S > 1: S views in flight on S HIP streams (views are independent given the parameters: the batch-of-views
+    # form of training, or multi-view evaluation); the default, 1, is the reference's one-view-at-a-time loop
+    side_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+
     def step(i):
         cam, gt = my_cams[i % len(my_cams)], gts[i % len(my_cams)]
+        if side_streams is not None:
+            with torch.cuda.stream(side_streams[i % args.streams]):
+                loss = train_view(cam, model, pipe, bg, gt, 0.2)["loss"]
+                for p in params:
+                    p.grad = None
+            return loss
         if fused_view:      # render + loss + backward enqueued by one library call (scorp_gs3d_train_view): same kernels
             loss = train_view(cam, model, pipe, bg, gt, 0.2)["loss"]
             for p in params:
@@ -303,6 +315,7 @@ def main():
             "roofline": roof,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
             "step_call": "scorp_gs3d_train_view" if fused_view else "render + fused_l1_ssim_loss + autograd backward",
+            "views_in_flight": args.streams,
             "view_hbm": {"algorithmic_bytes_per_view": int(B_view), "achieved_GBs": round(value / world * B_view / 1e9, 1),
                          "frac_of_8TBs": round(value / world * B_view / 8e12, 5)},
             "kernels": kernels,

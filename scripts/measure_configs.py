@@ -39,7 +39,9 @@ def main():
     from scorp_amd.align import render_views, rotation_sweep
     from scorp_amd.fused_loss import fused_l1_ssim_loss
     from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd import rasterizer3d as R
     from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.train_view import train_view
     from scorp_amd.renderer import render
     from scorp_amd.synthetic import SCENES, make_gaussians, ring_cameras
     from scorp_amd.train import PipelineParams, training_iteration
@@ -70,6 +72,21 @@ def main():
     n = 20 if args.quick else 100
     dt = sync_time(train_it, n)
     print(json.dumps({"config": "#2 train_3dgs loop, S2: 500k Gaussians 1600x1200 SH3, render+L1/SSIM+backward+FusedAdam, exact pair sizing (1 sync/iter)",
+                      "iterations_per_s": round(1 / dt, 1), "ms_per_iteration": round(dt * 1e3, 3)}), flush=True)
+    # same loop with the one-call view (scorp_gs3d_train_view) and a reserved pair buffer: no host sync in the iteration
+    PairPolicy.reserve = int(max(R.LAST_NUM_PAIRS_LOG[-8:]) * 1.25) + 1024
+
+    def train_it_fused(i):
+        it["n"] += 1
+        if it["n"] % 1000 == 0:
+            it["n"] += 1
+        training_iteration(m, cams[i % 8], gts[i % 8], opt, pipe, bg, it["n"], densify=False, fused_view=True)
+    for i in range(5):
+        train_it_fused(i)
+    PairPolicy.drain()
+    dt = sync_time(train_it_fused, n)
+    PairPolicy.drain()
+    print(json.dumps({"config": "#2 (one-call view) same loop through scorp_gs3d_train_view + FusedAdam, reserved pair buffer (no sync in the iteration)",
                       "iterations_per_s": round(1 / dt, 1), "ms_per_iteration": round(dt * 1e3, 3)}), flush=True)
     del m, gts
 
@@ -120,6 +137,21 @@ def main():
     n = 20 if args.quick else 200
     dt = sync_time(refine_it, n)
     print(json.dumps({"config": "#4 post_refine loop: 4 x 100k SH0 objects as ONE model, 1600x1200, masked L1+SSIM, colours only + FusedAdam",
+                      "iterations_per_s": round(1 / dt, 1), "ms_per_iteration": round(dt * 1e3, 3),
+                      "s_per_800_iterations": round(800 * dt, 2)}), flush=True)
+    PairPolicy.reserve = int(max(R.LAST_NUM_PAIRS_LOG[-8:]) * 1.25) + 1024
+
+    def refine_it_fused(i):
+        train_view(cams[i % 8], m, pipe, bg, gts[i % 8], 0.2, mask=masks[i % 8])
+        with torch.no_grad():
+            m.optimizer.step()
+            m.optimizer.zero_grad(set_to_none=True)
+    for i in range(5):
+        refine_it_fused(i)
+    PairPolicy.drain()
+    dt = sync_time(refine_it_fused, n)
+    PairPolicy.drain()
+    print(json.dumps({"config": "#4 (one-call view) same loop through scorp_gs3d_train_view (frozen leaves get no gradient), reserved pair buffer",
                       "iterations_per_s": round(1 / dt, 1), "ms_per_iteration": round(dt * 1e3, 3),
                       "s_per_800_iterations": round(800 * dt, 2)}), flush=True)
 
