@@ -49,6 +49,22 @@ def test_struct_layout_matches_header():
     from scorp_amd import _C
     assert ctypes.sizeof(_C.ScorpGs3dInputs) == 40 + 12 * 8 + 8   # 10 ints/floats, 12 pointers, raw_params + padding
     assert ctypes.sizeof(_C.ScorpGs3dGrads) == 9 * 8
+    assert ctypes.sizeof(_C.ScorpGs3dTrainView) == 13 * 8 + 2 * 4 + 7 * 8   # see the struct in include/scorp_gs.h
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/scorp_gs.h must be consumable from C (the boundary is a C ABI), and the structs there must have the
+    sizes the ctypes mirror assumes."""
+    import os, subprocess
+    from scorp_amd import _C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include "scorp_gs.h"\nint main(void) { printf("%zu %zu %zu\\n", '
+                   'sizeof(ScorpGs3dInputs), sizeof(ScorpGs3dGrads), sizeof(ScorpGs3dTrainView)); return 0; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    a, b, c = (int(x) for x in subprocess.check_output([str(exe)]).split())
+    assert (a, b, c) == (ctypes.sizeof(_C.ScorpGs3dInputs), ctypes.sizeof(_C.ScorpGs3dGrads), ctypes.sizeof(_C.ScorpGs3dTrainView))
 
 
 def test_shim_packages_expose_reference_names(built_lib):
