@@ -296,9 +296,20 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch (see profiles/README.md)
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get(args.scene, {}).get(dom)
+            # the limiter the HBM figure cannot show: VALU issue slots.  wave64 VALU instructions per launch from
+            # the SQ counter pass (profiles/valu.json), 4 cycles each on one of 256 CUs x 4 SIMDs at 2.4 GHz
+            valu = None
+            vpath = os.path.join(ROOT, "profiles", "valu.json")
+            if os.path.exists(vpath):
+                vi = json.load(open(vpath)).get(args.scene, {}).get(dom)
+                if vi:
+                    slots = kernels[dom]["avg_us"] * 1e-6 * 2.4e9 * 256 * 4
+                    valu = {"valu_insts_per_launch": vi["valu_insts"], "issue_slot_frac": round(vi["valu_insts"] * 4 / slots, 4),
+                            "note": "wave64 VALU instructions x 4 cycles / (launch duration x 1024 SIMDs x 2.4 GHz)"}
             roof = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(kernels[dom]["GBs"] / HBM_PEAK_GBS, 5), traffic=traffic,
                         avg_launch_us=kernels[dom]["avg_us"], algorithmic_bytes=int(kernel_algorithmic_bytes(dom, N, Nvis_mean, K, HW, D_mean)),
+                        valu=valu,
                         note="dominant kernel timed live in the timed region; the other kernels' averages come from the "
                              "bracketed warm-up steps. Blend kernels are VALU-issue bound, not HBM bound (DESIGN.md)")
         B_view = N * 720 + HW * 40 + 28 * D_mean
