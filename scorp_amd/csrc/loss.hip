@@ -71,16 +71,32 @@ ssim_l1_forward_kernel(const float *__restrict__ img, const float *__restrict__ 
   const int ch = lt.ch, x0 = lt.x0, y0 = lt.y0;
   const size_t HW = (size_t)H * W;
   const float *xp = img + ch * HW, *yp = gt + ch * HW;
-  for (int i = threadIdx.x; i < kLP * kLP; i += 256) {
-    const int r = i / kLP, c = i % kLP;
-    const int gy = y0 + r - kLH, gx = x0 + c - kLH;
-    float xv = 0.0f, yv = 0.0f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      const size_t p = (size_t)gy * W + gx;
-      const float m = mask ? mask[p] : 1.0f;
-      xv = xp[p] * m; yv = yp[p] * m;
+  {
+    // The patch: 1764 elements = 7 per thread.  All of a thread's loads leave together, from clamped (always valid)
+    // addresses, and out-of-image elements are zeroed by a select afterwards: as a loop with the bounds test around the
+    // loads this was seven dependent round trips to memory per workgroup - most of its life.
+    constexpr int kPer = (kLP * kLP + 255) / 256;
+    float xv[kPer], yv[kPer], mv[kPer];
+    bool in[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int i = min(threadIdx.x + 256 * j, kLP * kLP - 1);
+      const int r = i / kLP, c = i - r * kLP;
+      const int gy = y0 + r - kLH, gx = x0 + c - kLH;
+      in[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const size_t p = (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+      xv[j] = xp[p]; yv[j] = yp[p];
+      mv[j] = mask ? mask[p] : 1.0f;
     }
-    s_x[r][c] = xv; s_y[r][c] = yv;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < kLP * kLP) {
+        const int r = i / kLP, c = i - r * kLP;
+        s_x[r][c] = in[j] ? xv[j] * mv[j] : 0.0f;
+        s_y[r][c] = in[j] ? yv[j] * mv[j] : 0.0f;
+      }
+    }
   }
   __syncthreads();
   // horizontal pass: one work item = one patch row x 6 adjacent output columns, 42 x 6 = 252 items = one pass of the
@@ -195,15 +211,21 @@ ssim_l1_backward_kernel(const float *__restrict__ img, const float *__restrict__
   const int c = threadIdx.x % kLT, r0 = (threadIdx.x / kLT) * 4;
   const float go = grad_out ? grad_out[0] : 1.0f;
   float xv[4], yv[4], mk[4], acc[4];
+  // the thread's own four pixels: all loads issued together from clamped addresses, out-of-image ones zeroed by a
+  // select (with the bounds test around the loads each pixel was two dependent round trips to memory)
 #pragma unroll
   for (int o = 0; o < 4; o++) {
     const int gy = y0 + r0 + o, gx = x0 + c;
-    xv[o] = yv[o] = mk[o] = acc[o] = 0.0f;
-    if (gy < H && gx < W) {
-      const size_t p = (size_t)gy * W + gx;
-      mk[o] = mask ? mask[p] : 1.0f;
-      xv[o] = img[ch * HW + p] * mk[o]; yv[o] = gt[ch * HW + p] * mk[o];
-    }
+    const size_t p = (size_t)min(gy, H - 1) * W + min(gx, W - 1);
+    mk[o] = mask ? mask[p] : 1.0f;
+    xv[o] = img[ch * HW + p]; yv[o] = gt[ch * HW + p];
+  }
+#pragma unroll
+  for (int o = 0; o < 4; o++) {
+    const bool in = y0 + r0 + o < H && x0 + c < W;
+    mk[o] = in ? mk[o] : 0.0f;
+    xv[o] *= mk[o]; yv[o] *= mk[o];
+    acc[o] = 0.0f;
   }
   // the patch of map q+1 is fetched into registers while map q is convolved (7 pixels per thread)
   constexpr int kPerThread = (kLP * kLP + 255) / 256;
@@ -211,20 +233,28 @@ ssim_l1_backward_kernel(const float *__restrict__ img, const float *__restrict__
   auto fetch = [&](int q) {
     const float *map = dmaps + q * CHW + ch * HW;
 #pragma unroll
-    for (int j = 0; j < kPerThread; j++) {
-      const int i = threadIdx.x + 256 * j;
-      const int r = i / kLP, cc = i % kLP;
+    for (int j = 0; j < kPerThread; j++) {   // clamped, unconditional loads; the select comes when the value is stored
+      const int i = min(threadIdx.x + 256 * j, kLP * kLP - 1);
+      const int r = i / kLP, cc = i - r * kLP;
       const int gy = y0 + r - kLH, gx = x0 + cc - kLH;
-      pre[j] = (i < kLP * kLP && gy >= 0 && gy < H && gx >= 0 && gx < W) ? map[(size_t)gy * W + gx] : 0.0f;
+      pre[j] = map[(size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
     }
   };
+  bool pre_in[kPerThread];   // the same for all three maps
+#pragma unroll
+  for (int j = 0; j < kPerThread; j++) {
+    const int i = min(threadIdx.x + 256 * j, kLP * kLP - 1);
+    const int r = i / kLP, cc = i - r * kLP;
+    const int gy = y0 + r - kLH, gx = x0 + cc - kLH;
+    pre_in[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+  }
   fetch(0);
 #pragma unroll 1
   for (int q = 0; q < 3; q++) {
 #pragma unroll
     for (int j = 0; j < kPerThread; j++) {
       const int i = threadIdx.x + 256 * j;
-      if (i < kLP * kLP) s_m[i / kLP][i % kLP] = pre[j];
+      if (i < kLP * kLP) s_m[i / kLP][i % kLP] = pre_in[j] ? pre[j] : 0.0f;
     }
     if (q < 2) fetch(q + 1);
     __syncthreads();
