@@ -95,7 +95,12 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
                 if data_parallel:
                     _sync_densification_stats(gaussians)
                     torch.manual_seed(1_000_003 * iteration)   # densify_and_split samples positions: same draw on every rank
+                n_before = gaussians.get_xyz.shape[0]
                 gaussians.densify_and_prune(opt.densify_grad_threshold, 0.005, scene_extent, size_threshold)
+                n_after = gaussians.get_xyz.shape[0]
+                if fused_view and n_after > n_before and PairPolicy.reserve > 0:
+                    # the one-call view never asks for the pair count: let the reservation grow with the model
+                    PairPolicy.reserve = max(PairPolicy.reserve, int(PairPolicy.reserve * (n_after / n_before) * 1.1) + 1024)
             if iteration % opt.opacity_reset_interval == 0:
                 gaussians.reset_opacity()
         gaussians.optimizer.step()
@@ -128,10 +133,21 @@ def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, backgr
                                      data_parallel=data_parallel and w > 1, **kw)
         losses.append(loss.detach())
         if kw.get("fused_view") and it % 32 == 0:
-            PairPolicy.drain()   # fused views reserve their pair buffer: verify (raises on overflow, grows the reservation)
+            _drain_reservation()
     if kw.get("fused_view"):
-        PairPolicy.drain()
+        _drain_reservation()
     return [float(l) for l in losses]
+
+
+def _drain_reservation():
+    """Fused views reserve their pair buffer instead of asking for the count.  An overflowed view was blended from
+    truncated tile lists (nothing is written out of bounds): drain() has already grown the reservation, training goes
+    on, the user is told."""
+    try:
+        PairPolicy.drain()
+    except RuntimeError as e:
+        import warnings
+        warnings.warn(f"train(fused_view=True): {e}; up to 32 iterations used truncated tile lists")
 
 
 def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, pipe=None, background=None, seed=0):
