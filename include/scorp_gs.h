@@ -117,6 +117,11 @@ int scorp_gs3d_num_pairs(const void *state, scorp_stream_t stream, uint64_t *num
  *    small nothing is written out of bounds, outputs are undefined and scorp_gs3d_check_overflow() reports it. */
 int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
                       float *out_depth, float *out_alpha, scorp_stream_t stream);
+/* 3'. the same images with nothing left behind for scorp_gs3d_backward (no per-pixel state, no cull verdicts in the
+ *     pair buffer): for the calls the reference makes under torch.no_grad() (align_3dgs_clpe_9dof.py:157-169 scoring
+ *     renders, evaluation views).  Same arguments, same outputs bit for bit. */
+int scorp_gs3d_render_image(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
+                            float *out_depth, float *out_alpha, scorp_stream_t stream);
 /* Synchronises; returns SCORP_ERR_OVERFLOW if the last render on this state needed more than `capacity` pairs
  * (and the needed count in *num_pairs), SCORP_OK otherwise. */
 int scorp_gs3d_check_overflow(const void *state, scorp_stream_t stream, uint64_t *num_pairs);

@@ -49,6 +49,7 @@ class ScorpAdamTensor(ctypes.Structure):
 EXPORTS = [
     "scorp_version", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
     "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
+    "scorp_gs3d_render_image",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
     "scorp_knn_dist2", "scorp_adam_step", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
@@ -86,6 +87,7 @@ def lib():
     L.scorp_gs3d_preprocess.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, sz, vp]
     L.scorp_gs3d_num_pairs.argtypes = [vp, vp, ctypes.POINTER(u64)]
     L.scorp_gs3d_render.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp, vp]
+    L.scorp_gs3d_render_image.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp, vp]
     L.scorp_gs3d_check_overflow.argtypes = [vp, vp, ctypes.POINTER(u64)]
     L.scorp_gs3d_backward.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp,
                                       ctypes.POINTER(ScorpGs3dGrads), vp, sz, vp]

@@ -439,6 +439,9 @@ sort_tiles_reg_kernel(const uint32_t *__restrict__ tile_start, const uint64_t *_
 constexpr int kFRing = 128, kFChunk = 64, kFGroup = 8;
 constexpr float kLog2eF = 1.4426950408889634f;
 
+// kForBackward = false (scorp_gs3d_render_image): nothing is left behind for a backward pass - no cull verdicts, no
+// per-pixel final T / last contributor, no bookkeeping of the last contributor in the blend loop.
+template <bool kForBackward>
 __global__ void __launch_bounds__(64)
 blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
@@ -488,7 +491,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       hit = conic_min_over_box(a.x, a.y, a.z, a.w, b.x, bx0, bx1, by0, by1) <= c.z;
       // remembered for the backward (one byte per (block, entry), in the pair buffer's key region, which is dead after
       // the sort): it then gathers and replays only the entries that passed this test
-      hit_flags[(size_t)quad * capacity + beg + base + lane] = hit ? 1 : 0;
+      if constexpr (kForBackward) hit_flags[(size_t)quad * capacity + beg + base + lane] = hit ? 1 : 0;
     }
     const uint64_t m = __ballot(hit);
     if (hit) {
@@ -539,7 +542,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
           C0 += rg.x * w; C1 += rg.y * w; C2 += bz.x * w;
           Dp += bz.y * w;
           T = ok ? test_T : -fabsf(T);
-          last = ae > 0.0f ? pos[i] : last;
+          if constexpr (kForBackward) last = ae > 0.0f ? pos[i] : last;
         }
       }
       head = (head + kFGroup) & (kFRing - 1);
@@ -552,8 +555,10 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
     T = fabsf(T);
-    final_T[pix] = T;
-    n_contrib[pix] = last;
+    if constexpr (kForBackward) {
+      final_T[pix] = T;
+      n_contrib[pix] = last;
+    }
     out_color[pix] = C0 + T * bg[0];
     out_color[HW + pix] = C1 + T * bg[1];
     out_color[2 * HW + pix] = C2 + T * bg[2];
@@ -708,8 +713,8 @@ extern "C" int scorp_gs3d_check_overflow(const void *state, scorp_stream_t strea
   return SCORP_OK;
 }
 
-extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
-                                 float *out_color, float *out_depth, float *out_alpha, scorp_stream_t stream_) {
+static int render_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
+                       float *out_depth, float *out_alpha, scorp_stream_t stream_, bool for_backward) {
   if (int e = validate(in)) return e;
   hipStream_t stream = (hipStream_t)stream_;
   const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
@@ -728,13 +733,24 @@ extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *p
   {
     ProfScope prof(kKBlendForward, stream);
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
-    blend_forward_wave_kernel<<<blocks, 64, 0, stream>>>(
+    auto bk = for_backward ? blend_forward_wave_kernel<true> : blend_forward_wave_kernel<false>;
+    bk<<<blocks, 64, 0, stream>>>(
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
         out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib),
         (uint8_t *)keys);
   }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;
+}
+
+extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
+                                 float *out_color, float *out_depth, float *out_alpha, scorp_stream_t stream) {
+  return render_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, stream, true);
+}
+
+extern "C" int scorp_gs3d_render_image(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
+                                       float *out_color, float *out_depth, float *out_alpha, scorp_stream_t stream) {
+  return render_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, stream, false);
 }
 
 extern "C" int scorp_gs3d_debug_geom(const void *state, int32_t N, int32_t W, int32_t H, float *xy, float *depth,

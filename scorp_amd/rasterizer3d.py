@@ -196,8 +196,11 @@ def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opaciti
             PairPolicy.reserve = max(4 * N, 1 << 20)
         capacity = PairPolicy.reserve
     pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
-    _C.check(L.scorp_gs3d_render(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(depth),
-                                 _ptr(alpha), stream), "scorp_gs3d_render")
+    # nothing to differentiate (the calls the reference makes under torch.no_grad()): the image-only render, which
+    # leaves no state for a backward pass
+    fn = L.scorp_gs3d_render if any(ctx.needs_input_grad) else L.scorp_gs3d_render_image
+    _C.check(fn(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(depth), _ptr(alpha), stream),
+             "scorp_gs3d_render")
     if PairPolicy.mode != "exact":
         # what drain() will look at: a copy of the 64-byte StateHeader the render just filled in (pair count, overflow
         # flag) - not the state itself, or every pending view would pin ~100 MB of device memory until the drain

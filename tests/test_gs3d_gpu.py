@@ -261,6 +261,24 @@ def test_backward_replays_on_one_forward(dev):
         assert np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max() < GRAD_REL_TOL
 
 
+def test_image_only_render_is_bit_identical(dev):
+    """Under torch.no_grad() the front-end takes scorp_gs3d_render_image (no state for a backward pass): the three
+    images and the radii must equal those of the differentiable render bit for bit."""
+    kw, _ = make_case(**CASES["sh3_bg_mod"])
+    out_g, _ = hip_render(kw, dev)                       # inputs require grad -> scorp_gs3d_render
+    from scorp_amd import rasterizer3d as R
+    T = lambda a: None if a is None else torch.tensor(a, device=dev)
+    s = R.GaussianRasterizationSettings(kw["H"], kw["W"], kw["tanfovx"], kw["tanfovy"], T(kw["bg"]), kw.get("scale_modifier", 1.0),
+                                        T(kw["view"]), T(kw["proj"]), kw.get("sh_degree", 0), T(kw["campos"]), False, False)
+    with torch.no_grad():
+        out_n = R.GaussianRasterizer(s)(means3D=T(kw["means3D"]), means2D=None, shs=T(kw.get("shs")),
+                                        colors_precomp=T(kw.get("colors_precomp")), opacities=T(kw["opacities"]),
+                                        scales=T(kw.get("scales")), rotations=T(kw.get("rotations")),
+                                        cov3D_precomp=T(kw.get("cov3D_precomp")))
+    for a, b in zip(out_g, out_n):
+        assert torch.equal(a.detach(), b)
+
+
 def test_no_grad_forward_and_debug_flag(dev):
     kw, _ = make_case(2000, 100, 60, 3, 13)
     o = oracle(kw)
