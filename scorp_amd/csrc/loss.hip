@@ -6,9 +6,10 @@
 // mirrors backward).  Same definition: Gaussian window sigma 1.5, zero padding 5, C1 = 0.01^2, C2 = 0.03^2,
 // mean over all C*H*W elements.  The 2-D window is the outer product of the 1-D one, so it is applied separably.
 //
-// Forward : one pass over 32x32 tiles (+5 halo) per channel: the five windowed moments, the SSIM value, |x-y|,
-//           per-block partial sums, and the three derivative maps d ssim/d{mu1, E[x^2], E[xy]}.
-// Backward: one pass: windowed sums of the three maps (the window is symmetric), combined with x and y.
+// Forward : one pass, a wave per 64-column strip streaming down the image: the five windowed moments, the SSIM
+//           value, |x-y|, per-wave partial sums, and the three derivative maps d ssim/d{mu1, E[x^2], E[xy]}.
+// Backward: one pass over 32x32 tiles (+5 halo): windowed sums of the three maps (the window is symmetric),
+//           combined with x and y.
 #include "common.hpp"
 
 namespace scorp {
@@ -60,112 +61,136 @@ __device__ __forceinline__ LossTile loss_tile(int gx, int gy, int C) {
   return t;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward: ONE WAVE per strip of 64 columns x kStripRows rows of one channel, no workgroup barriers.  The wave
+// walks its strip top to bottom one image row at a time: the row (64 + 10 halo columns) is loaded two rows ahead,
+// x, y, x^2 + y^2, xy go through a per-wave LDS row buffer from which every lane reads its 11 taps (horizontal
+// pass), and the vertical pass lives in registers: the last 11 rows' horizontal sums form a ring that is indexed
+// statically because the row loop is unrolled by 11.  (The first form, 32x32 tiles per workgroup with the two passes
+// separated by barriers as in the backward below, spent most of a workgroup's life waiting and needed 36 KB of LDS:
+// 54 us against 49.)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kStripIters = 4;                          // unrolled-by-11 groups of rows per strip
+constexpr int kStripRows = 11 * kStripIters - 10;       // output rows per strip (34)
+constexpr int kRowBuf = 80;                             // floats per row-buffer array (74 used)
+
+struct StripJob { int ch, cx0, ry0; bool valid; };
+__device__ __forceinline__ StripJob strip_job(int C, int H, int W) {
+  const int sx = (W + 63) / 64, sy = (H + kStripRows - 1) / kStripRows;
+  // readfirstlane: the wave index is uniform, but derived from threadIdx the compiler would carry the whole job
+  // (channel, strip origin, every row base address) in vector registers
+  const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  StripJob j;
+  j.valid = wave < C * sx * sy;
+  j.ch = wave / (sx * sy);
+  const int rem = wave - j.ch * sx * sy;
+  j.ry0 = (rem / sx) * kStripRows; j.cx0 = (rem % sx) * 64;
+  return j;
+}
+static inline int strip_waves(int C, int H, int W) { return C * ((W + 63) / 64) * ((H + kStripRows - 1) / kStripRows); }
+
 __global__ void __launch_bounds__(256)
-ssim_l1_forward_kernel(const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ mask,
-                       int C, int H, int W, Window win, float *__restrict__ dmaps, float *__restrict__ partials) {
-  __shared__ float s_x[kLP][kLPS], s_y[kLP][kLPS];
-  __shared__ float s_h[4][kLP][kLHS];   // mu1, mu2, E[x^2] + E[y^2] (only the sum enters SSIM and d/dx), E[xy]
-  __shared__ float s_red[4];
-  const LossTile lt = loss_tile((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
-  if (!lt.valid) return;
-  const int ch = lt.ch, x0 = lt.x0, y0 = lt.y0;
-  const size_t HW = (size_t)H * W;
+ssim_l1_forward_strip_kernel(const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ mask,
+                             int C, int H, int W, Window win, float *__restrict__ dmaps, float *__restrict__ partials) {
+  __shared__ float s_row[4][4][kRowBuf];   // [wave][x, y, x^2 + y^2, xy][column]
+  const StripJob job = strip_job(C, H, W);
+  if (!job.valid) return;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float(*buf)[kRowBuf] = s_row[wv];
+  const int ch = job.ch, cx0 = job.cx0, ry0 = job.ry0;
+  const size_t HW = (size_t)H * W, CHW = (size_t)C * HW;
   const float *xp = img + ch * HW, *yp = gt + ch * HW;
-  {
-    // The patch: 1764 elements = 7 per thread.  All of a thread's loads leave together, from clamped (always valid)
-    // addresses, and out-of-image elements are zeroed by a select afterwards: as a loop with the bounds test around the
-    // loads this was seven dependent round trips to memory per workgroup - most of its life.
-    constexpr int kPer = (kLP * kLP + 255) / 256;
-    float xv[kPer], yv[kPer], mv[kPer];
-    bool in[kPer];
+  const int gx = cx0 + lane;                               // this lane's output column
+  const int ca = cx0 - kLH + lane, cb = cx0 + 64 - kLH + lane;   // columns of its one / two (lane < 10) patch elements
+  const bool cin_a = ca >= 0 && ca < W, cin_b = lane < 2 * kLH && cb < W;
+  const int ca_c = min(max(ca, 0), W - 1), cb_c = min(cb, W - 1);
+  struct RowRegs { float xa, ya, ma, xb, yb, mb; };
+  // clamped, unconditional loads (zeroed by a select later); uniform row base + 32-bit lane offset, so that the loads
+  // take the scalar-base addressing form instead of a 64-bit address computation per load
+  const uint32_t oa = (uint32_t)ca_c, ob = (uint32_t)cb_c;
+  auto fetch = [&](int r) {
+    RowRegs v;
+    const size_t ro = (size_t)min(max(r, 0), H - 1) * W;
+    const float *xr = xp + ro, *yr = yp + ro;
+    v.xa = xr[oa]; v.ya = yr[oa]; v.xb = xr[ob]; v.yb = yr[ob];
+    v.ma = v.mb = 1.0f;
+    if (mask) { const float *mr = mask + ro; v.ma = mr[oa]; v.mb = mr[ob]; }
+    return v;
+  };
+  float hist[4][11], cx[11], cy[11];                       // rings, slot = row mod 11 (static: the loop is unrolled by 11)
 #pragma unroll
-    for (int j = 0; j < kPer; j++) {
-      const int i = min(threadIdx.x + 256 * j, kLP * kLP - 1);
-      const int r = i / kLP, c = i - r * kLP;
-      const int gy = y0 + r - kLH, gx = x0 + c - kLH;
-      in[j] = gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const size_t p = (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
-      xv[j] = xp[p]; yv[j] = yp[p];
-      mv[j] = mask ? mask[p] : 1.0f;
-    }
+  for (int k = 0; k < 11; k++) { hist[0][k] = hist[1][k] = hist[2][k] = hist[3][k] = 0.0f; cx[k] = cy[k] = 0.0f; }
+  float l1_sum = 0.0f, ssim_sum = 0.0f;
+  const int rbeg = ry0 - kLH;
+  RowRegs n0 = fetch(rbeg), n1 = fetch(rbeg + 1);
+#pragma unroll 1
+  for (int it = 0; it < kStripIters; it++) {
 #pragma unroll
-    for (int j = 0; j < kPer; j++) {
-      const int i = threadIdx.x + 256 * j;
-      if (i < kLP * kLP) {
-        const int r = i / kLP, c = i - r * kLP;
-        s_x[r][c] = in[j] ? xv[j] * mv[j] : 0.0f;
-        s_y[r][c] = in[j] ? yv[j] * mv[j] : 0.0f;
+    for (int u = 0; u < 11; u++) {
+      const int r = rbeg + it * 11 + u;
+      const RowRegs cur = n0;
+      n0 = n1;
+      n1 = fetch(r + 2);
+      const bool rin = r >= 0 && r < H;
+      {
+        const float m = (rin && cin_a) ? cur.ma : 0.0f;
+        const float xv = cur.xa * m, yv = cur.ya * m;
+        buf[0][lane] = xv; buf[1][lane] = yv; buf[2][lane] = xv * xv + yv * yv; buf[3][lane] = xv * yv;
+        if (lane < 2 * kLH) {
+          const float m2 = (rin && cin_b) ? cur.mb : 0.0f;
+          const float x2 = cur.xb * m2, y2 = cur.yb * m2;
+          buf[0][64 + lane] = x2; buf[1][64 + lane] = y2; buf[2][64 + lane] = x2 * x2 + y2 * y2; buf[3][64 + lane] = x2 * y2;
+        }
       }
-    }
-  }
-  __syncthreads();
-  // horizontal pass: one work item = one patch row x 6 adjacent output columns, 42 x 6 = 252 items = one pass of the
-  // workgroup; the products x^2, y^2, xy are formed once per loaded element, not once per tap
-  {
-    const int it = threadIdx.x;
-    const int r = it / kHG, c0 = (it % kHG) * kHO;
-    if (it < kLP * kHG) {
-      float xs[kHO + 10], ys[kHO + 10], ss[kHO + 10], xy[kHO + 10];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float h0 = 0, h1 = 0, h2 = 0, h3 = 0;
 #pragma unroll
-      for (int k = 0; k < kHO + 10; k++) {
-        const bool in = c0 + k < kLP;   // the last group of a row covers columns 30..35 of 32
-        xs[k] = in ? s_x[r][c0 + k] : 0.0f; ys[k] = in ? s_y[r][c0 + k] : 0.0f;
-        ss[k] = xs[k] * xs[k] + ys[k] * ys[k]; xy[k] = xs[k] * ys[k];
+      for (int k = 0; k < 11; k++) {
+        const float w = win.w[k];
+        h0 += w * buf[0][lane + k]; h1 += w * buf[1][lane + k]; h2 += w * buf[2][lane + k]; h3 += w * buf[3][lane + k];
       }
-#pragma unroll
-      for (int o = 0; o < kHO; o++) {
+      cx[u] = buf[0][lane + kLH]; cy[u] = buf[1][lane + kLH];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();                      // the next row's writes come after these reads
+      hist[0][u] = h0; hist[1][u] = h1; hist[2][u] = h2; hist[3][u] = h3;
+      // output row ro = r - 5: its window is rows ro-5 .. ro+5 = r-10 .. r, ring slots (u + 1 + k) mod 11
+      const int ro = r - kLH;
+      if (ro >= ry0 && ro < H && ro < ry0 + kStripRows) {   // wave-uniform
         float m1 = 0, m2 = 0, ess = 0, e12 = 0;
 #pragma unroll
         for (int k = 0; k < 11; k++) {
           const float w = win.w[k];
-          m1 += w * xs[o + k]; m2 += w * ys[o + k]; ess += w * ss[o + k]; e12 += w * xy[o + k];
+          const int sl = (u + 1 + k) % 11;
+          m1 += w * hist[0][sl]; m2 += w * hist[1][sl]; ess += w * hist[2][sl]; e12 += w * hist[3][sl];
         }
-        if (c0 + o < kLT) { s_h[0][r][c0 + o] = m1; s_h[1][r][c0 + o] = m2; s_h[2][r][c0 + o] = ess; s_h[3][r][c0 + o] = e12; }
+        if (gx < W) {
+          const float m1s = m1 * m1, m2s = m2 * m2, m12 = m1 * m2;
+          const float s12 = e12 - m12;
+          const float A1 = 2 * m12 + kC1, A2 = 2 * s12 + kC2, B1 = m1s + m2s + kC1, B2 = (ess - m1s - m2s) + kC2;
+          // B1 >= C1, B2 >= ~C2 > 0: hardware reciprocals (1 ulp) instead of two IEEE division sequences
+          const float rB2 = __builtin_amdgcn_rcpf(B2);
+          const float inv = __builtin_amdgcn_rcpf(B1) * rB2;
+          const float ssim = A1 * A2 * inv;
+          ssim_sum += ssim;
+          const int sc = (u + 11 - kLH) % 11;               // the centre row's x, y
+          l1_sum += fabsf(cx[sc] - cy[sc]);
+          if (dmaps) {
+            float *d0 = dmaps + ch * HW + (size_t)ro * W;    // uniform row base + lane offset
+            d0[(uint32_t)gx] = (2 * m2 * (A2 - A1) - 2 * m1 * ssim * (B2 - B1)) * inv;  // d ssim / d mu1
+            (d0 + CHW)[(uint32_t)gx] = -ssim * rB2;                                      // d ssim / d E[x^2]
+            (d0 + 2 * CHW)[(uint32_t)gx] = 2 * A1 * inv;                                  // d ssim / d E[xy]
+          }
+        }
       }
     }
   }
-  __syncthreads();
-  // vertical pass: thread = one column x 4 adjacent rows
-  const int c = threadIdx.x % kLT, r0 = (threadIdx.x / kLT) * 4;
-  float l1_sum = 0.0f, ssim_sum = 0.0f;
-  float col[4][14];
 #pragma unroll
-  for (int q = 0; q < 4; q++)
-#pragma unroll
-    for (int k = 0; k < 14; k++) col[q][k] = s_h[q][r0 + k][c];
-#pragma unroll
-  for (int o = 0; o < 4; o++) {
-    float m1 = 0, m2 = 0, ess = 0, e12 = 0;
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float w = win.w[k];
-      m1 += w * col[0][o + k]; m2 += w * col[1][o + k]; ess += w * col[2][o + k]; e12 += w * col[3][o + k];
-    }
-    const int gy = y0 + r0 + o, gx = x0 + c;
-    if (gy < H && gx < W) {
-      const float m1s = m1 * m1, m2s = m2 * m2, m12 = m1 * m2;
-      const float s12 = e12 - m12;
-      const float A1 = 2 * m12 + kC1, A2 = 2 * s12 + kC2, B1 = m1s + m2s + kC1, B2 = (ess - m1s - m2s) + kC2;
-      const float inv = 1.0f / (B1 * B2);
-      const float ssim = A1 * A2 * inv;
-      ssim_sum += ssim;
-      const float xv = s_x[r0 + o + kLH][c + kLH], yv = s_y[r0 + o + kLH][c + kLH];
-      l1_sum += fabsf(xv - yv);
-      if (dmaps) {
-        const size_t p = (size_t)gy * W + gx;
-        const size_t CHW = (size_t)C * HW;
-        dmaps[ch * HW + p] = (2 * m2 * (A2 - A1) - 2 * m1 * ssim * (B2 - B1)) * inv;  // d ssim / d mu1
-        dmaps[CHW + ch * HW + p] = -ssim / B2;                                        // d ssim / d E[x^2]
-        dmaps[2 * CHW + ch * HW + p] = 2 * A1 * inv;                                   // d ssim / d E[xy]
-      }
-    }
-  }
-  const float bl1 = block_sum_256(l1_sum, s_red);
-  const float bss = block_sum_256(ssim_sum, s_red);
-  if (threadIdx.x == 0) {
-    const int b = lt.logical;
-    partials[2 * b] = bl1;
-    partials[2 * b + 1] = bss;
+  for (int off = 32; off >= 1; off >>= 1) { l1_sum += __shfl_xor(l1_sum, off, 64); ssim_sum += __shfl_xor(ssim_sum, off, 64); }
+  if (lane == 0) {
+    const int wave = blockIdx.x * 4 + wv;
+    partials[2 * wave] = l1_sum;
+    partials[2 * wave + 1] = ssim_sum;
   }
 }
 
@@ -307,7 +332,7 @@ static inline int loss_blocks(int C, int H, int W) { return ((W + kLT - 1) / kLT
 
 // workspace = derivative maps [3][C][H][W] followed by per-block partial sums [blocks][2]
 extern "C" size_t scorp_loss_workspace_bytes(int32_t C, int32_t H, int32_t W) {
-  return align_up((size_t)3 * C * H * W * 4, 256) + align_up((size_t)loss_blocks(C, H, W) * 8, 256);
+  return align_up((size_t)3 * C * H * W * 4, 256) + align_up((size_t)strip_waves(C, H, W) * 8, 256);
 }
 
 extern "C" int scorp_loss_l1_ssim_forward(const float *img, const float *gt, const float *mask, int32_t C, int32_t H,
@@ -321,14 +346,14 @@ extern "C" int scorp_loss_l1_ssim_forward(const float *img, const float *gt, con
   hipStream_t stream = (hipStream_t)stream_;
   float *dmaps = (float *)workspace;
   float *partials = (float *)((char *)workspace + align_up((size_t)3 * C * H * W * 4, 256));
-  const int grid = (loss_blocks(C, H, W) + 7) / 8 * 8;
   const Window win = make_window();
+  const int nparts = strip_waves(C, H, W);
   {
     ProfScope prof(kKLossForward, stream);
-    ssim_l1_forward_kernel<<<grid, 256, 0, stream>>>(img, gt, mask, C, H, W, win, need_backward ? dmaps : nullptr, partials);
+    ssim_l1_forward_strip_kernel<<<(nparts + 3) / 4, 256, 0, stream>>>(img, gt, mask, C, H, W, win, need_backward ? dmaps : nullptr, partials);
   }
   SCORP_KERNEL_CHECK("ssim_l1_forward", 0, stream);
-  loss_finalize_kernel<<<1, 1024, 0, stream>>>(partials, loss_blocks(C, H, W), (double)C * H * W, lambda_dssim, out_loss3);
+  loss_finalize_kernel<<<1, 1024, 0, stream>>>(partials, nparts, (double)C * H * W, lambda_dssim, out_loss3);
   SCORP_KERNEL_CHECK("loss_finalize", 0, stream);
   return SCORP_OK;
 }
