@@ -79,9 +79,20 @@ def cpu_baseline(raw, cam, deg, W, H):
     o.backward(w, None, None)
     dt = time.perf_counter() - t0
     gs_oracle.set_parallel_backward(False)
-    return dict(value=1.0 / dt, unit="views/s", cores=cores, kind="port",
-                sample=f"1 view of the same workload (render fwd+bwd, no loss), {dt:.2f} s, OpenMP over {cores} host threads "
-                       f"(os.cpu_count()={os.cpu_count()})"), o
+    # the loss half of the step on the same host: the torch formulation of the reference's l1_loss / ssim
+    # (scorp_amd/loss.py restates gs3dgs/utils/loss_utils.py:17-73), forward + backward on the oracle's image
+    from scorp_amd.loss import l1_loss, ssim
+    torch.set_num_threads(cores)
+    img = torch.tensor(o.color).requires_grad_(True)
+    gt = (img.detach() + 0.05).clamp(0, 1)
+    t1 = time.perf_counter()
+    loss = 0.8 * l1_loss(img, gt) + 0.2 * (1.0 - ssim(img, gt))
+    loss.backward()
+    dt_loss = time.perf_counter() - t1
+    return dict(value=1.0 / (dt + dt_loss), unit="views/s", cores=cores, kind="port",
+                sample=f"1 view of the same workload: OpenMP oracle render fwd+bwd {dt:.2f} s + torch-CPU L1/SSIM loss fwd+bwd "
+                       f"{dt_loss:.2f} s, {cores} host threads (os.cpu_count()={os.cpu_count()})",
+                render_s=round(dt, 3), loss_s=round(dt_loss, 3)), o
 
 
 def small_parity(dev):
