@@ -54,6 +54,7 @@ struct Pg2Args {
 };
 
 __device__ __forceinline__ void pixel_rows(const float *pm, int W, int H, float Q[3][4]) {
+#pragma clang fp contract(off)   // the splat-to-pixel transform feeds ceil(extent): same roundings as the CPU oracle
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const float p0 = pm[c * 4 + 0], p1 = pm[c * 4 + 1], p3 = pm[c * 4 + 3];
@@ -64,6 +65,7 @@ __device__ __forceinline__ void pixel_rows(const float *pm, int W, int H, float 
 }
 
 __device__ __forceinline__ void quat_R(float4 q, float *R) {
+#pragma clang fp contract(off)
   const float r = q.x, x = q.y, y = q.z, z = q.w;
   R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - r * z);     R[2] = 2 * (x * z + r * y);
   R[3] = 2 * (x * y + r * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - r * x);
