@@ -344,8 +344,15 @@ def main():
             "forward_only_views_per_s_per_gpu": round(fwd_only, 1),
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"], _ = cpu_baseline(raw, my_cams[0].to("cpu"), deg, W, H)
+            line["cpu_baseline"], orc = cpu_baseline(raw, my_cams[0].to("cpu"), deg, W, H)
             line["parity"] = small_parity(dev)
+            if not surfels:   # the same full-size view, HIP against the CPU oracle the baseline just rendered
+                with torch.no_grad():
+                    hip = render(my_cams[0].to(dev), model, pipe, bg)["render"].cpu().numpy()   # (.to() moves in place)
+                mse = float(((hip - orc.color) ** 2).mean())
+                line["parity"]["full_size"] = dict(workload=f"{args.scene} view 0", l1=float(np.abs(hip - orc.color).mean()),
+                                                   max_abs=float(np.abs(hip - orc.color).max()),
+                                                   psnr_db=(99.0 if mse == 0 else float(10 * math.log10(1.0 / mse))))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
