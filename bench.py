@@ -76,7 +76,7 @@ def cpu_baseline(raw, cam, deg, W, H):
     w = np.full((3, H, W), 1.0 / (3 * H * W), np.float32)
     t0 = time.perf_counter()
     o = OracleRender(np.float32, **kw)
-    o.backward(w, None, None)
+    o.full_size_case = (kw, w, o.backward(w, None, None))   # kept for the full-size parity figures
     dt = time.perf_counter() - t0
     gs_oracle.set_parallel_backward(False)
     # the loss half of the step on the same host: the torch formulation of the reference's l1_loss / ssim
@@ -353,6 +353,18 @@ def main():
                 line["parity"]["full_size"] = dict(workload=f"{args.scene} view 0", l1=float(np.abs(hip - orc.color).mean()),
                                                    max_abs=float(np.abs(hip - orc.color).max()),
                                                    psnr_db=(99.0 if mse == 0 else float(10 * math.log10(1.0 / mse))))
+                # ... and the gradients of the oracle's backward pass (same inputs, same upstream gradient), per tensor
+                # max |difference| / max |reference|, through the reference call convention (activated inputs)
+                from tests.test_gs3d_gpu import hip_render
+                kw_o, w_o, g_o = orc.full_size_case
+                out_h, t_h = hip_render(kw_o, dev)
+                (out_h[0] * torch.tensor(w_o, device=dev)).sum().backward()
+                rel = {}
+                for nm in ("means3D", "means2D", "opacities", "shs", "scales", "rotations"):
+                    ref = g_o[nm]
+                    got = t_h[nm].grad.detach().cpu().numpy().reshape(ref.shape)
+                    rel[nm] = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-20))
+                line["parity"]["full_size"]["grad_max_rel_err"] = rel
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
