@@ -292,9 +292,9 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, uint32_t n, uint32_t P) {
   __syncthreads();
 }
 
-// Two launches share the tiles by list length so that the common case keeps a small LDS footprint (8 KiB -> 8
-// workgroups per CU instead of 5): kCap = 1024 handles lists of up to 1024 entries, kCap = 4096 the longer ones
-// (in LDS up to 4096 entries, with the same network on global memory beyond).
+// The LDS / global-memory form of the network, launched for the lists sort_tiles_reg_kernel (below) leaves alone:
+// kCap = 4096, kMinExclusive = 1024 handles lists longer than 1024 entries (in LDS up to 4096, with the same network
+// on global memory beyond).  Its own launch so that the common case keeps an 8 KiB LDS footprint.
 template <int kCap, int kMinExclusive>
 __global__ void __launch_bounds__(256)
 sort_tiles_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict__ keys,
