@@ -38,6 +38,13 @@ namespace {
 //   they are flushed with float atomics shaped as whole 40-byte row segments (lanes = consecutive floats).
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// The W half of the reduction (blend weights x upstream colour / depth gradients: plain sums, no cancellation
+// afterwards) runs on v_mfma_f32_16x16x32_bf16 with both factors split into two bf16 terms (truncated high part +
+// remainder; the product keeps hi*hi + hi*lo + lo*hi, relative error ~2^-16): 6 MFMAs of 16 cycles instead of 16 of 32,
+// and fp32 MFMA time is paid in full on this chip (scripts/mb_mfma_valu.hip).  The V half (moments that are
+// afterwards re-centred on the splat, a cancelling operation) stays on exact fp32 MFMAs.
+constexpr int kWStride = 72;                 // bf16 elements per slot row of the w matrices (144 B: conflict-free b128 reads)
 constexpr int kXStride = 68;                 // floats per slot row of the wave-private v / w matrices: rows stay 16-byte
                                              // aligned for the A-operand's ds_read_b128; row writes are conflict-free
 constexpr int kGroup = 16;                   // splats per MFMA group
@@ -68,8 +75,11 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   // opacity * G = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity)
   __shared__ float4 q_a[kRing], q_b[kRing], q_c[kRing];
   __shared__ __attribute__((aligned(16))) uint32_t q_id[kRing], q_pos[kRing];
-  __shared__ __attribute__((aligned(16))) float xv[kGroup * kXStride], xw[kGroup * kXStride];
-  float *dbuf = xw;  // the 16x12 result tile reuses the w matrix once the MFMAs have consumed it
+  __shared__ __attribute__((aligned(16))) float xv[kGroup * kXStride];
+  __shared__ __attribute__((aligned(16))) uint16_t xwh[kGroup * kWStride], xwl[kGroup * kWStride];   // w = hi + lo (bf16 bits)
+  float *dbuf = reinterpret_cast<float *>(xwh);  // the 16x12 result tile reuses the w matrix once the MFMAs have consumed it
+  float *xs = reinterpret_cast<float *>(xwh);    // prologue scratch: 64 x 4 floats spanning xwh and the start of xwl
+  static_assert(sizeof(uint16_t) * kGroup * kWStride * 2 >= 64 * 4 * sizeof(float), "prologue scratch fits");
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
@@ -108,24 +118,38 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   // half — so one register array serves both halves; the V and W products accumulate separately and the lane keeps the
   // one that belongs to its column.  Every lane already holds its own pixel's four gradients, so they are exchanged
   // through LDS (xw is idle until the first group) instead of being gathered from global memory again.
-  xw[lane * 4 + 0] = dpix0; xw[lane * 4 + 1] = dpix1; xw[lane * 4 + 2] = dpix2; xw[lane * 4 + 3] = ddep;
+  xs[lane * 4 + 0] = dpix0; xs[lane * 4 + 1] = dpix1; xs[lane * 4 + 2] = dpix2; xs[lane * 4 + 3] = ddep;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int t = 0; t < 16; t++) {
+  for (int t = 0; t < 16; t++) {   // fp32 B operand of the V half: MFMA t covers pixels t, t + 16, t + 32, t + 48
     const int q = t + 16 * bk;
     const int qx = bx + (q & 7), qy = by + (q >> 3);
     const float xl = (float)qx - cx, yl = (float)qy - cy;
     float v = 0.0f;
     v = bn == 0 ? 1.0f : v; v = bn == 1 ? xl : v; v = bn == 2 ? yl : v;
     v = bn == 3 ? xl * xl : v; v = bn == 4 ? xl * yl : v; v = bn == 5 ? yl * yl : v;
-    const float w = xw[q * 4 + ((bn - 6) & 3)];
-    bb[t] = (bn >= 6 && bn <= 9) ? w : v;
+    bb[t] = v;
   }
+  // bf16 B operand of the W half: bf16 MFMA b (0, 1) covers pixels 32 b + 8 bk + j, j = 0..7, of column bn
+  union Frag { bf16x8 v; uint16_t h[8]; uint4 q; };
+  Frag bwh[2], bwl[2];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int q = 32 * b + 8 * bk + j;
+      const float w = (bn >= 6 && bn <= 9) ? xs[q * 4 + ((bn - 6) & 3)] : 0.0f;
+      const uint32_t hb = __float_as_uint(w) & 0xFFFF0000u;
+      const float rem = w - __uint_as_float(hb);
+      bwh[b].h[j] = (uint16_t)(hb >> 16);
+      bwl[b].h[j] = (uint16_t)(__float_as_uint(rem) >> 16);
+    }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
   const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
+  const int wbase = (lane & 15) * kWStride + 8 * (lane >> 4);   // bf16 elements: row = slot, pixels 8 bk .. 8 bk + 7 (+ 32)
   int head = 0, count = 0;
 
   // head stays a multiple of kGroup (only a wave's final group is partial), so the slots of a group are head + i
@@ -184,7 +208,12 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
             s_last = sc;
             last_alpha = alpha;
             xv[i * kXStride + lane] = Go[i8] * dL_dal;
-            xw[i * kXStride + lane] = w;
+            {  // w = hi + lo as two truncated bf16 (the stores take the upper halves of the registers)
+              const uint32_t hb = __float_as_uint(w) & 0xFFFF0000u;
+              const float rem = w - __uint_as_float(hb);
+              xwh[i * kWStride + lane] = (uint16_t)(hb >> 16);
+              xwl[i * kWStride + lane] = (uint16_t)(__float_as_uint(rem) >> 16);
+            }
           }
         }
       }
@@ -193,21 +222,27 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       f32x4 dv = {0.0f, 0.0f, 0.0f, 0.0f}, dw = {0.0f, 0.0f, 0.0f, 0.0f};
       // A operands: the lane's 16 + 16 values are consecutive in its row, fetched as eight 16-byte reads issued
       // together; the V chain and the W chain are independent and interleave on the matrix pipe
-      float4 av[4], aw[4];
+      float4 av[4];
+      Frag awh[2], awl[2];
 #pragma unroll
       for (int t4 = 0; t4 < 4; t4++) av[t4] = *reinterpret_cast<const float4 *>(&xv[abase + 4 * t4]);
 #pragma unroll
-      for (int t4 = 0; t4 < 4; t4++) aw[t4] = *reinterpret_cast<const float4 *>(&xw[abase + 4 * t4]);
+      for (int b = 0; b < 2; b++) {
+        awh[b].q = *reinterpret_cast<const uint4 *>(&xwh[wbase + 32 * b]);
+        awl[b].q = *reinterpret_cast<const uint4 *>(&xwl[wbase + 32 * b]);
+      }
 #pragma unroll
-      for (int t4 = 0; t4 < 4; t4++) {
+      for (int b = 0; b < 2; b++) {   // W half: hi*hi + hi*lo + lo*hi on the bf16 matrix path
+        dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awh[b].v, bwh[b].v, dw, 0, 0, 0);
+        dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awh[b].v, bwl[b].v, dw, 0, 0, 0);
+        dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awl[b].v, bwh[b].v, dw, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t4 = 0; t4 < 4; t4++) {   // V half: exact fp32
         dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bb[4 * t4], dv, 0, 0, 0);
-        dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].x, bb[4 * t4], dw, 0, 0, 0);
         dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].y, bb[4 * t4 + 1], dv, 0, 0, 0);
-        dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].y, bb[4 * t4 + 1], dw, 0, 0, 0);
         dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].z, bb[4 * t4 + 2], dv, 0, 0, 0);
-        dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].z, bb[4 * t4 + 2], dw, 0, 0, 0);
         dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].w, bb[4 * t4 + 3], dv, 0, 0, 0);
-        dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].w, bb[4 * t4 + 3], dw, 0, 0, 0);
       }
       const f32x4 d = bn < 6 ? dv : dw;
       if (bn < 10) {
