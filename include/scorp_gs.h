@@ -156,6 +156,9 @@ int scorp_gs2d_preprocess(const ScorpGs3dInputs *in, int32_t *out_radii, void *s
                           scorp_stream_t stream);
 int scorp_gs2d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
                       float *out_allmap, scorp_stream_t stream);
+/* As scorp_gs3d_render_image: the same images with nothing left behind for scorp_gs2d_backward. */
+int scorp_gs2d_render_image(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
+                            float *out_allmap, scorp_stream_t stream);
 int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
                         const float *dL_dcolor, const float *dL_dallmap, const ScorpGs3dGrads *grads, void *scratch,
                         size_t scratch_bytes, scorp_stream_t stream);

@@ -54,6 +54,7 @@ EXPORTS = [
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
     "scorp_knn_dist2", "scorp_adam_step", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
+    "scorp_gs2d_render_image",
     "scorp_gs2d_backward", "scorp_gs2d_debug_geom", "scorp_gs2d_debug_tiles", "scorp_gs2d_maps_forward",
     "scorp_gs2d_maps_backward", "scorp_gs2d_regularizers_workspace_bytes", "scorp_gs2d_regularizers_forward",
     "scorp_gs2d_regularizers_backward", "scorp_gs3d_train_view",
@@ -105,6 +106,7 @@ def lib():
     L.scorp_gs2d_backward_scratch_bytes.argtypes = [i32]
     L.scorp_gs2d_preprocess.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, sz, vp]
     L.scorp_gs2d_render.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp]
+    L.scorp_gs2d_render_image.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp]
     L.scorp_gs2d_backward.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, ctypes.POINTER(ScorpGs3dGrads), vp, sz, vp]
     L.scorp_gs2d_debug_geom.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.scorp_gs2d_debug_tiles.argtypes = [vp, vp, u64, i32, i32, i32, vp, vp, vp]

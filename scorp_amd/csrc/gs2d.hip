@@ -310,6 +310,9 @@ __device__ __forceinline__ bool eval_surfel(const float4 e0, const float4 e1, co
 
 constexpr int k2FRing = 128, k2FChunk = 64, k2FGroup = 8;
 
+// kForBackward = false (scorp_gs2d_render_image): no cull verdicts, per-pixel state or contributor bookkeeping is left
+// behind for a backward pass.
+template <bool kForBackward>
 __global__ void __launch_bounds__(64)
 blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                             const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
@@ -355,7 +358,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
     bool hit = false;
     if (id0 != 0xFFFFFFFFu) {
       hit = surfel_reaches_box(r2.y, r2.z, r4, r5, bx0, bx1, by0, by1);
-      hit_flags[(size_t)quad * capacity + beg + base + lane] = hit ? 1 : 0;
+      if constexpr (kForBackward) hit_flags[(size_t)quad * capacity + beg + base + lane] = hit ? 1 : 0;
     }
     const uint64_t m = __ballot(hit);
     if (hit) {
@@ -406,11 +409,11 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
           const bool contributes = ae > 0.0f;
           const bool is_med = contributes & (T > 0.5f);
           med = is_med ? dz[i] : med;
-          med_c = is_med ? pos[i] : med_c;
+          if constexpr (kForBackward) med_c = is_med ? pos[i] : med_c;
           N0 += nr.x * w; N1 += nr.y * w; N2 += nr.z * w;
           C0 += nr.w * w; C1 += gb.x * w; C2 += gb.y * w;
           T = ok ? test_T : -fabsf(T);
-          last = contributes ? pos[i] : last;
+          if constexpr (kForBackward) last = contributes ? pos[i] : last;
         }
       }
       head = (head + k2FGroup) & (k2FRing - 1);
@@ -423,8 +426,10 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
     T = fabsf(T);
-    final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
-    n_contrib[pix] = last; n_contrib[HW + pix] = med_c;
+    if constexpr (kForBackward) {
+      final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
+      n_contrib[pix] = last; n_contrib[HW + pix] = med_c;
+    }
     out_color[pix] = C0 + T * bg[0]; out_color[HW + pix] = C1 + T * bg[1]; out_color[2 * HW + pix] = C2 + T * bg[2];
     allmap[pix] = Dp; allmap[HW + pix] = 1.0f - T;
     allmap[2 * HW + pix] = N0; allmap[3 * HW + pix] = N1; allmap[4 * HW + pix] = N2;
@@ -925,8 +930,8 @@ extern "C" int scorp_gs2d_preprocess(const ScorpGs3dInputs *in, int32_t *out_rad
   return bin_count_and_scan(L, base, N, in->debug, stream);
 }
 
-extern "C" int scorp_gs2d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
-                                 float *out_color, float *out_allmap, scorp_stream_t stream_) {
+static int render2d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
+                         float *out_allmap, scorp_stream_t stream_, bool for_backward) {
   if (int e = validate2(in)) return e;
   hipStream_t stream = (hipStream_t)stream_;
   const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
@@ -939,13 +944,24 @@ extern "C" int scorp_gs2d_render(const ScorpGs3dInputs *in, void *state, void *p
   if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
   {
     ProfScope prof(kKBlendForward2d, stream);
-    blend2d_forward_wave_kernel<<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(
+    auto bk = for_backward ? blend2d_forward_wave_kernel<true> : blend2d_forward_wave_kernel<false>;
+    bk<<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(
         (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
         (uint32_t *)(base + L.n_contrib), (uint8_t *)(pb + P.keys));
   }
   SCORP_KERNEL_CHECK("blend_forward_2d", in->debug, stream);
   return SCORP_OK;
+}
+
+extern "C" int scorp_gs2d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
+                                 float *out_color, float *out_allmap, scorp_stream_t stream) {
+  return render2d_impl(in, state, pairs, capacity, out_color, out_allmap, stream, true);
+}
+
+extern "C" int scorp_gs2d_render_image(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
+                                       float *out_color, float *out_allmap, scorp_stream_t stream) {
+  return render2d_impl(in, state, pairs, capacity, out_color, out_allmap, stream, false);
 }
 
 extern "C" int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,

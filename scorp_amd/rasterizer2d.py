@@ -38,8 +38,8 @@ def _forward2d(ctx, settings, means3D, sh, sh_rest, colors_precomp, opacities, s
             PairPolicy.reserve = max(4 * N, 1 << 20)
         capacity = PairPolicy.reserve
     pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
-    _C.check(L.scorp_gs2d_render(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(allmap), stream),
-             "scorp_gs2d_render")
+    fn = L.scorp_gs2d_render if any(ctx.needs_input_grad) else L.scorp_gs2d_render_image   # nothing to differentiate
+    _C.check(fn(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(allmap), stream), "scorp_gs2d_render")
     if PairPolicy.mode != "exact":
         PairPolicy._pending.append(state[:64].clone())   # the StateHeader only (see rasterizer3d._forward_common)
     ctx.settings, ctx.capacity = settings, capacity

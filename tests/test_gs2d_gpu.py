@@ -311,3 +311,15 @@ def test_fused_surfel_regularizers_match_the_torch_formulation(dev, depth_ratio)
         a, b = getattr(p0, name).grad, getattr(p1, name).grad
         assert torch.isfinite(b).all()
         assert (a - b).abs().max() <= 2e-4 * a.abs().max() + 1e-12, name
+
+
+def test_image_only_render_2d_is_bit_identical(dev):
+    """Without anything to differentiate the front-end takes scorp_gs2d_render_image (no state for a backward pass):
+    colour, radii and the seven allmap channels must equal those of the differentiable render bit for bit."""
+    name = next(iter(CASES))
+    kw, _ = make_case2d(**CASES[name])
+    out_g, _ = hip_render2d(kw, dev)                          # inputs require grad -> scorp_gs2d_render
+    with torch.no_grad():
+        out_n, _ = hip_render2d(kw, dev, requires_grad=False)  # -> scorp_gs2d_render_image
+    for a, b in zip(out_g, out_n):
+        assert torch.equal(a.detach(), b)
