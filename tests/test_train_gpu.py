@@ -188,3 +188,29 @@ def test_training_with_fused_views_matches_the_autograd_loop(dev):
     (la, na), (lb, nb) = out
     assert all(abs(x - y) <= 2e-3 * abs(x) + 1e-6 for x, y in zip(la[:30], lb[:30])), (la[:30], lb[:30])
     assert abs(na - nb) <= 0.02 * na, (na, nb)      # clone / split decisions sit on thresholds: a handful may flip
+
+
+def test_reserve_mode_pends_headers_not_states_and_train_view_checks_its_buffers(dev):
+    """What a reserve-mode view leaves pending until drain() is a copy of the 64-byte state header (a whole forward state
+    per pending view pinned ~110 MB each at 1 M Gaussians); and scorp_gs3d_train_view refuses bad buffers with a message
+    instead of launching anything."""
+    import ctypes
+    from scorp_amd import _C
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams
+    from scorp_amd.train_view import train_view
+    m = GaussianModel.from_raw(make_gaussians(2000, 3, 3, log_scale_mean=math.log(0.03)), 3, device=dev)
+    m.active_sh_degree = 3
+    cam = ring_cameras(3, 96, 64, 1, radius=3.0, device=dev)[0]
+    gt = torch.rand(3, 64, 96, device=dev)
+    PairPolicy.drain()
+    n0 = len(PairPolicy._pending)
+    train_view(cam, m, PipelineParams(), torch.zeros(3, device=dev), gt)
+    assert len(PairPolicy._pending) == n0 + 1 and PairPolicy._pending[-1].numel() == 64
+    assert PairPolicy.drain() > 0
+    L = _C.lib()
+    v = _C.ScorpGs3dTrainView()          # everything NULL
+    assert L.scorp_gs3d_train_view(ctypes.byref(v), None) != 0
+    assert b"NULL" in L.scorp_last_error()
