@@ -132,6 +132,15 @@ int scorp_gs3d_check_overflow(const void *state, scorp_stream_t stream, uint64_t
 int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
                         const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
                         const ScorpGs3dGrads *grads, void *scratch, size_t scratch_bytes, scorp_stream_t stream);
+/* The same with `flags`.  The blend backward reduces over a block's pixels on the matrix cores; by default the two
+ * factors travel as two fp16 terms each (22 bits, exact products, fp32 accumulation: "split" form, the fast one).
+ * SCORP_BACKWARD_EXACT_FP32 selects fp32 MFMAs throughout (the form the reference CUDA's fp32 arithmetic corresponds
+ * to; ~1.3x the blend-backward time): the parity tests compare the two.  scorp_gs3d_backward == flags 0. */
+#define SCORP_BACKWARD_EXACT_FP32 1u
+int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
+                           const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                           const ScorpGs3dGrads *grads, void *scratch, size_t scratch_bytes, uint32_t flags,
+                           scorp_stream_t stream);
 
 /* ---- introspection for stage-level parity tests (device->host copies; synchronises) ---- */
 /* xy[N,2], depth[N], conic_opacity[N,4], rgb[N,3], rect[N,4] (tile units, max exclusive); any may be NULL. */

@@ -50,7 +50,7 @@ EXPORTS = [
     "scorp_version", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
     "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
     "scorp_gs3d_render_image",
-    "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
+    "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_backward_ex", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
     "scorp_knn_dist2", "scorp_adam_step", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
@@ -60,6 +60,8 @@ EXPORTS = [
     "scorp_gs2d_regularizers_backward", "scorp_gs3d_train_view",
     "scorp_prof_enable", "scorp_prof_select", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
 ]
+
+BACKWARD_EXACT_FP32 = 1   # scorp_gs3d_backward_ex flag (include/scorp_gs.h)
 
 _lib = None
 
@@ -92,6 +94,8 @@ def lib():
     L.scorp_gs3d_check_overflow.argtypes = [vp, vp, ctypes.POINTER(u64)]
     L.scorp_gs3d_backward.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp,
                                       ctypes.POINTER(ScorpGs3dGrads), vp, sz, vp]
+    L.scorp_gs3d_backward_ex.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp,
+                                         ctypes.POINTER(ScorpGs3dGrads), vp, sz, ctypes.c_uint32, vp]
     L.scorp_gs3d_debug_geom.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.scorp_gs3d_debug_tiles.argtypes = [vp, vp, u64, i32, i32, i32, vp, vp, vp]
     L.scorp_loss_workspace_bytes.restype = sz

@@ -81,6 +81,13 @@ __device__ __forceinline__ float conic_min_over_box(float cx, float cy, float A,
   return best;
 }
 
+// log2(opacity * G) of a splat at a pixel: L + A' dx^2 + C' dy^2 + B' dx dy with (dx, dy) = splat centre - pixel, the conic
+// pre-scaled by -log2(e)/2 (B' by -log2(e)) and L = log2(opacity).  Horner form, 5 VALU after dx, dy; the forward and the
+// backward blend share it so that both see the same alpha bit for bit.
+__device__ __forceinline__ float splat_exponent(float dx, float dy, float A, float B, float C, float L) {
+  return __builtin_fmaf(__builtin_fmaf(A, dx, B * dy), dx, __builtin_fmaf(C * dy, dy, L));
+}
+
 // A float in the constant address space: uniform loads through such a pointer go to the scalar cache (s_load) instead of
 // occupying VMEM slots.  Only for data no kernel of the same launch writes (camera matrices).
 typedef __attribute__((address_space(4))) float CFloat;

@@ -17,11 +17,9 @@ namespace {
 // matrix cores.
 //
 // For one splat the ten sums over pixels factor as  sum_p v_p * {1, x_p, y_p, x_p^2, x_p y_p, y_p^2}  (geometry:
-// v_p = G * opacity * dL/dalpha, pixel coordinates relative to the tile centre) and  sum_p w_p * {dL/dr, dL/dg, dL/db,
-// dL/ddepth}_p  (w_p = alpha * T).  With a wave's 64 pixels as the K dimension that is D[16 splats][16] =
-// [V | W](16 x 128) * [basis_v ; basis_w](128 x 16): 32 exact-fp32 v_mfma_f32_16x16x4_f32 per 16 splats instead of
-// 60 cross-lane shuffles per splat.  (A lane supplies one column of the basis, so the V and the W product run as two
-// independent chains over ONE basis register array and the lane keeps the result that belongs to its column.)
+// v_p = G * opacity * dL/dalpha, pixel coordinates relative to the block centre) and  sum_p w_p * {dL/dr, dL/dg, dL/db,
+// dL/ddepth}_p  (w_p = alpha * T).  With a wave's 64 pixels as the K dimension that is
+// D[16 splats][16 columns] = [V | W] * [basis_v ; basis_w].
 //
 // Per wave and 16-splat group:
 //   1a (straight-line, no dependence between splats): alpha and G*opacity of the 16 splats at this lane's pixel;
@@ -31,25 +29,40 @@ namespace {
 //      collapse into ONE, because only their dot product with this pixel's upstream gradient is ever used:
 //      s = c.dL/dcolor + z*dL/ddepth + dL/dalpha,  R <- last_alpha * s_last + (1 - last_alpha) * R,
 //      dL/dalpha_i = (s - R) * T - T_final / (1 - alpha) * (bg . dL/dcolor);
-//   lane (= pixel) writes v, w into a wave-private LDS matrix [slot][pixel] (row stride 68 floats: conflict-free row
-//   writes, 16-byte-aligned rows for the transposed A-operand reads); the per-pixel basis is loop-invariant and lives
-//   in 16 registers as the B operand;
+//   lane (= pixel) writes v, w into two wave-private LDS matrices [slot][pixel] (row stride 68 dwords: conflict-free
+//   row writes, 16-byte-aligned rows for the transposed A-operand reads);
 //   the 16x16 MFMA result holds block-frame moments, which sixteen lanes turn into the ten screen-space gradients;
 //   they are flushed with float atomics shaped as whole 40-byte row segments (lanes = consecutive floats).
+//
+// Two forms of the reduction (template parameter kExact, entry point scorp_gs3d_backward_ex):
+//   * SPLIT (default): v and w leave the lane as TWO fp16 terms each - h1 = rtz16(x), h2 = rtz16(x - h1), 22 bits
+//     together (fp32 carries 24) - packed (v | w) into one dword per term, so a slot costs one ds_write2_b32.  With
+//     K = (pixel, v-or-w) the whole reduction is 8 v_mfma_f32_16x16x32_f16 per group (two passes, one per term, over
+//     ONE B operand): columns 0..5 hold the position basis (half-integer block coordinates and their products, exact
+//     in fp16) against the v slots, columns 6..9 / 10..13 the high / low fp16 term of the upstream gradients against
+//     the w slots.  The products are exact and accumulate in fp32.  Range: the pixel's upstream gradients are
+//     pre-scaled by a power of two chosen per wave from the block's largest |dL/dpixel| (so v sits around 2^7 ... and
+//     the conversion saturates, RTZ, instead of overflowing), w by 2^10; the sums are unscaled by exact powers of two.
+//   * EXACT (kExact): v and w stay fp32, 16 + 16 v_mfma_f32_16x16x4_f32 per group (fp32 MFMAs run at the fp32 VALU
+//     rate and their time is paid in full, scripts/mb_mfma_valu.hip: 608 -> 128 matrix cycles per group is what the
+//     split form buys).  The parity tests compare the two forms with each other and each with the oracle.
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-// The W half of the reduction (blend weights x upstream colour / depth gradients: plain sums, no cancellation
-// afterwards) runs on v_mfma_f32_16x16x32_bf16 with both factors split into two bf16 terms (truncated high part +
-// remainder; the product keeps hi*hi + hi*lo + lo*hi, relative error ~2^-16): 6 MFMAs of 16 cycles instead of 16 of 32,
-// and fp32 MFMA time is paid in full on this chip (scripts/mb_mfma_valu.hip).  The V half (moments that are
-// afterwards re-centred on the splat, a cancelling operation) stays on exact fp32 MFMAs.
-constexpr int kWStride = 72;                 // bf16 elements per slot row of the w matrices (144 B: conflict-free b128 reads)
-constexpr int kXStride = 68;                 // floats per slot row of the wave-private v / w matrices: rows stay 16-byte
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kXStride = 68;                 // dwords per slot row of the wave-private matrices: rows stay 16-byte
                                              // aligned for the A-operand's ds_read_b128; row writes are conflict-free
 constexpr int kGroup = 16;                   // splats per MFMA group
+constexpr int kDStride = 16;                 // floats per slot row of the 16 x 14 result tile
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kVTargetExp = 7;               // split form: the block's largest |dL/dpixel| is scaled into [2^7, 2^8)
+constexpr int kVTargetExpDA = 4;             // ... [2^4, 2^5) when depth / alpha gradients (depth values!) take part
+constexpr float kWScale = 1024.0f;           // split form: blend weights (<= 1) are carried as w * 2^10
 
+__device__ __forceinline__ uint32_t pack_rtz16(float lo, float hi) {   // (fp16 rtz(lo)) | (fp16 rtz(hi)) << 16
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+}
+__device__ __forceinline__ float half_lo(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p & 0xFFFFu)); }
+__device__ __forceinline__ float half_hi(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p >> 16)); }
 
 // ---------------------------------------------------------------------------------------------------------
 // B1w: the replay with ONE WAVE PER 8x8 PIXEL BLOCK as the unit of work (64-thread workgroups, no workgroup
@@ -63,7 +76,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kRing = 64, kChunk = 32;
 
-template <bool kHasDA>  // false: no upstream gradient on the depth / alpha images (the photometric-loss-only step)
+template <bool kHasDA, bool kExact>  // kHasDA false: no upstream gradient on the depth / alpha images (the photometric-loss-only step)
 __global__ void __launch_bounds__(64, 3)
 blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                            const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
@@ -75,11 +88,11 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   // opacity * G = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity)
   __shared__ float4 q_a[kRing], q_b[kRing], q_c[kRing];
   __shared__ __attribute__((aligned(16))) uint32_t q_id[kRing], q_pos[kRing];
-  __shared__ __attribute__((aligned(16))) float xv[kGroup * kXStride];
-  __shared__ __attribute__((aligned(16))) uint16_t xwh[kGroup * kWStride], xwl[kGroup * kWStride];   // w = hi + lo (bf16 bits)
-  float *dbuf = reinterpret_cast<float *>(xwh);  // the 16x12 result tile reuses the w matrix once the MFMAs have consumed it
-  float *xs = reinterpret_cast<float *>(xwh);    // prologue scratch: 64 x 4 floats spanning xwh and the start of xwl
-  static_assert(sizeof(uint16_t) * kGroup * kWStride * 2 >= 64 * 4 * sizeof(float), "prologue scratch fits");
+  // [slot][pixel] matrices.  split form: x1 = first fp16 terms (v | w << 16), x2 = second terms; exact form: x1 = v, x2 = w (fp32)
+  __shared__ __attribute__((aligned(16))) uint32_t x1[kGroup * kXStride], x2[kGroup * kXStride];
+  float *dbuf = reinterpret_cast<float *>(x1);   // the 16 x 14 result tile reuses x1 once the MFMAs have consumed it
+  float *xs = reinterpret_cast<float *>(x1);     // prologue scratch: 64 x 4 floats
+  static_assert(kGroup * kDStride <= kGroup * kXStride && 64 * 4 <= kGroup * kXStride, "scratch fits");
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
@@ -105,51 +118,75 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     if (kHasDA && dL_dalpha) dalp = dL_dalpha[pix];
   }
   if (last == 0) { dpix0 = dpix1 = dpix2 = ddep = dalp = 0.0f; }
-  const float tf_bg = T_final * (bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2);
   uint32_t todo = last;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
   todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // tell the compiler it is wave-uniform: the chunk loop,
   if (todo == 0) return;                                        // ring head / count and slot indices then live in SGPRs
-  const int bn = lane & 15, bk = lane >> 4;
-  float bb[16];
-  // B operand.  A lane supplies ONE column bn of the 16-column basis: columns 0..5 are the position basis of the V half
-  // (1, x, y, x^2, xy, y^2 in the block frame), 6..9 the upstream gradients (dL/dr, dL/dg, dL/db, dL/ddepth) of the W
-  // half — so one register array serves both halves; the V and W products accumulate separately and the lane keeps the
-  // one that belongs to its column.  Every lane already holds its own pixel's four gradients, so they are exchanged
-  // through LDS (xw is idle until the first group) instead of being gathered from global memory again.
-  xs[lane * 4 + 0] = dpix0; xs[lane * 4 + 1] = dpix1; xs[lane * 4 + 2] = dpix2; xs[lane * 4 + 3] = ddep;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  // split form: one power-of-two scale per wave from the block's largest upstream gradient
+  float sv = 1.0f, inv_sv = 1.0f;
+  if constexpr (!kExact) {
+    float amax = fmaxf(fmaxf(fabsf(dpix0), fabsf(dpix1)), fabsf(dpix2));
+    if (kHasDA) amax = fmaxf(amax, fmaxf(fabsf(ddep), fabsf(dalp)));
 #pragma unroll
-  for (int t = 0; t < 16; t++) {   // fp32 B operand of the V half: MFMA t covers pixels t, t + 16, t + 32, t + 48
-    const int q = t + 16 * bk;
-    const int qx = bx + (q & 7), qy = by + (q >> 3);
-    const float xl = (float)qx - cx, yl = (float)qy - cy;
-    float v = 0.0f;
-    v = bn == 0 ? 1.0f : v; v = bn == 1 ? xl : v; v = bn == 2 ? yl : v;
-    v = bn == 3 ? xl * xl : v; v = bn == 4 ? xl * yl : v; v = bn == 5 ? yl * yl : v;
-    bb[t] = v;
+    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xFFu);            // biased exponent; 0: zero / denormal
+    int sb = eb == 0 ? 127 : 254 + (kHasDA ? kVTargetExpDA : kVTargetExp) - eb;   // biased exponent of the scale
+    sb = min(max(sb, 1), 253);
+    sv = __uint_as_float((uint32_t)sb << 23);
+    inv_sv = __uint_as_float((uint32_t)(254 - sb) << 23);
   }
-  // bf16 B operand of the W half: bf16 MFMA b (0, 1) covers pixels 32 b + 8 bk + j, j = 0..7, of column bn
-  union Frag { bf16x8 v; uint16_t h[8]; uint4 q; };
-  Frag bwh[2], bwl[2];
-#pragma unroll
-  for (int b = 0; b < 2; b++)
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int q = 32 * b + 8 * bk + j;
-      const float w = (bn >= 6 && bn <= 9) ? xs[q * 4 + ((bn - 6) & 3)] : 0.0f;
-      const uint32_t hb = __float_as_uint(w) & 0xFFFF0000u;
-      const float rem = w - __uint_as_float(hb);
-      bwh[b].h[j] = (uint16_t)(hb >> 16);
-      bwl[b].h[j] = (uint16_t)(__float_as_uint(rem) >> 16);
-    }
+  // In the split form the recurrence runs on T' = 2^10 T (so that w' = alpha T' is the scaled blend weight at no cost)
+  // and on upstream gradients scaled by sv / 2^10, which makes dL/dalpha come out scaled by sv:
+  //   sv dL/dalpha = (s'' - R'') T' - (sv T_final bg.dL/dcolor) / (1 - alpha).
+  const float tf_bg = sv * (T_final * (bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2));
+  const int bn = lane & 15, bk = lane >> 4;
+  // Every lane already holds its own pixel's four gradients, so the B operand's W columns are exchanged through LDS
+  // (the matrices are idle until the first group) instead of being gathered from global memory again.
+  xs[lane * 4 + 0] = sv * dpix0; xs[lane * 4 + 1] = sv * dpix1; xs[lane * 4 + 2] = sv * dpix2; xs[lane * 4 + 3] = sv * ddep;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
+  // B operand.  A lane supplies ONE column bn of the 16-column basis: columns 0..5 are the position basis of the V half
+  // (1, x, y, x^2, xy, y^2 in the block frame), the following ones the upstream gradients (dL/dr, dL/dg, dL/db,
+  // dL/ddepth) of the W half.
+  union Frag { f16x8 v; uint4 q; uint32_t d[4]; };
+  float bb[kExact ? 16 : 1];
+  Frag bh[kExact ? 1 : 4];
+  if constexpr (kExact) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) {   // fp32 MFMA t covers pixels t, t + 16, t + 32, t + 48
+      const int q = t + 16 * bk;
+      const float xl = (float)(q & 7) - 3.5f, yl = (float)(q >> 3) - 3.5f;
+      float v = 0.0f;
+      v = bn == 0 ? 1.0f : v; v = bn == 1 ? xl : v; v = bn == 2 ? yl : v;
+      v = bn == 3 ? xl * xl : v; v = bn == 4 ? xl * yl : v; v = bn == 5 ? yl * yl : v;
+      v = (bn >= 6 && bn <= 9) ? xs[q * 4 + ((bn - 6) & 3)] : v;
+      bb[t] = v;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; m++)      // fp16 MFMA m covers pixels 16 bk + 4 m + j, j = 0..3: element 2j = v slot, 2j + 1 = w slot
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = 16 * bk + 4 * m + j;
+        const float xl = (float)(q & 7) - 3.5f, yl = (float)(q >> 3) - 3.5f;
+        float v = 0.0f;
+        v = bn == 0 ? 1.0f : v; v = bn == 1 ? xl : v; v = bn == 2 ? yl : v;
+        v = bn == 3 ? xl * xl : v; v = bn == 4 ? xl * yl : v; v = bn == 5 ? yl * yl : v;
+        const float g = (bn >= 6 && bn <= 13) ? xs[q * 4 + ((bn - 6) & 3)] : 0.0f;
+        const uint32_t g1 = pack_rtz16(g, 0.0f);
+        const float gw = bn <= 9 ? half_lo(g1) : g - half_lo(g1);     // columns 6..9: first term, 10..13: the remainder
+        bh[m].d[j] = pack_rtz16(v, gw);
+      }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if constexpr (!kExact) {
+    const float sq = sv * (1.0f / kWScale);
+    dpix0 *= sq; dpix1 *= sq; dpix2 *= sq; ddep *= sq; dalp *= sq;
+  }
+  float T = kExact ? T_final : kWScale * T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
   const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
-  const int wbase = (lane & 15) * kWStride + 8 * (lane >> 4);   // bf16 elements: row = slot, pixels 8 bk .. 8 bk + 7 (+ 32)
   int head = 0, count = 0;
 
   // head stays a multiple of kGroup (only a wave's final group is partial), so the slots of a group are head + i
@@ -174,7 +211,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       // 1a + 1b in two halves of 8 splats: the straight-line part keeps only 8 (alpha, G*opacity) pairs live
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        float Go[8], al[8];
+        float Go[8];
         const uint4 pl = *reinterpret_cast<const uint4 *>(gp + h * 8), ph = *reinterpret_cast<const uint4 *>(gp + h * 8 + 4);
         const uint32_t pos8[8] = {pl.x, pl.y, pl.z, pl.w, ph.x, ph.y, ph.z, ph.w};
 #pragma unroll
@@ -183,12 +220,10 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
           const float4 a = ga[i];
           const float2 co = *reinterpret_cast<const float2 *>(&gb[i]);
           const uint32_t pos = pos8[i8];
-          const float dx = a.x - pxf, dy = a.y - pyf;
-          const float e = co.y + a.z * dx * dx + co.x * dy * dy + a.w * dx * dy;   // log2(opacity * G)
+          const float e = splat_exponent(a.x - pxf, a.y - pyf, a.z, a.w, co.x, co.y);   // log2(opacity * G)
           const float g_o = __builtin_amdgcn_exp2f(e);
-          const float alpha = fminf(kAlphaMax, g_o);
-          const bool ok = (kFull || i < nslots) & (pos <= last) & (e <= co.y) & (alpha >= kAlphaMin);
-          al[i8] = ok ? alpha : 0.0f;
+          // alpha = min(0.99, g_o) >= 1/255  <=>  g_o >= 1/255
+          const bool ok = (kFull || i < nslots) & (pos <= last) & (e <= co.y) & (g_o >= kAlphaMin);
           Go[i8] = ok ? g_o : 0.0f;
         }
 #pragma unroll
@@ -197,7 +232,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
           if (kFull || i < nslots) {  // wave-uniform: stale ring entries beyond the group must not enter the recurrence
             const float2 rg = *reinterpret_cast<const float2 *>(&gb[i].z);
             const float2 bz = *reinterpret_cast<const float2 *>(&gc[i]);
-            const float alpha = al[i8];
+            const float alpha = fminf(kAlphaMax, Go[i8]);
             const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
             T *= rinv;
             const float w = alpha * T;
@@ -207,62 +242,79 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
             const float dL_dal = (sc - R) * T - tf_bg * rinv;
             s_last = sc;
             last_alpha = alpha;
-            xv[i * kXStride + lane] = Go[i8] * dL_dal;
-            {  // w = hi + lo as two truncated bf16 (the stores take the upper halves of the registers)
-              const uint32_t hb = __float_as_uint(w) & 0xFFFF0000u;
-              const float rem = w - __uint_as_float(hb);
-              xwh[i * kWStride + lane] = (uint16_t)(hb >> 16);
-              xwl[i * kWStride + lane] = (uint16_t)(__float_as_uint(rem) >> 16);
+            const float v = Go[i8] * dL_dal;
+            if constexpr (kExact) {
+              x1[i * kXStride + lane] = __float_as_uint(v);
+              x2[i * kXStride + lane] = __float_as_uint(w);
+            } else {   // x = h1 + h2, two fp16 terms (round toward zero, saturating); v and w share the dwords
+              const uint32_t p1 = pack_rtz16(v, w);
+              const uint32_t p2 = pack_rtz16(__builtin_fmaf(half_lo(p1), -1.0f, v), __builtin_fmaf(half_hi(p1), -1.0f, w));
+              x1[i * kXStride + lane] = p1;
+              x2[i * kXStride + lane] = p2;
             }
           }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      f32x4 dv = {0.0f, 0.0f, 0.0f, 0.0f}, dw = {0.0f, 0.0f, 0.0f, 0.0f};
-      // A operands: the lane's 16 + 16 values are consecutive in its row, fetched as eight 16-byte reads issued
-      // together; the V chain and the W chain are independent and interleave on the matrix pipe
-      float4 av[4];
-      Frag awh[2], awl[2];
+      f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+      // A operands: the lane's 16 pixels per matrix are consecutive in its row, fetched as eight 16-byte reads issued together
+      if constexpr (kExact) {
+        f32x4 dv = {0.0f, 0.0f, 0.0f, 0.0f}, dw = {0.0f, 0.0f, 0.0f, 0.0f};
+        float4 av[4], aw[4];
 #pragma unroll
-      for (int t4 = 0; t4 < 4; t4++) av[t4] = *reinterpret_cast<const float4 *>(&xv[abase + 4 * t4]);
+        for (int t4 = 0; t4 < 4; t4++) {
+          av[t4] = *reinterpret_cast<const float4 *>(&x1[abase + 4 * t4]);
+          aw[t4] = *reinterpret_cast<const float4 *>(&x2[abase + 4 * t4]);
+        }
 #pragma unroll
-      for (int b = 0; b < 2; b++) {
-        awh[b].q = *reinterpret_cast<const uint4 *>(&xwh[wbase + 32 * b]);
-        awl[b].q = *reinterpret_cast<const uint4 *>(&xwl[wbase + 32 * b]);
+        for (int t4 = 0; t4 < 4; t4++) {   // two independent chains interleave on the matrix pipe
+          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bb[4 * t4], dv, 0, 0, 0);
+          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].x, bb[4 * t4], dw, 0, 0, 0);
+          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].y, bb[4 * t4 + 1], dv, 0, 0, 0);
+          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].y, bb[4 * t4 + 1], dw, 0, 0, 0);
+          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].z, bb[4 * t4 + 2], dv, 0, 0, 0);
+          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].z, bb[4 * t4 + 2], dw, 0, 0, 0);
+          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].w, bb[4 * t4 + 3], dv, 0, 0, 0);
+          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].w, bb[4 * t4 + 3], dw, 0, 0, 0);
+        }
+        d = bn < 6 ? dv : dw;
+      } else {
+        Frag a1[4], a2[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          a1[m].q = *reinterpret_cast<const uint4 *>(&x1[abase + 4 * m]);
+          a2[m].q = *reinterpret_cast<const uint4 *>(&x2[abase + 4 * m]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[m].v, bh[m].v, d, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[m].v, bh[m].v, d, 0, 0, 0);
       }
+      if (bn < 14) {
 #pragma unroll
-      for (int b = 0; b < 2; b++) {   // W half: hi*hi + hi*lo + lo*hi on the bf16 matrix path
-        dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awh[b].v, bwh[b].v, dw, 0, 0, 0);
-        dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awh[b].v, bwl[b].v, dw, 0, 0, 0);
-        dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(awl[b].v, bwh[b].v, dw, 0, 0, 0);
-      }
-#pragma unroll
-      for (int t4 = 0; t4 < 4; t4++) {   // V half: exact fp32
-        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bb[4 * t4], dv, 0, 0, 0);
-        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].y, bb[4 * t4 + 1], dv, 0, 0, 0);
-        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].z, bb[4 * t4 + 2], dv, 0, 0, 0);
-        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].w, bb[4 * t4 + 3], dv, 0, 0, 0);
-      }
-      const f32x4 d = bn < 6 ? dv : dw;
-      if (bn < 10) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) dbuf[(4 * bk + r) * kAccStride + bn] = d[r];
+        for (int r = 0; r < 4; r++) dbuf[(4 * bk + r) * kDStride + bn] = d[r];
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (lane < nslots) {  // block-frame moments -> the ten screen-space gradients of slot `lane`
-        float *m = dbuf + lane * kAccStride;
+        float *m = dbuf + lane * kDStride;
         const float4 a = ga[lane];
         const float4 b = gb[lane];
         const float opac = gc[lane].z;
         const float cA = a.z * (-2.0f / kLog2e), cB = a.w * (-1.0f / kLog2e), cC = b.x * (-2.0f / kLog2e);
         const float xl = a.x - cx, yl = a.y - cy;
-        const float m0 = m[0], mx = m[1], my = m[2], mxx = m[3], mxy = m[4], myy = m[5];
+        const float m0 = m[0] * inv_sv, mx = m[1] * inv_sv, my = m[2] * inv_sv, mxx = m[3] * inv_sv, mxy = m[4] * inv_sv,
+                    myy = m[5] * inv_sv;
         const float svdx = xl * m0 - mx, svdy = yl * m0 - my;
         const float svdx2 = xl * xl * m0 - 2.0f * xl * mx + mxx;
         const float svdxdy = xl * yl * m0 - xl * my - yl * mx + mxy;
         const float svdy2 = yl * yl * m0 - 2.0f * yl * my + myy;
+        if constexpr (!kExact) {   // W sums: first-term + remainder columns, unscaled
+          const float inv_w = inv_sv * (1.0f / kWScale);
+#pragma unroll
+          for (int c = 0; c < 4; c++) m[6 + c] = (m[6 + c] + m[10 + c]) * inv_w;
+        }
         m[0] = 0.5f * W * (-cA * svdx - cB * svdy);
         m[1] = 0.5f * H * (-cC * svdy - cB * svdx);
         m[2] = -0.5f * svdx2;
@@ -282,7 +334,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
         const int sl = f / 10, col = f - sl * 10;
         park_v[k] = 0.0f;
         if (sl < nslots) {
-          park_v[k] = dbuf[sl * kAccStride + col];
+          park_v[k] = dbuf[sl * kDStride + col];
           park_o[k] = q_id[head + sl] * (uint32_t)kAccStride + col;
         }
       }
@@ -358,6 +410,14 @@ extern "C" int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state,
                                    const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
                                    const ScorpGs3dGrads *grads, void *scratch, size_t scratch_bytes,
                                    scorp_stream_t stream_) {
+  return scorp_gs3d_backward_ex(in, state, pairs, capacity, dL_dcolor, dL_ddepth, dL_dalpha, grads, scratch, scratch_bytes,
+                                0u, stream_);
+}
+
+extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
+                                      const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                                      const ScorpGs3dGrads *grads, void *scratch, size_t scratch_bytes, uint32_t flags,
+                                      scorp_stream_t stream_) {
   if (!in || !state || !pairs || !grads || !scratch) { set_error("NULL argument to scorp_gs3d_backward"); return SCORP_ERR_INVALID; }
   if (!dL_dcolor) { set_error("dL_dcolor is NULL"); return SCORP_ERR_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
@@ -380,7 +440,9 @@ extern "C" int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state,
   {
     ProfScope prof(kKBlendBackward, stream);
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
-    auto wk = (dL_ddepth || dL_dalpha) ? blend_backward_wave_kernel<true> : blend_backward_wave_kernel<false>;
+    const bool da = dL_ddepth || dL_dalpha, exact = (flags & SCORP_BACKWARD_EXACT_FP32) != 0;
+    auto wk = exact ? (da ? blend_backward_wave_kernel<true, true> : blend_backward_wave_kernel<false, true>)
+                    : (da ? blend_backward_wave_kernel<true, false> : blend_backward_wave_kernel<false, false>);
     wk<<<blocks, 64, 0, stream>>>(
         (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const SplatRec *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),

@@ -436,13 +436,19 @@ sort_tiles_reg_kernel(const uint32_t *__restrict__ tile_start, const uint64_t *_
 // does not contribute to a pixel enters as alpha = 0, which changes nothing).  Stops as soon as all 64 pixels are
 // saturated.  The four waves of a tile are numbered onto the same XCD.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kFRing = 128, kFChunk = 64, kFGroup = 8;
+#ifndef SCORP_FWD_GROUP
+#define SCORP_FWD_GROUP 8
+#endif
+#ifndef SCORP_FWD_WAVES
+#define SCORP_FWD_WAVES 1
+#endif
+constexpr int kFRing = 128, kFChunk = 64, kFGroup = SCORP_FWD_GROUP;
 constexpr float kLog2eF = 1.4426950408889634f;
 
 // kForBackward = false (scorp_gs3d_render_image): nothing is left behind for a backward pass - no cull verdicts, no
 // per-pixel final T / last contributor, no bookkeeping of the last contributor in the blend loop.
 template <bool kForBackward>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, SCORP_FWD_WAVES)
 blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
@@ -514,15 +520,18 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       const float2 *gc = q_c + hv;
       const uint32_t *gp = q_pos + hv;
       float al[kFGroup];
-      static_assert(kFGroup == 8, "positions are fetched as two 16-byte LDS reads");
-      const uint4 pl = *reinterpret_cast<const uint4 *>(gp), ph = *reinterpret_cast<const uint4 *>(gp + 4);
-      const uint32_t pos[kFGroup] = {pl.x, pl.y, pl.z, pl.w, ph.x, ph.y, ph.z, ph.w};
+      static_assert(kFGroup % 4 == 0, "positions are fetched as 16-byte LDS reads");
+      uint32_t pos[kFGroup];
+#pragma unroll
+      for (int i = 0; i < kFGroup; i += 4) {
+        const uint4 p4 = *reinterpret_cast<const uint4 *>(gp + i);
+        pos[i] = p4.x; pos[i + 1] = p4.y; pos[i + 2] = p4.z; pos[i + 3] = p4.w;
+      }
 #pragma unroll
       for (int i = 0; i < kFGroup; i++) {
         const float4 qa = ga[i];
         const float2 co = *reinterpret_cast<const float2 *>(&gb[i]);
-        const float dx = qa.x - pxf, dy = qa.y - pyf;
-        const float e = co.y + qa.z * dx * dx + co.x * dy * dy + qa.w * dx * dy;   // log2(opacity * G)
+        const float e = splat_exponent(qa.x - pxf, qa.y - pyf, qa.z, qa.w, co.x, co.y);   // log2(opacity * G)
         const float alpha = fminf(kAlphaMax, __builtin_amdgcn_exp2f(e));
         al[i] = ((kFull || i < nslots) & (e <= co.y) & (alpha >= kAlphaMin)) ? alpha : 0.0f;   // e <= log2 o: power <= 0
       }

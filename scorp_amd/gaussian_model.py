@@ -80,6 +80,10 @@ class OptimizationParams:
     densify_until_iter = 25_000
     densify_grad_threshold = 0.0002
     random_background = True
+    # prune thresholds handed to densify_and_prune (gs3dgs/arguments/__init__.py:94-95; train_3dgs.py:184-185)
+    opacity_cull = 0.6
+    max_screen_size = 0.5
+    lambda_normal = 0.05
     # depth / regularisation terms (gs3dgs/arguments/__init__.py:91-99)
     lambda_depth_sensor = 1.5
     lambda_isotropic = 0.0005
@@ -93,8 +97,12 @@ class OptimizationParams2D(OptimizationParams):
     lambda_dist = 0.0
     lambda_normal = 0.05
     lambda_isotropic = 0.0001
+    opacity_cull = 0.5           # gs2dgs/arguments/__init__.py:101-102; train_2dgs.py:193-194
+    max_screen_size = 0.2
     dn_l1_weight_init = 0.2
     dn_l1_weight_final = 0.05
+    dn_box_p = 128
+    dn_p_corr = 0.5
 
 
 class GaussianModel:

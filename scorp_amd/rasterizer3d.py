@@ -7,7 +7,9 @@ colors_precomp, opacities, scales, rotations, cov3D_precomp) -> (color[3,H,W], r
 alpha[1,H,W])`, differentiable w.r.t. all eight arguments.  PyTorch supplies device memory, the current
 stream and autograd bookkeeping; every kernel is in the HIP library, reached through ctypes.
 """
+import contextlib
 import ctypes
+import threading
 from typing import NamedTuple
 
 import torch
@@ -62,6 +64,24 @@ class PairPolicy:
         if err:
             raise RuntimeError(f"pair reservation too small ({err}); reservation grown to {cls.reserve}, re-run the view(s)")
         return worst
+
+
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def backward_precision(mode):
+    """Forwards issued inside `with backward_precision("exact_fp32"):` run their backward with fp32 MFMAs throughout
+    (scorp_gs3d_backward_ex, SCORP_BACKWARD_EXACT_FP32) instead of the default two-term fp16 split of the pixel->splat
+    reduction.  The choice is recorded per forward (thread-local while the block is active), so a backward that runs
+    after the block still honours it.  Used by the parity tests to compare the two forms."""
+    assert mode in ("split", "exact_fp32")
+    prev = getattr(_tls, "backward_flags", 0)
+    _tls.backward_flags = _C.BACKWARD_EXACT_FP32 if mode == "exact_fp32" else 0
+    try:
+        yield
+    finally:
+        _tls.backward_flags = prev
 
 
 LAST_NUM_PAIRS_LOG = []   # pair counts of the most recent "exact"-mode forwards (diagnostics / bench bookkeeping)
@@ -164,9 +184,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ga = _prep(grad_alpha, "grad_alpha") if grad_alpha is not None else None
         scratch_bytes = L.scorp_gs3d_backward_scratch_bytes(N)
         scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
-        _C.check(L.scorp_gs3d_backward(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(gd),
-                                       _ptr(ga), ctypes.byref(grads), _ptr(scratch), scratch_bytes, _stream()),
-                 "scorp_gs3d_backward")
+        _C.check(L.scorp_gs3d_backward_ex(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(gd),
+                                          _ptr(ga), ctypes.byref(grads), _ptr(scratch), scratch_bytes, ctx.backward_flags,
+                                          _stream()),
+                 "scorp_gs3d_backward_ex")
         return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None
 
 
@@ -206,6 +227,7 @@ def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opaciti
         # flag) - not the state itself, or every pending view would pin ~100 MB of device memory until the drain
         PairPolicy._pending.append(state[:64].clone())
     ctx.settings, ctx.capacity = settings, capacity
+    ctx.backward_flags = getattr(_tls, "backward_flags", 0)
     ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward: the kernels skip those terms
     return color, radii, depth, alpha, state, pairs, keep
 
@@ -253,9 +275,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ga = _prep(grad_alpha, "grad_alpha") if grad_alpha is not None else None
         scratch_bytes = L.scorp_gs3d_backward_scratch_bytes(N)
         scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
-        _C.check(L.scorp_gs3d_backward(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(gd),
-                                       _ptr(ga), ctypes.byref(grads), _ptr(scratch), scratch_bytes, _stream()),
-                 "scorp_gs3d_backward")
+        _C.check(L.scorp_gs3d_backward_ex(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(gd),
+                                          _ptr(ga), ctypes.byref(grads), _ptr(scratch), scratch_bytes, ctx.backward_flags,
+                                          _stream()),
+                 "scorp_gs3d_backward_ex")
         return (g_means3D, g_means2D, g_dc if need[2] else None, g_rest if need[3] else None, g_op, g_sc, g_rot, None)
 
 

@@ -48,7 +48,7 @@ def _sync_densification_stats(gaussians):
 
 def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteration, scene_extent=4.0, densify=True,
                        render_fn=render, loss_fn=fused_l1_ssim_loss, data_parallel=False, gt_depth=None, gt_depth_est=None,
-                       surfels=False, fused_view=False):
+                       surfels=False, fused_view=False, white_background=False):
     """Returns (loss tensor, render package). Mirrors train_3dgs.py:74-193 for one camera.  With `data_parallel` the
     caller hands each rank a different camera; gradients are averaged over ranks before the optimizer step and the
     densification statistics are reduced before they are used, so the replicas stay bit-identical."""
@@ -91,18 +91,18 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
             gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis].float())
             gaussians.add_densification_stats(pkg["viewspace_points"], vis)
             if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
-                size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+                size_threshold = opt.max_screen_size if iteration > opt.opacity_reset_interval else None   # train_3dgs.py:184
                 if data_parallel:
                     _sync_densification_stats(gaussians)
                     torch.manual_seed(1_000_003 * iteration)   # densify_and_split samples positions: same draw on every rank
                 n_before = gaussians.get_xyz.shape[0]
-                gaussians.densify_and_prune(opt.densify_grad_threshold, 0.005, scene_extent, size_threshold)
+                gaussians.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, scene_extent, size_threshold)
                 n_after = gaussians.get_xyz.shape[0]
                 if fused_view and n_after > n_before and PairPolicy.reserve > 0:
                     # the one-call view never asks for the pair count: let the reservation grow with the model
                     PairPolicy.reserve = max(PairPolicy.reserve, int(PairPolicy.reserve * (n_after / n_before) * 1.1) + 1024)
-            if iteration % opt.opacity_reset_interval == 0:
-                gaussians.reset_opacity()
+            if iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter):
+                gaussians.reset_opacity()   # train_3dgs.py:187-188
         gaussians.optimizer.step()
         gaussians.optimizer.zero_grad(set_to_none=True)
     return loss, pkg

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 IMG_L1_TOL = 1e-4      # mean |delta| per pixel-channel, the tolerance BASELINE.json's north_star states
 GRAD_REL_TOL = 2e-3    # max |delta| / max |ref| per gradient tensor (float atomics + fast exp vs libm)
+GRAD_L1_TOL = 1e-4     # sum |delta| / sum |ref| per gradient tensor: north_star's "within 1e-4 L1", applied to gradients
 
 
 @pytest.fixture(scope="module")
@@ -60,12 +61,16 @@ def compare_forward(out, o, l1_tol=IMG_L1_TOL):
     assert np.abs(color - o.color).max() < 2e-2
 
 
-def compare_grads(t, g, tol=GRAD_REL_TOL):
+def compare_grads(t, g, tol=GRAD_REL_TOL, l1_tol=GRAD_L1_TOL, report=None):
     def close(name, got, ref):
         got = got.detach().cpu().numpy().reshape(ref.shape)
         scale = max(np.abs(ref).max(), 1e-20)
         err = np.abs(got - ref).max() / scale
+        l1 = np.abs(got.astype(np.float64) - ref).sum() / max(np.abs(ref.astype(np.float64)).sum(), 1e-30)
+        if report is not None:
+            report[name] = (float(err), float(l1))
         assert err < tol, f"grad {name}: max err {err:.3e} of scale {scale:.3e}"
+        assert l1 < l1_tol, f"grad {name}: relative L1 error {l1:.3e} (sum |delta| / sum |ref|)"
     close("means3D", t["means3D"].grad, g["means3D"])
     close("means2D", t["means2D"].grad, g["means2D"])
     close("opacities", t["opacities"].grad, g["opacities"])
@@ -95,12 +100,17 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("precision", ["split", "exact_fp32"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_forward_backward_parity(name, dev):
+def test_forward_backward_parity(name, precision, dev):
+    """Images and all gradients against the oracle, for both forms of the backward's pixel->splat reduction (the default
+    two-term fp16 split on v_mfma_f32_16x16x32_f16 and the all-fp32 MFMA form, scorp_gs3d_backward_ex)."""
+    from scorp_amd.rasterizer3d import backward_precision
     case = dict(CASES[name])
     kw, _ = make_case(**case)
     o = oracle(kw)
-    out, t = hip_render(kw, dev)
+    with backward_precision(precision):
+        out, t = hip_render(kw, dev)
     compare_forward(out, o)
     wc, wd, wa = image_weights(kw["H"], kw["W"], case["seed"])
     color, _, depth, alpha = out
@@ -108,6 +118,35 @@ def test_forward_backward_parity(name, dev):
            (alpha * torch.tensor(wa, device=dev)).sum()
     loss.backward()
     compare_grads(t, o.backward(wc, wd, wa))
+
+
+@pytest.mark.parametrize("name", ["sh3_bg_mod", "tiny_splats", "huge_splats", "inside_cloud"])
+def test_split_backward_equals_exact_fp32_backward(name, dev):
+    """The fast backward (pixel->splat sums on fp16 MFMAs, both factors split into two fp16 terms = 22 bits) against
+    the all-fp32 MFMA backward on the SAME forward: every gradient tensor within 2e-5 relative L1 and 1e-4 of its
+    maximum - float-atomics noise plus 2^-22 per product; upstream gradients scaled by 1e-6 and 1e+4 exercise the
+    per-wave power-of-two range scaling of the split form."""
+    from scorp_amd.rasterizer3d import backward_precision
+    case = dict(CASES[name])
+    kw, _ = make_case(**case)
+    wc, wd, wa = image_weights(kw["H"], kw["W"], case["seed"])
+    for scale, with_da in ((1.0, True), (1e-6, False), (1e4, True)):
+        grads = {}
+        for precision in ("split", "exact_fp32"):
+            with backward_precision(precision):
+                out, t = hip_render(kw, dev)
+            color, _, depth, alpha = out
+            loss = (color * torch.tensor(wc * scale, device=dev)).sum()
+            if with_da:
+                loss = loss + (depth * torch.tensor(wd * scale, device=dev)).sum() + (alpha * torch.tensor(wa * scale, device=dev)).sum()
+            loss.backward()
+            grads[precision] = {k: v.grad.detach().cpu().numpy().astype(np.float64) for k, v in t.items() if v is not None and v.grad is not None}
+        for k, ref in grads["exact_fp32"].items():
+            got = grads["split"][k]
+            assert np.isfinite(got).all()
+            l1 = np.abs(got - ref).sum() / max(np.abs(ref).sum(), 1e-300)
+            mx = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300)
+            assert l1 < 2e-5 and mx < 1e-4, f"{k} (upstream x{scale:g}): rel L1 {l1:.2e}, max {mx:.2e}"
 
 
 def _raw_forward(kw, dev, capacity=None):

@@ -134,6 +134,7 @@ def _dp_setup():
     opt.random_background = False
     opt.densify_from_iter, opt.densification_interval, opt.densify_until_iter = 2, 4, 100
     opt.opacity_reset_interval, opt.densify_grad_threshold = 9, 1e-9
+    opt.opacity_cull, opt.max_screen_size = 0.005, 20   # (the reference's 0.6 / 0.5 would prune all 40 after the opacity reset)
     cams = [_FakeCam(k, 64, 64) for k in range(6)]
     g = torch.Generator().manual_seed(5)
     gts = [torch.rand(3, 8, 8, generator=g) for _ in cams]
@@ -204,7 +205,8 @@ def test_two_rank_data_parallel_training_keeps_replicas_identical():
                 m.add_densification_stats(p["viewspace_points"], vis)
             if it > opt.densify_from_iter and it % opt.densification_interval == 0:
                 torch.manual_seed(1_000_003 * it)
-                m.densify_and_prune(opt.densify_grad_threshold, 0.005, 4.0, 20 if it > opt.opacity_reset_interval else None)
+                m.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, 4.0,
+                                    opt.max_screen_size if it > opt.opacity_reset_interval else None)
             if it % opt.opacity_reset_interval == 0:
                 m.reset_opacity()
             m.optimizer.step()
