@@ -25,11 +25,16 @@ constexpr float kDet2Eps = 0.0000001f;
 
 // ---- device records ----
 // One projected splat as the blend kernels gather it: three 16-byte loads from one 48-byte record.
+// The conic is stored the way the blend exponent uses it (splat_exponent below): with k = log2(e)/2,
+//   A = -k * conic_xx, B = -2k * conic_xy, C = -k * conic_yy, L = log2(opacity),  log2(opacity * G) = L + A dx^2 + B dx dy + C dy^2,
+// so a hit travels from the record to a wave's LDS without per-chunk arithmetic (and could travel by LDS-DMA).
 struct alignas(16) SplatRec {
-  float x, y, A, B;         // pixel-space centre, conic A,B
-  float C, o, r, g;         // conic C, opacity, colour r,g
-  float b, depth, kcut, _;  // colour b, view-space z, cutoff: alpha >= 1/255 only where A dx^2 + 2B dx dy + C dy^2 <= kcut
+  float x, y, A, B;         // pixel-space centre, scaled conic A, B
+  float C, L, r, g;         // scaled conic C, log2(opacity), colour r, g
+  float b, depth, kcut, o;  // colour b, view-space z, cutoff: alpha >= 1/255 only where k * q <= kcut
+                            // (q = conic quadratic form, kcut = k * (2 ln(255 o) plus slack)), opacity
 };
+constexpr float kConicScale = 0.72134752044448170f;   // k = log2(e) / 2
 static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
 
 // What the binning kernels stream per Gaussian (16 bytes, coalesced).
@@ -146,13 +151,18 @@ struct StateLayout {
   }
 };
 
-// Pair buffer: keys[capacity] u64 (depth_bits<<32 | splat) bucketed by tile, then point_list[capacity] u32.
+// Pair buffer: keys[capacity] u64 (depth_bits<<32 | splat) bucketed by tile, then the depth-sorted point_list[capacity]
+// u32.  The keys are dead once the lists are sorted; the blend forward then leaves there, per 8x8 block, what the
+// backward replays: 3DGS the block's HIT LIST hits[quad][capacity] u32 (the splats that passed the exact
+// ellipse-vs-block test, in list order, compacted; 16 bytes per pair, so the region is twice the keys), 2DGS one
+// verdict byte per (quad, entry).
 struct PairLayout {
-  size_t keys, list, total;
+  size_t keys, hits, list, total;
   explicit PairLayout(uint64_t capacity) {
     size_t c = capacity > 0 ? (size_t)capacity : 1;
     keys = 0;
-    list = align_up(c * 8, 256);
+    hits = 0;
+    list = align_up(c * 16, 256);
     total = align_up(list + c * 4, 256);
   }
 };

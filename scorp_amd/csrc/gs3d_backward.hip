@@ -66,28 +66,30 @@ __device__ __forceinline__ float half_hi(uint32_t p) { return (float)__builtin_b
 
 // ---------------------------------------------------------------------------------------------------------
 // B1w: the replay with ONE WAVE PER 8x8 PIXEL BLOCK as the unit of work (64-thread workgroups, no workgroup
-// barriers, no waiting for the slowest wave of a tile).  A wave walks its tile's sorted list back to front 32 entries
-// at a time: each lane reads the forward's verdict of the exact ellipse-vs-block test for one entry and gathers the
-// record only if it passed (flags, list entries and records are fetched two chunks ahead), the survivors are
-// compacted (ballot + popcount) into a 64-entry ring in the wave's own LDS, and whenever 16 are queued they go
-// through the 1a / 1b / MFMA pipeline described above.  The 16x16 result is converted from block-frame moments
-// to the ten gradients by lanes 0..15 and added to the per-Gaussian accumulators with float atomics (zero terms are
-// skipped).  Blocks are numbered so that the four waves of a tile land on the same XCD (same L2).
+// barriers, no waiting for the slowest wave of a tile).  A wave walks its block's HIT LIST (left by the forward: the
+// splats that passed the exact ellipse-vs-block test, compacted, in blend order) back to front 64 hits at a time: each
+// lane gathers one record (list entries are fetched two chunks ahead, records one) into a 64-slot staging buffer in the
+// wave's own LDS, and the chunk's four groups of 16 go through the 1a / 1b / MFMA pipeline described above.  A hit's
+// position in the list is arithmetic (no per-slot position array): slot i of a group whose first slot has 1-based
+// position `top` belongs to the pixel's blend iff top - i <= last contributor of the pixel.  The 16x16 result is
+// converted from block-frame moments to the ten gradients by lanes 0..15 and added to the per-Gaussian accumulators
+// with float atomics (zero terms are skipped).  Blocks are numbered so that the four waves of a tile land on the same
+// XCD (same L2).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kRing = 64, kChunk = 32;
+constexpr int kChunk = 64;
 
 template <bool kHasDA, bool kExact>  // kHasDA false: no upstream gradient on the depth / alpha images (the photometric-loss-only step)
 __global__ void __launch_bounds__(64, 3)
-blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ hits,
                            const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                            const float *__restrict__ bg, const float *__restrict__ final_T,
                            const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
                            const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dalpha,
-                           float *__restrict__ acc, const uint8_t *__restrict__ hit_flags) {
-  // ring entries: (x, y, A', B'), (C', log2 opacity, r, g), (b, depth, opacity, -): conic pre-scaled so that
-  // opacity * G = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity)
-  __shared__ float4 q_a[kRing], q_b[kRing], q_c[kRing];
-  __shared__ __attribute__((aligned(16))) uint32_t q_id[kRing], q_pos[kRing];
+                           float *__restrict__ acc) {
+  // staged records as preprocess stored them: (x, y, A, B), (C, log2 opacity, r, g), (b, depth, -, opacity) with
+  // opacity * G = exp2(A dx^2 + C dy^2 + B dx dy + log2 opacity)
+  __shared__ float4 q_a[kChunk], q_b[kChunk], q_c[kChunk];
+  __shared__ __attribute__((aligned(16))) uint32_t q_id[kChunk];
   // [slot][pixel] matrices.  split form: x1 = first fp16 terms (v | w << 16), x2 = second terms; exact form: x1 = v, x2 = w (fp32)
   __shared__ __attribute__((aligned(16))) uint32_t x1[kGroup * kXStride], x2[kGroup * kXStride];
   float *dbuf = reinterpret_cast<float *>(x1);   // the 16 x 14 result tile reuses x1 once the MFMAs have consumed it
@@ -187,10 +189,6 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   }
   float T = kExact ? T_final : kWScale * T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
   const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
-  int head = 0, count = 0;
-
-  // head stays a multiple of kGroup (only a wave's final group is partial), so the slots of a group are head + i
-  // without wrap-around: one LDS base per array, immediate offsets
   float park_v[3] = {0.0f, 0.0f, 0.0f};      // a group's sums, parked until flush_sums
   uint32_t park_o[3] = {0u, 0u, 0u};           // ... and their float offsets in acc (N * 12 < 2^32, checked at the entry point)
   auto flush_sums = [&]() {
@@ -200,30 +198,29 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       park_v[k] = 0.0f;
     }
   };
-  auto process_group = [&](auto full, int nslots) {
-    flush_sums();   // (a second group of the same chunk: the first one's sums leave now)
+  // slots of a group: head + i, head a multiple of kGroup: one LDS base per array, immediate offsets.  `top` = 1-based
+  // position in the hit list of the group's first slot (positions fall by one per slot)
+  auto process_group = [&](auto full, int nslots, int head, int top) {
+    flush_sums();   // (a later group of the same chunk: the previous one's sums leave now)
     constexpr bool kFull = decltype(full)::value;   // full groups run straight-line; only a wave's last one is partial
     {
       int hv = head;
       asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
       const float4 *ga = q_a + hv, *gb = q_b + hv, *gc = q_c + hv;
-      const uint32_t *gp = q_pos + hv;
-      // 1a + 1b in two halves of 8 splats: the straight-line part keeps only 8 (alpha, G*opacity) pairs live
+      const int first = top - (int)last;   // slot i takes part in this pixel's blend iff top - i <= last, i.e. i >= first
+      // 1a + 1b in two halves of 8 splats: the straight-line part keeps only 8 G*opacity values live
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         float Go[8];
-        const uint4 pl = *reinterpret_cast<const uint4 *>(gp + h * 8), ph = *reinterpret_cast<const uint4 *>(gp + h * 8 + 4);
-        const uint32_t pos8[8] = {pl.x, pl.y, pl.z, pl.w, ph.x, ph.y, ph.z, ph.w};
 #pragma unroll
         for (int i8 = 0; i8 < 8; i8++) {
           const int i = h * 8 + i8;
           const float4 a = ga[i];
           const float2 co = *reinterpret_cast<const float2 *>(&gb[i]);
-          const uint32_t pos = pos8[i8];
           const float e = splat_exponent(a.x - pxf, a.y - pyf, a.z, a.w, co.x, co.y);   // log2(opacity * G)
           const float g_o = __builtin_amdgcn_exp2f(e);
           // alpha = min(0.99, g_o) >= 1/255  <=>  g_o >= 1/255
-          const bool ok = (kFull || i < nslots) & (pos <= last) & (e <= co.y) & (g_o >= kAlphaMin);
+          const bool ok = (kFull || i < nslots) & (i >= first) & (e <= co.y) & (g_o >= kAlphaMin);
           Go[i8] = ok ? g_o : 0.0f;
         }
 #pragma unroll
@@ -301,8 +298,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
         float *m = dbuf + lane * kDStride;
         const float4 a = ga[lane];
         const float4 b = gb[lane];
-        const float opac = gc[lane].z;
-        const float cA = a.z * (-2.0f / kLog2e), cB = a.w * (-1.0f / kLog2e), cC = b.x * (-2.0f / kLog2e);
+        const float opac = gc[lane].w;
+        const float cA = a.z * (-1.0f / kConicScale), cB = a.w * (-0.5f / kConicScale), cC = b.x * (-1.0f / kConicScale);
         const float xl = a.x - cx, yl = a.y - cy;
         const float m0 = m[0] * inv_sv, mx = m[1] * inv_sv, my = m[2] * inv_sv, mxx = m[3] * inv_sv, mxy = m[4] * inv_sv,
                     myy = m[5] * inv_sv;
@@ -341,58 +338,43 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    head = (head + kGroup) & (kRing - 1);   // a partial group is the wave's last one
-    count -= nslots;
   };
 
-  // The chunk's gathers are a chain of dependent loads (flag + list entry -> record) of ~1 us each way; with three
-  // waves per SIMD nothing hides them, so they are software-pipelined two chunks deep: while chunk c is replayed the
-  // records of chunk c+1 and the flags / indices of chunk c+2 are already in flight.
-  auto fetch_idx = [&](uint32_t dn, bool &hit_, uint32_t &id_, uint32_t &pos1_) {
-    hit_ = false; id_ = 0; pos1_ = 0;
-    if (lane < kChunk && dn + lane < todo) {
-      const uint32_t pos0 = todo - 1 - dn - lane;
-      pos1_ = pos0 + 1;
-      hit_ = hit_flags[(size_t)quad * capacity + beg + pos0] != 0;   // the forward's exact ellipse-vs-block verdict
-      id_ = point_list[beg + pos0];
-    }
+  // The chunk's gathers are a chain of dependent loads (hit-list entry -> record) of ~1 us each way; with three waves
+  // per SIMD nothing hides them, so they are software-pipelined two chunks deep: while chunk c is replayed the records
+  // of chunk c+1 and the list entries of chunk c+2 are already in flight.  Chunk c holds the hits at 0-based positions
+  // todo - 64 c - 1 (slot 0) down to todo - 64 c - 64 (slot 63): slots ascend back to front.
+  const uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
+  auto fetch_id = [&](uint32_t c_) {
+    const int o = (int)todo - (int)(kChunk * c_) - 1 - lane;
+    return o >= 0 ? my_hits[o] : 0xFFFFFFFFu;
   };
-  auto fetch_rec = [&](bool hit_, uint32_t id_, float4 &a_, float4 &b_, float4 &c_) {
-    if (hit_) {
+  auto fetch_rec = [&](uint32_t id_, float4 &a_, float4 &b_, float4 &c_) {
+    if (id_ != 0xFFFFFFFFu) {
       const float4 *src = reinterpret_cast<const float4 *>(rec + id_);
       a_ = src[0]; b_ = src[1]; c_ = src[2];
     }
   };
-  bool hit, hit1;
-  uint32_t id, pos1, id1, pos1_1;
   float4 a, b, c;
-  fetch_idx(0, hit, id, pos1);
-  fetch_rec(hit, id, a, b, c);
-  fetch_idx(kChunk, hit1, id1, pos1_1);
-  for (uint32_t done_n = 0; done_n < todo; done_n += kChunk) {
+  uint32_t id = fetch_id(0);
+  fetch_rec(id, a, b, c);
+  uint32_t id1 = fetch_id(1);
+  const uint32_t nchunks = (todo + kChunk - 1) / kChunk;
+  for (uint32_t ch = 0; ch < nchunks; ch++) {
     float4 a1, b1, c1;
-    fetch_rec(hit1, id1, a1, b1, c1);
-    bool hit2;
-    uint32_t id2, pos1_2;
-    fetch_idx(done_n + 2 * kChunk, hit2, id2, pos1_2);
+    fetch_rec(id1, a1, b1, c1);
+    const uint32_t id2 = fetch_id(ch + 2);
     flush_sums();
-    const uint64_t m = __ballot(hit);
-    if (hit) {
-      const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (kRing - 1);
-      q_a[qi] = make_float4(a.x, a.y, -0.5f * kLog2e * a.z, -kLog2e * a.w);
-      q_b[qi] = make_float4(-0.5f * kLog2e * b.x, __builtin_amdgcn_logf(b.y), b.z, b.w);
-      q_c[qi] = make_float4(c.x, c.y, b.y, 0.0f);
-      q_id[qi] = id;
-      q_pos[qi] = pos1;
-    }
-    count += __builtin_popcountll(m);
+    if (id != 0xFFFFFFFFu) { q_a[lane] = a; q_b[lane] = b; q_c[lane] = c; q_id[lane] = id; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const bool last_chunk = done_n + kChunk >= todo;
-    while (count >= kGroup) process_group(std::true_type{}, kGroup);
-    if (last_chunk && count > 0) process_group(std::false_type{}, count);
-    hit = hit1; id = id1; pos1 = pos1_1; a = a1; b = b1; c = c1;
-    hit1 = hit2; id1 = id2; pos1_1 = pos1_2;
+    const int top = (int)todo - (int)(kChunk * ch);          // 1-based position of slot 0
+    const int n = top < kChunk ? top : kChunk;               // hits in this chunk (only the last chunk is short)
+    for (int head = 0; head < n; head += kGroup) {
+      if (n - head >= kGroup) process_group(std::true_type{}, kGroup, head, top - head);
+      else process_group(std::false_type{}, n - head, head, top - head);
+    }
+    id = id1; a = a1; b = b1; c = c1; id1 = id2;
   }
   flush_sums();
 }
@@ -444,9 +426,9 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
     auto wk = exact ? (da ? blend_backward_wave_kernel<true, true> : blend_backward_wave_kernel<false, true>)
                     : (da ? blend_backward_wave_kernel<true, false> : blend_backward_wave_kernel<false, false>);
     wk<<<blocks, 64, 0, stream>>>(
-        (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const SplatRec *)(base + L.rec),
+        (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.hits), (const SplatRec *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),
-        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc, (const uint8_t *)(pb + P.keys));
+        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc);
   }
   SCORP_KERNEL_CHECK("blend_backward", in->debug, stream);
   {

@@ -430,11 +430,14 @@ sort_tiles_reg_kernel(const uint32_t *__restrict__ tile_start, const uint64_t *_
 
 // ---------------------------------------------------------------------------------------------------------
 // K5: front-to-back blend with ONE WAVE PER 8x8 BLOCK as the unit (64-thread workgroups, no workgroup barriers), the
-// forward twin of blend_backward_wave_kernel: the wave walks the tile's list front to back 32 entries at a time, each
+// forward twin of blend_backward_wave_kernel: the wave walks the tile's list front to back 64 entries at a time, each
 // lane gathers one record and runs the exact conic-vs-block test, survivors are compacted into a per-wave LDS ring,
 // and groups of 8 go through a straight-line alpha phase followed by the branch-free sequential blend (a splat that
 // does not contribute to a pixel enters as alpha = 0, which changes nothing).  Stops as soon as all 64 pixels are
 // saturated.  The four waves of a tile are numbered onto the same XCD.
+// For the backward it leaves the block's HIT LIST (the splat ids that passed the test, in list order, compacted, in the
+// dead key region of the pair buffer) and per pixel the final T and the 1-based position IN THAT LIST of the last splat
+// that contributed: the backward replays the hit list and never looks at the tile's list again.
 // ---------------------------------------------------------------------------------------------------------
 #ifndef SCORP_FWD_GROUP
 #define SCORP_FWD_GROUP 8
@@ -443,9 +446,8 @@ sort_tiles_reg_kernel(const uint32_t *__restrict__ tile_start, const uint64_t *_
 #define SCORP_FWD_WAVES 1
 #endif
 constexpr int kFRing = 128, kFChunk = 64, kFGroup = SCORP_FWD_GROUP;
-constexpr float kLog2eF = 1.4426950408889634f;
 
-// kForBackward = false (scorp_gs3d_render_image): nothing is left behind for a backward pass - no cull verdicts, no
+// kForBackward = false (scorp_gs3d_render_image): nothing is left behind for a backward pass - no hit lists, no
 // per-pixel final T / last contributor, no bookkeeping of the last contributor in the blend loop.
 template <bool kForBackward>
 __global__ void __launch_bounds__(64, SCORP_FWD_WAVES)
@@ -453,9 +455,9 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
                           float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                          uint8_t *__restrict__ hit_flags) {
-  // ring entries: (x, y, A', B'), (C', log2 opacity, r, g), (b, depth): conic pre-scaled so that
-  // alpha = exp2(A' dx^2 + C' dy^2 + B' dx dy + log2 opacity), one v_exp and no multiply
+                          uint32_t *__restrict__ hits) {
+  // ring entries: the record's (x, y, A, B), (C, log2 opacity, r, g), (b, depth) as preprocess stored them:
+  // alpha = exp2(A dx^2 + C dy^2 + B dx dy + log2 opacity), one v_exp and no multiply
   __shared__ float4 q_a[kFRing], q_b[kFRing];
   __shared__ float2 q_c[kFRing];
   __shared__ __attribute__((aligned(16))) uint32_t q_pos[kFRing];
@@ -470,10 +472,12 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t n = end - beg;
+  uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
   float T = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f;   // T < 0: pixel finished (see below)
   uint32_t last = 0;
   int head = 0, count = 0;   // head stays a multiple of kFGroup (only a wave's final group is partial), so the
                              // slots of a group are head + i without wrap-around: one LDS base, immediate offsets
+  uint32_t nh = 0;           // hits so far (wave-uniform): a hit's 1-based position in the block's hit list is its `pos`
   // The chunk's gathers (list entry -> record) are dependent loads of ~1 us each; they are software-pipelined: while
   // chunk c is blended the records of chunk c+1 and the list entries of chunk c+2 are already in flight.
   auto fetch_id = [&](uint32_t bs) { return (bs + lane < n) ? point_list[beg + bs + lane] : 0xFFFFFFFFu; };
@@ -493,21 +497,20 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     fetch_rec(id1, a1, b1, c1);
     const uint32_t id2 = fetch_id(base + 2 * kFChunk);
     bool hit = false;
-    if (id0 != 0xFFFFFFFFu) {
-      hit = conic_min_over_box(a.x, a.y, a.z, a.w, b.x, bx0, bx1, by0, by1) <= c.z;
-      // remembered for the backward (one byte per (block, entry), in the pair buffer's key region, which is dead after
-      // the sort): it then gathers and replays only the entries that passed this test
-      if constexpr (kForBackward) hit_flags[(size_t)quad * capacity + beg + base + lane] = hit ? 1 : 0;
-    }
+    if (id0 != 0xFFFFFFFFu)   // the record holds -k * conic and k * cutoff (k > 0): the test is scale-invariant
+      hit = conic_min_over_box(a.x, a.y, -a.z, -0.5f * a.w, -b.x, bx0, bx1, by0, by1) <= c.z;
     const uint64_t m = __ballot(hit);
     if (hit) {
-      const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (kFRing - 1);
-      q_a[qi] = make_float4(a.x, a.y, -0.5f * kLog2eF * a.z, -kLog2eF * a.w);
-      q_b[qi] = make_float4(-0.5f * kLog2eF * b.x, __builtin_amdgcn_logf(b.y), b.z, b.w);
+      const uint32_t rank = nh + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      const int qi = (head + count + (int)(rank - nh)) & (kFRing - 1);
+      q_a[qi] = a;
+      q_b[qi] = b;
       q_c[qi] = make_float2(c.x, c.y);
-      q_pos[qi] = base + lane + 1u;
+      q_pos[qi] = rank + 1u;
+      if constexpr (kForBackward) my_hits[rank] = id0;   // (rank < n: inside this tile's slice of the region)
     }
     count += __builtin_popcountll(m);
+    nh += (uint32_t)__builtin_popcountll(m);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool last_chunk = base + kFChunk >= n;
@@ -736,7 +739,6 @@ static int render_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint
   if (!out_color || !out_depth || !out_alpha) { set_error("output image pointer is NULL"); return SCORP_ERR_INVALID; }
   char *base = (char *)state, *pb = (char *)pairs;
   uint32_t *tile_start = (uint32_t *)(base + L.tile_start);
-  uint64_t *keys = (uint64_t *)(pb + P.keys);
   uint32_t *point_list = (uint32_t *)(pb + P.list);
   if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
   {
@@ -746,7 +748,7 @@ static int render_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint
     bk<<<blocks, 64, 0, stream>>>(
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
         out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib),
-        (uint8_t *)keys);
+        (uint32_t *)(pb + P.hits));
   }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;
@@ -781,7 +783,10 @@ extern "C" int scorp_gs3d_debug_geom(const void *state, int32_t N, int32_t W, in
     const SplatRec &s = vis ? hrec[i] : z;
     if (xy) { xy[2 * i] = s.x; xy[2 * i + 1] = s.y; }
     if (depth) depth[i] = s.depth;
-    if (conic_opacity) { conic_opacity[4 * i] = s.A; conic_opacity[4 * i + 1] = s.B; conic_opacity[4 * i + 2] = s.C; conic_opacity[4 * i + 3] = s.o; }
+    if (conic_opacity) {   // back from the exponent form
+      conic_opacity[4 * i] = s.A * (-1.0f / kConicScale); conic_opacity[4 * i + 1] = s.B * (-0.5f / kConicScale);
+      conic_opacity[4 * i + 2] = s.C * (-1.0f / kConicScale); conic_opacity[4 * i + 3] = s.o;
+    }
     if (rgb) { rgb[3 * i] = s.r; rgb[3 * i + 1] = s.g; rgb[3 * i + 2] = s.b; }
     if (rect) { rect[4 * i] = vis ? hbin[i].x0 : 0; rect[4 * i + 1] = vis ? hbin[i].y0 : 0; rect[4 * i + 2] = vis ? hbin[i].x1 : 0; rect[4 * i + 3] = vis ? hbin[i].y1 : 0; }
   }

@@ -148,9 +148,10 @@ __device__ __forceinline__ void emit_splat(const PgArgs &a, int i, const SplatGe
   int radius_out = 0;
   if (g.vis) {
     float4 *dst = reinterpret_cast<float4 *>(rec + i);
-    dst[0] = make_float4(g.sx, g.sy, g.cA, g.cB);
-    dst[1] = make_float4(g.cC, g.op, rgb[0], rgb[1]);
-    dst[2] = make_float4(rgb[2], g.tz, g.kcut, 0.0f);
+    // the conic in the blend kernels' exponent form (SplatRec, common.hpp)
+    dst[0] = make_float4(g.sx, g.sy, -kConicScale * g.cA, -2.0f * kConicScale * g.cB);
+    dst[1] = make_float4(-kConicScale * g.cC, __builtin_amdgcn_logf(g.op), rgb[0], rgb[1]);
+    dst[2] = make_float4(rgb[2], g.tz, kConicScale * g.kcut, g.op);
     br.x0 = (uint16_t)g.x0; br.y0 = (uint16_t)g.y0; br.x1 = (uint16_t)g.x1; br.y1 = (uint16_t)g.y1;
     br.depth_bits = __float_as_uint(g.tz);
     br.radius = g.radius | (clamp_bits << kClampShift);
