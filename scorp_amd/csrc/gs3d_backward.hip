@@ -78,8 +78,11 @@ __device__ __forceinline__ float half_hi(uint32_t p) { return (float)__builtin_b
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kChunk = 64;
 
+#ifndef SCORP_BWD_WAVES
+#define SCORP_BWD_WAVES 4
+#endif
 template <bool kHasDA, bool kExact>  // kHasDA false: no upstream gradient on the depth / alpha images (the photometric-loss-only step)
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, SCORP_BWD_WAVES)
 blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ hits,
                            const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                            const float *__restrict__ bg, const float *__restrict__ final_T,
@@ -90,11 +93,12 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   // opacity * G = exp2(A dx^2 + C dy^2 + B dx dy + log2 opacity)
   __shared__ float4 q_a[kChunk], q_b[kChunk], q_c[kChunk];
   __shared__ __attribute__((aligned(16))) uint32_t q_id[kChunk];
-  // [slot][pixel] matrices.  split form: x1 = first fp16 terms (v | w << 16), x2 = second terms; exact form: x1 = v, x2 = w (fp32)
-  __shared__ __attribute__((aligned(16))) uint32_t x1[kGroup * kXStride], x2[kGroup * kXStride];
-  float *dbuf = reinterpret_cast<float *>(x1);   // the 16 x 14 result tile reuses x1 once the MFMAs have consumed it
-  float *xs = reinterpret_cast<float *>(x1);     // prologue scratch: 64 x 4 floats
-  static_assert(kGroup * kDStride <= kGroup * kXStride && 64 * 4 <= kGroup * kXStride, "scratch fits");
+  // [row][pixel] matrix of one half-group (8 splats).  split form: rows 0..7 = first fp16 terms (v | w << 16) of the 8
+  // splats, rows 8..15 = second terms; exact form: rows 0..7 = v, rows 8..15 = w (fp32)
+  __shared__ __attribute__((aligned(16))) uint32_t xm[16 * kXStride];
+  float *dbuf = reinterpret_cast<float *>(xm);   // the 2 x 16 x 14 result tile reuses the matrix once the MFMAs have consumed it
+  float *xs = reinterpret_cast<float *>(xm);     // prologue scratch: 64 x 4 floats
+  static_assert(2 * kGroup * kDStride <= 16 * kXStride && 64 * 4 <= 16 * kXStride, "scratch fits");
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
@@ -189,28 +193,31 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   }
   float T = kExact ? T_final : kWScale * T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
   const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
-  float park_v[3] = {0.0f, 0.0f, 0.0f};      // a group's sums, parked until flush_sums
-  uint32_t park_o[3] = {0u, 0u, 0u};           // ... and their float offsets in acc (N * 12 < 2^32, checked at the entry point)
+  float park_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // a group's sums, parked until flush_sums
+  uint32_t park_o[4] = {0u, 0u, 0u, 0u};        // ... and their float offsets in acc (N * 16 < 2^32, checked at the entry point)
   auto flush_sums = [&]() {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
       if (park_v[k] != 0.0f) atomicAdd(acc + park_o[k], park_v[k]);
       park_v[k] = 0.0f;
     }
   };
   // slots of a group: head + i, head a multiple of kGroup: one LDS base per array, immediate offsets.  `top` = 1-based
-  // position in the hit list of the group's first slot (positions fall by one per slot)
+  // position in the hit list of the group's first slot (positions fall by one per slot).
+  // A group is two halves of 8 splats.  Each half: 1a, 1b, then ONE pass over the matrix pipe whose 16 rows are
+  // (8 slots) x (first term | second term) [exact form: (8 slots) x (v | w)], so the [row][pixel] matrix in LDS is
+  // 16 x 64 dwords whatever the form; the two halves' results wait in registers and leave together.
   auto process_group = [&](auto full, int nslots, int head, int top) {
     flush_sums();   // (a later group of the same chunk: the previous one's sums leave now)
     constexpr bool kFull = decltype(full)::value;   // full groups run straight-line; only a wave's last one is partial
-    {
-      int hv = head;
-      asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
-      const float4 *ga = q_a + hv, *gb = q_b + hv, *gc = q_c + hv;
-      const int first = top - (int)last;   // slot i takes part in this pixel's blend iff top - i <= last, i.e. i >= first
-      // 1a + 1b in two halves of 8 splats: the straight-line part keeps only 8 G*opacity values live
+    int hv = head;
+    asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
+    const float4 *ga = q_a + hv, *gb = q_b + hv, *gc = q_c + hv;
+    const int first = top - (int)last;   // slot i takes part in this pixel's blend iff top - i <= last, i.e. i >= first
+    f32x4 dd[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < 2; h++) {
+      if (kFull || h * 8 < nslots) {   // wave-uniform
         float Go[8];
 #pragma unroll
         for (int i8 = 0; i8 < 8; i8++) {
@@ -226,7 +233,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
 #pragma unroll
         for (int i8 = 0; i8 < 8; i8++) {
           const int i = h * 8 + i8;
-          if (kFull || i < nslots) {  // wave-uniform: stale ring entries beyond the group must not enter the recurrence
+          if (kFull || i < nslots) {  // wave-uniform: stale staging entries beyond the group must not enter the recurrence
             const float2 rg = *reinterpret_cast<const float2 *>(&gb[i].z);
             const float2 bz = *reinterpret_cast<const float2 *>(&gc[i]);
             const float alpha = fminf(kAlphaMax, Go[i8]);
@@ -241,103 +248,107 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
             last_alpha = alpha;
             const float v = Go[i8] * dL_dal;
             if constexpr (kExact) {
-              x1[i * kXStride + lane] = __float_as_uint(v);
-              x2[i * kXStride + lane] = __float_as_uint(w);
+              xm[i8 * kXStride + lane] = __float_as_uint(v);
+              xm[(8 + i8) * kXStride + lane] = __float_as_uint(w);
             } else {   // x = h1 + h2, two fp16 terms (round toward zero, saturating); v and w share the dwords
               const uint32_t p1 = pack_rtz16(v, w);
               const uint32_t p2 = pack_rtz16(__builtin_fmaf(half_lo(p1), -1.0f, v), __builtin_fmaf(half_hi(p1), -1.0f, w));
-              x1[i * kXStride + lane] = p1;
-              x2[i * kXStride + lane] = p2;
+              xm[i8 * kXStride + lane] = p1;
+              xm[(8 + i8) * kXStride + lane] = p2;
             }
           }
         }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
-      // A operands: the lane's 16 pixels per matrix are consecutive in its row, fetched as eight 16-byte reads issued together
-      if constexpr (kExact) {
-        f32x4 dv = {0.0f, 0.0f, 0.0f, 0.0f}, dw = {0.0f, 0.0f, 0.0f, 0.0f};
-        float4 av[4], aw[4];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // A operands: the lane's 16 pixels are consecutive in its row, fetched as four 16-byte reads issued together
+        f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (kExact) {
+          float4 av[4];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; t4++) {
-          av[t4] = *reinterpret_cast<const float4 *>(&x1[abase + 4 * t4]);
-          aw[t4] = *reinterpret_cast<const float4 *>(&x2[abase + 4 * t4]);
+          for (int t4 = 0; t4 < 4; t4++) av[t4] = *reinterpret_cast<const float4 *>(&xm[abase + 4 * t4]);
+#pragma unroll
+          for (int t4 = 0; t4 < 4; t4++) {
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bb[4 * t4], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].y, bb[4 * t4 + 1], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].z, bb[4 * t4 + 2], d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].w, bb[4 * t4 + 3], d, 0, 0, 0);
+          }
+        } else {
+          Frag af[4];
+#pragma unroll
+          for (int m = 0; m < 4; m++) af[m].q = *reinterpret_cast<const uint4 *>(&xm[abase + 4 * m]);
+#pragma unroll
+          for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m].v, bh[m].v, d, 0, 0, 0);
         }
-#pragma unroll
-        for (int t4 = 0; t4 < 4; t4++) {   // two independent chains interleave on the matrix pipe
-          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bb[4 * t4], dv, 0, 0, 0);
-          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].x, bb[4 * t4], dw, 0, 0, 0);
-          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].y, bb[4 * t4 + 1], dv, 0, 0, 0);
-          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].y, bb[4 * t4 + 1], dw, 0, 0, 0);
-          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].z, bb[4 * t4 + 2], dv, 0, 0, 0);
-          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].z, bb[4 * t4 + 2], dw, 0, 0, 0);
-          dv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].w, bb[4 * t4 + 3], dv, 0, 0, 0);
-          dw = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[t4].w, bb[4 * t4 + 3], dw, 0, 0, 0);
-        }
-        d = bn < 6 ? dv : dw;
-      } else {
-        Frag a1[4], a2[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-          a1[m].q = *reinterpret_cast<const uint4 *>(&x1[abase + 4 * m]);
-          a2[m].q = *reinterpret_cast<const uint4 *>(&x2[abase + 4 * m]);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[m].v, bh[m].v, d, 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[m].v, bh[m].v, d, 0, 0, 0);
+        dd[h] = d;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the next half (and the result tile) overwrite the matrix
       }
-      if (bn < 14) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) dbuf[(4 * bk + r) * kDStride + bn] = d[r];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (lane < nslots) {  // block-frame moments -> the ten screen-space gradients of slot `lane`
-        float *m = dbuf + lane * kDStride;
-        const float4 a = ga[lane];
-        const float4 b = gb[lane];
-        const float opac = gc[lane].w;
-        const float cA = a.z * (-1.0f / kConicScale), cB = a.w * (-0.5f / kConicScale), cC = b.x * (-1.0f / kConicScale);
-        const float xl = a.x - cx, yl = a.y - cy;
-        const float m0 = m[0] * inv_sv, mx = m[1] * inv_sv, my = m[2] * inv_sv, mxx = m[3] * inv_sv, mxy = m[4] * inv_sv,
-                    myy = m[5] * inv_sv;
-        const float svdx = xl * m0 - mx, svdy = yl * m0 - my;
-        const float svdx2 = xl * xl * m0 - 2.0f * xl * mx + mxx;
-        const float svdxdy = xl * yl * m0 - xl * my - yl * mx + mxy;
-        const float svdy2 = yl * yl * m0 - 2.0f * yl * my + myy;
-        if constexpr (!kExact) {   // W sums: first-term + remainder columns, unscaled
-          const float inv_w = inv_sv * (1.0f / kWScale);
-#pragma unroll
-          for (int c = 0; c < 4; c++) m[6 + c] = (m[6 + c] + m[10 + c]) * inv_w;
-        }
-        m[0] = 0.5f * W * (-cA * svdx - cB * svdy);
-        m[1] = 0.5f * H * (-cC * svdy - cB * svdx);
-        m[2] = -0.5f * svdx2;
-        m[3] = -svdxdy;
-        m[4] = -0.5f * svdy2;
-        m[5] = m0 / opac;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // The 160 sums go out as three wave-wide atomic instructions - but not yet: they are parked in registers and
-      // issued after the next chunk's gathers have been picked up (flush_sums).  vmcnt counts loads and atomics alike
-      // and the compiler waits with vmcnt(0) for the gathers, so atomics issued right here would be waited for, at
-      // their full memory-side latency, at the top of the next chunk.
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const int f = lane + 64 * k;
-        const int sl = f / 10, col = f - sl * 10;
-        park_v[k] = 0.0f;
-        if (sl < nslots) {
-          park_v[k] = dbuf[sl * kDStride + col];
-          park_o[k] = q_id[head + sl] * (uint32_t)kAccStride + col;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
+    // result tile [term][slot][column] (it reuses the matrix): lane (bn, bk) holds rows 4 bk .. 4 bk + 3 of column bn
+    if (bn < 14) {
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          dbuf[((bk >> 1) * kGroup + h * 8 + ((4 * bk + r) & 7)) * kDStride + bn] = dd[h][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nslots) {  // block-frame moments -> the ten screen-space gradients of slot `lane`
+      float *m = dbuf + lane * kDStride;
+      const float *m2 = m + kGroup * kDStride;
+      const float4 a = ga[lane];
+      const float4 b = gb[lane];
+      const float opac = gc[lane].w;
+      const float cA = a.z * (-1.0f / kConicScale), cB = a.w * (-0.5f / kConicScale), cC = b.x * (-1.0f / kConicScale);
+      const float xl = a.x - cx, yl = a.y - cy;
+      float mm[10];
+      {
+        const float4 u0 = *reinterpret_cast<const float4 *>(m), u1 = *reinterpret_cast<const float4 *>(m + 4),
+                     u2 = *reinterpret_cast<const float4 *>(m + 8), u3 = *reinterpret_cast<const float4 *>(m + 12);
+        const float4 w0 = *reinterpret_cast<const float4 *>(m2), w1 = *reinterpret_cast<const float4 *>(m2 + 4),
+                     w2 = *reinterpret_cast<const float4 *>(m2 + 8), w3 = *reinterpret_cast<const float4 *>(m2 + 12);
+        if constexpr (kExact) {      // rows 0..7 carried v (columns 0..5), rows 8..15 w (columns 6..9)
+          mm[0] = u0.x; mm[1] = u0.y; mm[2] = u0.z; mm[3] = u0.w; mm[4] = u1.x; mm[5] = u1.y;
+          mm[6] = w1.z; mm[7] = w1.w; mm[8] = w2.x; mm[9] = w2.y;
+        } else {                     // first + second term; W sums = (first-term + remainder columns) of the upstream gradients
+          const float inv_w = inv_sv * (1.0f / kWScale);
+          mm[0] = (u0.x + w0.x) * inv_sv; mm[1] = (u0.y + w0.y) * inv_sv; mm[2] = (u0.z + w0.z) * inv_sv;
+          mm[3] = (u0.w + w0.w) * inv_sv; mm[4] = (u1.x + w1.x) * inv_sv; mm[5] = (u1.y + w1.y) * inv_sv;
+          mm[6] = ((u1.z + w1.z) + (u2.z + w2.z)) * inv_w; mm[7] = ((u1.w + w1.w) + (u2.w + w2.w)) * inv_w;
+          mm[8] = ((u2.x + w2.x) + (u3.x + w3.x)) * inv_w; mm[9] = ((u2.y + w2.y) + (u3.y + w3.y)) * inv_w;
+        }
+      }
+      const float m0 = mm[0], mx = mm[1], my = mm[2], mxx = mm[3], mxy = mm[4], myy = mm[5];
+      const float svdx = xl * m0 - mx, svdy = yl * m0 - my;
+      const float svdx2 = xl * xl * m0 - 2.0f * xl * mx + mxx;
+      const float svdxdy = xl * yl * m0 - xl * my - yl * mx + mxy;
+      const float svdy2 = yl * yl * m0 - 2.0f * yl * my + myy;
+      *reinterpret_cast<float4 *>(m) = make_float4(0.5f * W * (-cA * svdx - cB * svdy), 0.5f * H * (-cC * svdy - cB * svdx),
+                                                   -0.5f * svdx2, -svdxdy);
+      *reinterpret_cast<float4 *>(m + 4) = make_float4(-0.5f * svdy2, m0 / opac, mm[6], mm[7]);
+      *reinterpret_cast<float2 *>(m + 8) = make_float2(mm[8], mm[9]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // The 160 sums go out as four wave-wide atomic instructions (lane = float of a 64-byte accumulator row, four rows
+    // per instruction, ten lanes of sixteen active: one memory-side request per splat) - but not yet: they are parked in registers and
+    // issued after the next chunk's gathers have been picked up (flush_sums).  vmcnt counts loads and atomics alike
+    // and the compiler waits with vmcnt(0) for the gathers, so atomics issued right here would be waited for, at
+    // their full memory-side latency, at the top of the next chunk.
+    static_assert(kAccStride == kDStride && kDStride == 16, "a result row maps onto an accumulator row lane for lane");
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int sl = 4 * k + (lane >> 4), col = lane & 15;
+      park_v[k] = 0.0f;
+      if (sl < nslots && col < 10) {
+        park_v[k] = dbuf[sl * kDStride + col];
+        park_o[k] = q_id[head + sl] * (uint32_t)kAccStride + col;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   };
 
   // The chunk's gathers are a chain of dependent loads (hit-list entry -> record) of ~1 us each way; with three waves

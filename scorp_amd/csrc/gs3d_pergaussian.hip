@@ -272,7 +272,7 @@ __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float 
   if constexpr (LIN) {
     RawParams r, ra;
     raw_issue_params(r, a.means3D + 3 * (size_t)i, a.rotations + 4 * (size_t)i, a.scales + 3 * (size_t)i, a.opacities + i);
-    static_assert(kAccStride == 12, "accumulator row: 12 floats, 10 used here");
+    static_assert(kAccStride >= 10, "accumulator row: 10 floats used here");
     const float *ap = acc + (size_t)i * kAccStride;
     raw_issue_params(ra, ap, ap + 3, ap + 7, reinterpret_cast<const float *>(&bin[i].radius));
     stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
@@ -302,9 +302,9 @@ __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float 
   for (int q = 0; q < 16; q++) { vm[q] = ((const CFloat *)a.view)[q]; pm[q] = ((const CFloat *)a.proj)[q]; }   // scalar cache
   float gm[3] = {0, 0, 0}, gs[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gc6[6] = {0, 0, 0, 0, 0, 0};
   float shx = 0, shy = 0, shz = 0, shinv = 0, gr3[3] = {0, 0, 0};
-  float a_[kAccStride];
+  float a_[10];
 #pragma unroll
-  for (int q = 0; q < kAccStride; q++) a_[q] = 0.0f;
+  for (int q = 0; q < 10; q++) a_[q] = 0.0f;
   float g_op = 0.0f;
   const ShRow row = sh_row(s_sh, threadIdx.x, lin);
   if (visible) {
