@@ -218,35 +218,49 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       if (kFull || h * 8 < nslots) {   // wave-uniform
-        float Go[8];
+        // One straight-line pass per splat (alpha, then the recurrence): with four waves per SIMD an in-order wave's own
+        // issue interval already covers the ALU latencies, so nothing is gained by separating a parallel alpha phase
+        // from the sequential part - and keeping eight (alpha, record) sets live costs the registers that let the
+        // staged records of the NEXT splats be fetched from LDS ahead of their use.
+        // The staged records are fetched kAhead splats ahead of their use (explicit rotation: left alone the scheduler
+        // issues each ds_read right in front of its use and the wave eats the LDS latency once per splat).
+#ifndef SCORP_BWD_AHEAD
+#define SCORP_BWD_AHEAD 3
+#endif
+        constexpr int kAhead = SCORP_BWD_AHEAD;
+        float4 ra[kAhead], rb[kAhead];
+        float2 rc[kAhead];
 #pragma unroll
-        for (int i8 = 0; i8 < 8; i8++) {
-          const int i = h * 8 + i8;
-          const float4 a = ga[i];
-          const float2 co = *reinterpret_cast<const float2 *>(&gb[i]);
-          const float e = splat_exponent(a.x - pxf, a.y - pyf, a.z, a.w, co.x, co.y);   // log2(opacity * G)
-          const float g_o = __builtin_amdgcn_exp2f(e);
-          // alpha = min(0.99, g_o) >= 1/255  <=>  g_o >= 1/255
-          const bool ok = (kFull || i < nslots) & (i >= first) & (e <= co.y) & (g_o >= kAlphaMin);
-          Go[i8] = ok ? g_o : 0.0f;
+        for (int j = 0; j < kAhead - 1; j++) {
+          ra[j] = ga[h * 8 + j]; rb[j] = gb[h * 8 + j]; rc[j] = *reinterpret_cast<const float2 *>(&gc[h * 8 + j]);
         }
 #pragma unroll
         for (int i8 = 0; i8 < 8; i8++) {
           const int i = h * 8 + i8;
+          if (i8 + kAhead - 1 < 8) {
+            const int j = (i8 + kAhead - 1) % kAhead, ij = i + kAhead - 1;
+            ra[j] = ga[ij]; rb[j] = gb[ij]; rc[j] = *reinterpret_cast<const float2 *>(&gc[ij]);
+          }
           if (kFull || i < nslots) {  // wave-uniform: stale staging entries beyond the group must not enter the recurrence
-            const float2 rg = *reinterpret_cast<const float2 *>(&gb[i].z);
-            const float2 bz = *reinterpret_cast<const float2 *>(&gc[i]);
-            const float alpha = fminf(kAlphaMax, Go[i8]);
+            const float4 a = ra[i8 % kAhead];
+            const float4 b = rb[i8 % kAhead];
+            const float2 bz = rc[i8 % kAhead];
+            const float e = splat_exponent(a.x - pxf, a.y - pyf, a.z, a.w, b.x, b.y);   // log2(opacity * G)
+            const float g_o = __builtin_amdgcn_exp2f(e);
+            // alpha = min(0.99, g_o) >= 1/255  <=>  g_o >= 1/255
+            const bool ok = (i >= first) & (e <= b.y) & (g_o >= kAlphaMin);
+            const float Go = ok ? g_o : 0.0f;
+            const float alpha = fminf(kAlphaMax, Go);
             const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
             T *= rinv;
             const float w = alpha * T;
             R = last_alpha * (s_last - R) + R;
-            const float sc = kHasDA ? rg.x * dpix0 + rg.y * dpix1 + bz.x * dpix2 + bz.y * ddep + dalp
-                                    : rg.x * dpix0 + rg.y * dpix1 + bz.x * dpix2;
+            const float sc = kHasDA ? b.z * dpix0 + b.w * dpix1 + bz.x * dpix2 + bz.y * ddep + dalp
+                                    : b.z * dpix0 + b.w * dpix1 + bz.x * dpix2;
             const float dL_dal = (sc - R) * T - tf_bg * rinv;
             s_last = sc;
             last_alpha = alpha;
-            const float v = Go[i8] * dL_dal;
+            const float v = Go * dL_dal;
             if constexpr (kExact) {
               xm[i8 * kXStride + lane] = __float_as_uint(v);
               xm[(8 + i8) * kXStride + lane] = __float_as_uint(w);
