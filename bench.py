@@ -212,6 +212,8 @@ def main():
     fused_view = not surfels and not args.autograd and not args.unfused
     if fused_view:
         from scorp_amd.train_view import train_view
+    if args.streams > 1 and not fused_view:
+        raise SystemExit("--streams > 1 runs the one-call 3DGS view (scorp_gs3d_train_view): not with --scene S6, --autograd or --unfused")
 
     # --streams S > 1: S views in flight on S HIP streams (views are independent given the parameters: the batch-of-views
     # form of training, or multi-view evaluation); the default, 1, is the reference's one-view-at-a-time loop

@@ -294,6 +294,12 @@ typedef struct ScorpAdamTensor {
 } ScorpAdamTensor;
 int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t num_tensors, double beta1, double beta2, double eps,
                     int32_t step, scorp_stream_t stream);
+/* The same step made conditional ON THE DEVICE: nothing is updated if *skip_if_nonzero != 0 when the kernel runs (NULL =
+ * unconditional).  For training loops that reserve the pair buffer instead of synchronising for the pair count: the word
+ * is the view's overflow flag (second 32-bit word of the forward state), so a view rendered from truncated tile lists
+ * cannot move the parameters or the Adam moments - without a host round trip per iteration. */
+int scorp_adam_step_guarded(const ScorpAdamTensor *tensors, int32_t num_tensors, double beta1, double beta2, double eps,
+                            int32_t step, const uint32_t *skip_if_nonzero, scorp_stream_t stream);
 
 /* ---- in-library kernel timing: hipEvent pairs recorded on the launch stream around every kernel ---- */
 /* Off by default. scorp_prof_enable(1) clears the accumulators and starts recording; collect() synchronises the

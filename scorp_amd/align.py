@@ -87,7 +87,7 @@ def _sweep_graph(model, rotations, ids, cameras, targets, bg, dev):
             fit = hypothesis_fitness(model, Rbuf, cameras, targets, bg)
             states, PairPolicy._pending = PairPolicy._pending, []
             # StateHeader: num_pairs u32 @0, overflow u32 @4
-            flags = torch.stack([st[:8].view(torch.int32) for st in states]).amax(0)
+            flags = torch.stack([p.header[:8].view(torch.int32) for p in states]).amax(0)
         worst_flags = torch.zeros(2, dtype=torch.int32, device=dev)
         out = []
         for i in ids:

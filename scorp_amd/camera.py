@@ -57,6 +57,7 @@ class Camera:
         self.uid = uid
         self.R, self.T = np.asarray(R, np.float64), np.asarray(T, np.float64)
         self.FoVx, self.FoVy = float(FoVx), float(FoVy)
+        self.FoVx_old, self.FoVy_old = self.FoVx, self.FoVy     # cameras.py:70-71: what restore_fov() goes back to
         self.image_name = image_name
         self.resolution = (int(resolution[0]), int(resolution[1]))
         self.resolution_original = self.resolution
@@ -82,9 +83,23 @@ class Camera:
         self.resolution = (int(self.resolution[0] * scale), int(self.resolution[1] * scale))
         self.image_width, self.image_height = self.resolution
 
-    def reset_resolution(self):
+    def restore_resolution(self):
+        """cameras.py:147-148."""
         self.resolution = self.resolution_original
         self.image_width, self.image_height = self.resolution
+
+    def scale_fov(self, scale_x, scale_y):
+        """cameras.py:150-151: both fields of view scaled, projection matrices rebuilt."""
+        self._update_fov(self.FoVx * scale_x, self.FoVy * scale_y)
+
+    def restore_fov(self):
+        """cameras.py:169-170."""
+        self._update_fov(self.FoVx_old, self.FoVy_old)
+
+    def _update_fov(self, fovx, fovy):
+        """cameras.py:153-167 (the reference rebuilds projection_matrix and full_proj_transform; so does _update)."""
+        self.FoVx, self.FoVy = float(fovx), float(fovy)
+        self._update()
 
 
 def look_at_camera(position, target, up, FoVx, resolution, device="cpu", uid=0):

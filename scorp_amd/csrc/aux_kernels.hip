@@ -72,7 +72,9 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
 }
 
 __global__ void __launch_bounds__(256)
-adam_kernel(AdamPack pk, float omb1, float beta2, float omb2, float eps, float bc1, float inv_sqrt_bc2) {
+adam_kernel(AdamPack pk, float omb1, float beta2, float omb2, float eps, float bc1, float inv_sqrt_bc2,
+            const uint32_t *__restrict__ skip_if_nonzero) {
+  if (skip_if_nonzero && *skip_if_nonzero != 0u) return;   // the step is conditional on a device word (see the entry point)
   int ti = 0;
 #pragma unroll
   for (int k = 1; k < SCORP_ADAM_MAX_TENSORS; k++)
@@ -125,6 +127,11 @@ extern "C" int scorp_knn_dist2(const float *xyz, int32_t N, float *out, scorp_st
 
 extern "C" int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t n, double beta1, double beta2, double eps,
                                int32_t step, scorp_stream_t stream_) {
+  return scorp_adam_step_guarded(tensors, n, beta1, beta2, eps, step, nullptr, stream_);
+}
+
+extern "C" int scorp_adam_step_guarded(const ScorpAdamTensor *tensors, int32_t n, double beta1, double beta2, double eps,
+                                       int32_t step, const uint32_t *skip_if_nonzero, scorp_stream_t stream_) {
   if (n < 0 || n > SCORP_ADAM_MAX_TENSORS || (n > 0 && !tensors) || step < 1) {
     set_error("bad arguments to scorp_adam_step (n=%d, step=%d)", n, step); return SCORP_ERR_INVALID;
   }
@@ -148,7 +155,7 @@ extern "C" int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t n, double
   {
     ProfScope prof(kKAdam, stream);
     adam_kernel<<<blocks, 256, 0, stream>>>(pk, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                                            (float)bc1, (float)(1.0 / sqrt(bc2)));
+                                            (float)bc1, (float)(1.0 / sqrt(bc2)), skip_if_nonzero);
   }
   SCORP_KERNEL_CHECK("adam", 0, stream);
   return SCORP_OK;

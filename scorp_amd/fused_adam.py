@@ -12,6 +12,10 @@ from . import _C
 class FusedAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
+        # Optional 1-element int32 device tensor: the NEXT step() updates nothing if it is non-zero when the kernel runs
+        # (scorp_adam_step_guarded).  train() sets it to the overflow word of a view rendered with a reserved pair buffer;
+        # step() consumes it.  (The host-side step counter still advances: one bias-correction step, immaterial.)
+        self.skip_flag = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -36,6 +40,8 @@ class FusedAdam(torch.optim.Adam):
                 key = (group["betas"], group["eps"], int(st["step"]))
                 by_cfg.setdefault(key, []).append((p, p.grad.contiguous(), st, float(group["lr"])))
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        skip, self.skip_flag = self.skip_flag, None
+        skip_ptr = None if skip is None else ctypes.c_void_p(skip.data_ptr())
         for (betas, eps, step), items in by_cfg.items():
             for i in range(0, len(items), 8):
                 chunk = items[i:i + 8]
@@ -45,5 +51,6 @@ class FusedAdam(torch.optim.Adam):
                     arr[k].param, arr[k].grad = p.data_ptr(), g.data_ptr()
                     arr[k].exp_avg, arr[k].exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                     arr[k].numel, arr[k].lr = p.numel(), lr
-                _C.check(L.scorp_adam_step(arr, len(chunk), betas[0], betas[1], eps, step, stream), "scorp_adam_step")
+                _C.check(L.scorp_adam_step_guarded(arr, len(chunk), betas[0], betas[1], eps, step, skip_ptr, stream),
+                         "scorp_adam_step_guarded")
         return loss

@@ -34,14 +34,12 @@ def _forward2d(ctx, settings, means3D, sh, sh_rest, colors_precomp, opacities, s
         LAST_NUM_PAIRS_LOG.append(int(n.value))
         del LAST_NUM_PAIRS_LOG[:-64]
     else:
-        if PairPolicy.reserve <= 0:
-            PairPolicy.reserve = max(4 * N, 1 << 20)
-        capacity = PairPolicy.reserve
+        capacity = PairPolicy.capacity(N, H, W)
     pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
     fn = L.scorp_gs2d_render if any(ctx.needs_input_grad) else L.scorp_gs2d_render_image   # nothing to differentiate
     _C.check(fn(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(allmap), stream), "scorp_gs2d_render")
     if PairPolicy.mode != "exact":
-        PairPolicy._pending.append(state[:64].clone())   # the StateHeader only (see rasterizer3d._forward_common)
+        PairPolicy.pend(state, N, H, W)   # the StateHeader only (see rasterizer3d.PairPolicy.pend)
     ctx.settings, ctx.capacity = settings, capacity
     return color, radii, allmap, state, pairs, keep
 

@@ -33,37 +33,86 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+class _Pending:
+    """One forward issued without a host synchronisation: a copy of its 64-byte StateHeader (pair count, overflow flag),
+    the event recorded behind that copy on the stream that produced it, and the reservation context it belongs to."""
+    __slots__ = ("header", "event", "key")
+
+    def __init__(self, header, event, key):
+        self.header, self.event, self.key = header, event, key
+
+    def numel(self):
+        return self.header.numel()
+
+
 class PairPolicy:
     """How the (tile,splat) pair buffer is sized.
 
     "exact"   (default) one 8-byte D2H read per forward tells the exact pair count — what the CUDA original
               does too; always correct.
-    "reserve" no host sync: the buffer is sized from the largest count seen so far times `slack`; each forward
-              is queued for `drain()`, which synchronises once, raises if any view overflowed and grows the
-              reservation.  For throughput loops that check once per N views.
+    "reserve" no host sync: the buffer is sized from the largest count seen so far IN THE SAME CONTEXT times `slack`;
+              each forward is queued for `drain()`, which waits for the forward's own stream, raises if any view
+              overflowed and grows that context's reservation.  For throughput loops that check once per N views.
+
+    A context is (number of Gaussians, image height, image width, stream): the align loop changes resolution per
+    render, densification changes N, `bench.py --streams` runs views on several streams — each gets its own
+    reservation instead of one process-wide number.  `reserve` is only a caller-set FLOOR for every context (0 = none);
+    `mode` / `slack` are configuration.  A context nobody has sized yet starts at max(4 N, 2^20) pairs.
     """
     mode = "exact"
     slack = 1.25
-    reserve = 0          # pairs
-    _pending = []        # copies of the 64-byte state headers whose overflow flag has not been read yet
+    reserve = 0          # pairs: floor applied to every context (callers that know their workload set it)
+    _ctx = {}            # context key -> reserved pairs learned by drain()
+    _pending = []        # _Pending entries whose overflow flag has not been read yet
+
+    @classmethod
+    def key(cls, N, H, W):
+        return (int(N), int(H), int(W), int(torch.cuda.current_stream().cuda_stream))
+
+    @classmethod
+    def capacity(cls, N, H, W):
+        """Pairs to reserve for a forward of this context."""
+        k = cls.key(N, H, W)
+        got = cls._ctx.get(k, 0)
+        if got <= 0 and cls.reserve <= 0:
+            got = max(4 * int(N), 1 << 20)
+        return max(got, int(cls.reserve))
+
+    @classmethod
+    def pend(cls, state, N, H, W):
+        """Queue a forward for drain(): copies the header on the current stream and records an event behind the copy."""
+        hdr = state[:64].clone()     # not the state itself, or every pending view would pin ~100 MB until the drain
+        ev = None
+        if not torch.cuda.is_current_stream_capturing():   # (a captured replay is checked by its capturer: align._sweep_graph)
+            ev = torch.cuda.Event()
+            ev.record()
+        cls._pending.append(_Pending(hdr, ev, cls.key(N, H, W)))
+        return hdr
 
     @classmethod
     def drain(cls):
-        """Synchronise and verify every forward issued in "reserve" mode since the last drain."""
+        """Verify every forward issued in "reserve" mode since the last drain (each on its own stream's event)."""
         L = _C.lib()
         pend, cls._pending = cls._pending, []
         worst = 0
         err = None
-        for state in pend:
+        for p in pend:
+            if p.event is not None:
+                p.event.synchronize()     # the header copy was made on the stream that rendered the view
             n = ctypes.c_uint64(0)
-            code = L.scorp_gs3d_check_overflow(state.data_ptr(), _stream(), ctypes.byref(n))
+            code = L.scorp_gs3d_check_overflow(p.header.data_ptr(), _stream(), ctypes.byref(n))
             worst = max(worst, n.value)
+            if p.key is not None:
+                cls._ctx[p.key] = max(cls._ctx.get(p.key, 0), int(n.value * cls.slack) + 1024)
             if code != 0 and err is None:
                 err = L.scorp_last_error().decode()
-        cls.reserve = max(cls.reserve, int(worst * cls.slack) + 1024)
         if err:
-            raise RuntimeError(f"pair reservation too small ({err}); reservation grown to {cls.reserve}, re-run the view(s)")
+            raise RuntimeError(f"pair reservation too small ({err}); the context's reservation has been grown, re-run the view(s)")
         return worst
+
+    @classmethod
+    def reset(cls):
+        cls.mode, cls.reserve, cls._ctx, cls._pending = "exact", 0, {}, []
 
 
 _tls = threading.local()
@@ -213,9 +262,7 @@ def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opaciti
         LAST_NUM_PAIRS_LOG.append(int(n.value))
         del LAST_NUM_PAIRS_LOG[:-64]
     else:
-        if PairPolicy.reserve <= 0:
-            PairPolicy.reserve = max(4 * N, 1 << 20)
-        capacity = PairPolicy.reserve
+        capacity = PairPolicy.capacity(N, H, W)
     pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
     # nothing to differentiate (the calls the reference makes under torch.no_grad()): the image-only render, which
     # leaves no state for a backward pass
@@ -223,9 +270,7 @@ def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opaciti
     _C.check(fn(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(depth), _ptr(alpha), stream),
              "scorp_gs3d_render")
     if PairPolicy.mode != "exact":
-        # what drain() will look at: a copy of the 64-byte StateHeader the render just filled in (pair count, overflow
-        # flag) - not the state itself, or every pending view would pin ~100 MB of device memory until the drain
-        PairPolicy._pending.append(state[:64].clone())
+        PairPolicy.pend(state, N, H, W)   # what drain() will look at: a copy of the StateHeader the render just filled in
     ctx.settings, ctx.capacity = settings, capacity
     ctx.backward_flags = getattr(_tls, "backward_flags", 0)
     ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward: the kernels skip those terms

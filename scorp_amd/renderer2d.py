@@ -22,7 +22,10 @@ def _camera_rays(view, dev):
     current resolution, so they are built once per (camera, resolution) and cached on the camera object — the
     reference rebuilds them (two 4x4 inversions, a host->device copy, a meshgrid) on every render."""
     W, H = view.resolution
-    key = (W, H, str(dev), view.world_view_transform.data_ptr(), view.full_proj_transform.data_ptr())
+    wv, fp = view.world_view_transform, view.full_proj_transform
+    # identity AND version of the two matrices: an in-place pose update (same storage) bumps `_version`, a replaced
+    # tensor changes the id even if the allocator hands back the old address
+    key = (W, H, str(dev), id(wv), wv._version, id(fp), fp._version)
     cache = getattr(view, "_scorp_rays", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
@@ -35,7 +38,7 @@ def _camera_rays(view, dev):
     rays_d = (points @ intrins.inverse().T @ c2w[:3, :3].T).contiguous()
     rays_o = c2w[:3, 3].contiguous()
     try:
-        view._scorp_rays = (key, rays_d, rays_o)
+        view._scorp_rays = (key, rays_d, rays_o, wv, fp)   # (holding the tensors keeps their ids from being reused)
     except Exception:
         pass
     return rays_d, rays_o

@@ -65,6 +65,12 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
         from .train_view import train_view
         pkg = train_view(cam, gaussians, pipe, bg, gt_image, opt.lambda_dssim)
         loss = pkg["loss"]
+        # The pair buffer was reserved, not sized from this view's count.  If the view overflowed it (device word
+        # pkg["overflow"]), its gradients come from truncated tile lists: the optimizer step is skipped on the device and
+        # the densification statistics below are masked - no host synchronisation, nothing wrong is ever applied.
+        if hasattr(gaussians.optimizer, "skip_flag"):
+            gaussians.optimizer.skip_flag = pkg["overflow"]
+        pkg["visibility_filter"] = pkg["visibility_filter"] & (pkg["overflow"] == 0)
     else:
         pkg = render_fn(cam, gaussians, pipe, bg)
         loss = loss_fn(pkg["render"], gt_image, opt.lambda_dssim)
@@ -95,12 +101,9 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
                 if data_parallel:
                     _sync_densification_stats(gaussians)
                     torch.manual_seed(1_000_003 * iteration)   # densify_and_split samples positions: same draw on every rank
-                n_before = gaussians.get_xyz.shape[0]
                 gaussians.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, scene_extent, size_threshold)
-                n_after = gaussians.get_xyz.shape[0]
-                if fused_view and n_after > n_before and PairPolicy.reserve > 0:
-                    # the one-call view never asks for the pair count: let the reservation grow with the model
-                    PairPolicy.reserve = max(PairPolicy.reserve, int(PairPolicy.reserve * (n_after / n_before) * 1.1) + 1024)
+                # (a different number of Gaussians is a new PairPolicy context: the fused view starts again from the
+                # default reservation of max(4 N, 2^20) pairs and drain() sizes it from what the views needed)
             if iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter):
                 gaussians.reset_opacity()   # train_3dgs.py:187-188
         gaussians.optimizer.step()
@@ -140,14 +143,15 @@ def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, backgr
 
 
 def _drain_reservation():
-    """Fused views reserve their pair buffer instead of asking for the count.  An overflowed view was blended from
-    truncated tile lists (nothing is written out of bounds): drain() has already grown the reservation, training goes
-    on, the user is told."""
+    """Fused views reserve their pair buffer instead of asking for the count.  A view that overflowed its reservation was
+    blended from truncated tile lists (nothing is written out of bounds) and was DISCARDED on the device: its optimizer
+    step was skipped and it did not enter the densification statistics (training_iteration).  drain() has grown the
+    reservation; training goes on, the user is told how that happened."""
     try:
         PairPolicy.drain()
     except RuntimeError as e:
         import warnings
-        warnings.warn(f"train(fused_view=True): {e}; up to 32 iterations used truncated tile lists")
+        warnings.warn(f"train(fused_view=True): {e}; the overflowed views were skipped (no optimizer step, no statistics)")
 
 
 def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, pipe=None, background=None, seed=0):

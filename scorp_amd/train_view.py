@@ -8,8 +8,10 @@ the GPU needs, and any hiccup of the host shows up as idle GPU.  No autograd gra
 `.grad` of the model's six raw leaves (accumulating, like backward()), the screen-space gradient in
 `out["viewspace_points"].grad` (what add_densification_stats reads, gaussian_model.py:603-605).
 
-The pair buffer is always "reserved" (no host synchronisation): sized from `PairPolicy.reserve`, verified by
-`PairPolicy.drain()` — call it before trusting a batch of views, as after `render()` in "reserve" mode.
+The pair buffer is always "reserved" (no host synchronisation): sized by `PairPolicy.capacity()` for this (model size,
+resolution, stream), verified by `PairPolicy.drain()`.  The view's overflow word comes back as a device tensor
+(`out["overflow"]`): `train()` hands it to `FusedAdam` (the step is skipped on the device if it is set) and masks the
+densification statistics with it, so a view that overflowed its reservation changes nothing.
 """
 import ctypes
 import math
@@ -57,9 +59,7 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     loss3, grad_color = new((3,)), new((3, H, W))
     state_bytes = L.scorp_gs3d_state_bytes(N, W, H)
     state = new((state_bytes,), torch.uint8)
-    if PairPolicy.reserve <= 0:
-        PairPolicy.reserve = max(4 * N, 1 << 20)
-    capacity = PairPolicy.reserve
+    capacity = PairPolicy.capacity(N, H, W)
     pairs = new((L.scorp_gs3d_pairs_bytes(capacity),), torch.uint8)
     ws_bytes = L.scorp_loss_workspace_bytes(3, H, W)
     ws = new((ws_bytes,), torch.uint8)
@@ -82,12 +82,15 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     v.grad_color, v.grads = grad_color.data_ptr(), ctypes.addressof(grads)
     v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes
     _C.check(L.scorp_gs3d_train_view(ctypes.byref(v), _stream()), "scorp_gs3d_train_view")
-    PairPolicy._pending.append(state[:64].clone())    # the StateHeader only (see rasterizer3d._forward_common)
+    header = PairPolicy.pend(state, N, H, W)          # the StateHeader only (see rasterizer3d.PairPolicy.pend)
     for p, gp in zip(leaves, g):
         if p.requires_grad:
             _accumulate(p, gp.view_as(p))
     return {"render": color, "viewspace_points": _ViewspaceGrad(g_means2D), "visibility_filter": visible.view(torch.bool),
-            "radii": radii, "render_depth": depth, "render_alpha": alpha, "loss": loss3[0], "l1": loss3[1], "ssim": loss3[2]}
+            "radii": radii, "render_depth": depth, "render_alpha": alpha, "loss": loss3[0], "l1": loss3[1], "ssim": loss3[2],
+            # != 0 if this view needed more pairs than were reserved (its images and gradients then come from truncated
+            # tile lists): a device word, so the caller can make the optimizer step conditional without a host sync
+            "overflow": header.view(torch.int32)[1:2]}
 
 
 class _ViewspaceGrad:

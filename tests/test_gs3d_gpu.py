@@ -350,7 +350,7 @@ def test_reserve_policy_matches_exact(dev):
         for a, b in zip(out_exact, out_res):
             assert torch.equal(a, b)
     finally:
-        PairPolicy.mode, PairPolicy.reserve, PairPolicy._pending = "exact", 0, []
+        PairPolicy.reset()
 
 
 def test_render_dict_mirrors_reference(dev):

@@ -185,11 +185,48 @@ def test_training_with_fused_views_matches_the_autograd_loop(dev):
         opt = OptimizationParams()
         opt.densify_from_iter, opt.densification_interval, opt.opacity_reset_interval = 20, 30, 10_000
         opt.random_background = False
+        opt.opacity_cull = 0.005     # (see test_training_loop_improves_psnr_and_densifies)
         losses = train(student, cams, gts, opt, PipelineParams(), iterations=40, scene_extent=3.0, fused_view=fused)
         out.append((losses, student.get_xyz.shape[0]))
     (la, na), (lb, nb) = out
     assert all(abs(x - y) <= 2e-3 * abs(x) + 1e-6 for x, y in zip(la[:30], lb[:30])), (la[:30], lb[:30])
     assert abs(na - nb) <= 0.02 * na, (na, nb)      # clone / split decisions sit on thresholds: a handful may flip
+
+
+def test_overflowed_fused_view_is_discarded_on_the_device(dev):
+    """A fused view whose reserved pair buffer is too small reports it in a device word; the guarded Adam step then
+    updates nothing and the view's visibility filter is empty (no densification statistics) - no host synchronisation
+    involved.  drain() afterwards grows the reservation and the next view of the same context goes through."""
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams, training_iteration
+    PairPolicy.reset()
+    m = GaussianModel.from_raw(make_gaussians(3000, 1, 4, log_scale_mean=math.log(0.05)), 1, device=dev)
+    m.active_sh_degree = 1
+    opt = OptimizationParams()
+    opt.random_background = False
+    m.training_setup(opt)
+    cam = ring_cameras(3, 128, 96, 2, radius=3.0, device=dev)[1]
+    gt = torch.rand(3, 96, 128, device=dev)
+    bg = torch.zeros(3, device=dev)
+    try:
+        PairPolicy._ctx[PairPolicy.key(3000, 96, 128)] = 64          # far too few pairs for this view
+        before = [p.detach().clone() for p in (m._xyz, m._features_dc, m._opacity, m._scaling, m._rotation)]
+        loss, pkg = training_iteration(m, cam, gt, opt, PipelineParams(), bg, 1, fused_view=True)
+        assert int(pkg["overflow"]) != 0
+        assert not bool(pkg["visibility_filter"].any())
+        for b, p in zip(before, (m._xyz, m._features_dc, m._opacity, m._scaling, m._rotation)):
+            assert torch.equal(b, p.detach()), "an overflowed view moved the parameters"
+        assert float(m.denom.sum()) == 0.0
+        with pytest.raises(RuntimeError):
+            PairPolicy.drain()                                       # reports the overflow, grows the reservation
+        loss, pkg = training_iteration(m, cam, gt, opt, PipelineParams(), bg, 2, fused_view=True)
+        assert int(pkg["overflow"]) == 0 and bool(pkg["visibility_filter"].any())
+        assert not torch.equal(before[0], m._xyz.detach())
+        assert PairPolicy.drain() > 0
+    finally:
+        PairPolicy.reset()
 
 
 def test_reserve_mode_pends_headers_not_states_and_train_view_checks_its_buffers(dev):
