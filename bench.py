@@ -116,11 +116,65 @@ def small_parity(dev):
                 psnr_db=(99.0 if mse == 0 else float(10 * math.log10(1.0 / mse))))
 
 
+def secondary_s6(dev, steps=40, warmup=8, cams=4):
+    """Secondary record of the default run: BASELINE config #5, the 2DGS surfel step on S6 (1 M surfels, 1600x1200, SH3):
+    render + 0.8 L1 + 0.2 (1 - SSIM) + normal-consistency / distortion regularisers + backward.  Same timing protocol."""
+    from scorp_amd import _C
+    from scorp_amd.fused_loss import fused_l1_ssim_loss
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd import rasterizer3d as R
+    from scorp_amd.renderer2d import GaussianModel2D, render as render2d, fused_surfel_regularizers
+    from scorp_amd.synthetic import SCENES, make_gaussians, ring_cameras
+    N, W, H, deg, seed, ncam_total = SCENES["S6"]
+    model = GaussianModel2D.from_raw(make_gaussians(N, deg, seed, scale_dims=2), deg, device=dev)
+    model.active_sh_degree = deg
+    params = [model._xyz, model._features_dc, model._features_rest, model._scaling, model._rotation, model._opacity]
+    my_cams = ring_cameras(ncam_total, W, H, seed, device=dev)[:cams]
+    bg, pipe = torch.zeros(3, device=dev), Pipe()
+    g = torch.Generator(device=dev).manual_seed(4321)
+    gts = []
+    with torch.no_grad():
+        for cam in my_cams:
+            img = render2d(cam, model, pipe, bg)["render"]
+            gts.append((img + 0.05 * torch.randn(img.shape, device=dev, generator=g)).clamp(0, 1))
+    Ds = list(R.LAST_NUM_PAIRS_LOG[-len(my_cams):])
+
+    def step(i):
+        out = render2d(my_cams[i % cams], model, pipe, bg)
+        loss = fused_l1_ssim_loss(out["render"], gts[i % cams], 0.2)
+        nl, dl = fused_surfel_regularizers(out, 0.05, 100.0)
+        (loss + nl + dl).backward()
+        for p in params:
+            p.grad = None
+
+    PairPolicy.mode, PairPolicy.reserve = "reserve", int(max(Ds) * 1.25) + 1024
+    _C.prof_enable(True)
+    for i in range(warmup):
+        step(i)
+    PairPolicy.drain()
+    torch.cuda.synchronize()
+    kern = _C.prof_collect()
+    _C.prof_enable(False)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    PairPolicy.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    PairPolicy.reset()
+    return {"metric": "fwd+bwd views/sec (S6, 2DGS surfels)", "value": round(steps / dt, 3), "unit": "views/s", "steps": steps,
+            "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+            "config": {"workload": f"S6: {N} surfels, {W}x{H}, SH degree {deg} (BASELINE config #5)",
+                       "step": "2DGS render + L1/SSIM + normal/distortion regularisers + backward (autograd call pattern)",
+                       "pairs_per_view_D": round(float(np.mean(Ds)))},
+            "kernels_us": {k: round(ms / cnt * 1e3, 1) for k, (ms, cnt) in kern.items() if cnt}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)      # SURVEY §8(d): >= 200 views after 20 warm-up views
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="S3")
     ap.add_argument("--cams", type=int, default=8, help="distinct cameras (with resident GT images) cycled per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,6 +189,8 @@ def main():
                          "pattern) instead of the single-call scorp_gs3d_train_view; same kernels, more host work per view")
     ap.add_argument("--unfused", action="store_true", help="reference call-site convention: torch activations + cat per view")
     ap.add_argument("--spatial-sort", action="store_true", help="GaussianModel.sort_spatially() first: Gaussians stored along a Z-order curve (not the default)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary record (the 2DGS workload S6) of the default N=1 run")
+    ap.add_argument("--exact-backward", action="store_true", help="all-fp32 MFMA reduction in the blend backward (scorp_gs3d_backward_ex) instead of the fp16 two-term split")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,6 +275,11 @@ def main():
     # form of training, or multi-view evaluation); the default, 1, is the reference's one-view-at-a-time loop
     side_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
 
+    if args.exact_backward:
+        R._tls.backward_flags = _C.BACKWARD_EXACT_FP32     # every forward from here on asks for the all-fp32 backward
+        if fused_view:
+            raise SystemExit("--exact-backward runs through the autograd call pattern: add --autograd")
+
     def step(i):
         cam, gt = my_cams[i % len(my_cams)], gts[i % len(my_cams)]
         if side_streams is not None:
@@ -280,6 +341,19 @@ def main():
     torch.cuda.synchronize()
     fwd_only = nf / (time.perf_counter() - tf0)
     PairPolicy.mode = "exact"
+    # work statistics of view 0 (SURVEY §8d asks for an honest pixel-splat figure next to HBM): (8x8 block, splat)
+    # iterations of the two blend kernels, each of which evaluates 64 pixel-splat pairs
+    work = None
+    if rank == 0 and not surfels:
+        import ctypes
+        R.KEEP_LAST_FORWARD = True
+        render(my_cams[0], model, pipe, bg)      # grad-enabled: the forward leaves its per-block statistics
+        R.KEEP_LAST_FORWARD = False
+        st, n_, w_, h_ = R.LAST_FORWARD
+        o3 = (ctypes.c_uint64 * 3)()
+        _C.check(_C.lib().scorp_gs3d_debug_work(st.data_ptr(), n_, w_, h_, ctypes.byref(o3), R._stream()), "scorp_gs3d_debug_work")
+        R.LAST_FORWARD = None
+        work = {"forward_block_splat_iterations": int(o3[0]), "backward_block_splat_iterations": int(o3[1]), "blocks_8x8": int(o3[2])}
     if world > 1:
         tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -305,26 +379,47 @@ def main():
                     kernels[name] = dict(avg_us=round(avg_ms * 1e3, 2), launches=cnt, alg_MB=round(b / 1e6, 2),
                                          GBs=round(b / (avg_ms * 1e-3) / 1e9, 1))
             dom = dominant if dominant in kernels else max(kernels, key=lambda k: kernels[k]["avg_us"])
-            traffic = None
+            lib_sha = _C.lib().scorp_source_sha().decode()
+            traffic, traffic_note = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-measured HBM bytes per launch (see profiles/README.md)
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(args.scene, {}).get(dom)
-            # the limiter the HBM figure cannot show: VALU issue slots.  wave64 VALU instructions per launch from
-            # the SQ counter pass (profiles/valu.json), 4 cycles each on one of 256 CUs x 4 SIMDs at 2.4 GHz
+                tj = json.load(open(tpath))
+                if tj.get("source_sha") == lib_sha:
+                    traffic = tj.get(args.scene, {}).get(dom)
+                else:
+                    traffic_note = (f"profiles/traffic.json was collected on kernel sources {tj.get('source_sha')}, the loaded library "
+                                    f"is {lib_sha}: re-run scripts/collect_profiles.sh")
+            # The limiter the HBM figure cannot show: the blend kernels are bound by VALU issue.  Per
+            # (8x8 block, splat) iteration the hot block's instruction mix (profiles/valu_mix.json, scripts/isa_mix.py)
+            # priced with the per-class issue costs MEASURED by scripts/mb_valu_peak.hip gives the time the launch would
+            # take with the VALU issuing back to back; frac = that / measured.
             valu = None
-            vpath = os.path.join(ROOT, "profiles", "valu.json")
-            if os.path.exists(vpath):
-                vi = json.load(open(vpath)).get(args.scene, {}).get(dom)
-                if vi:
-                    slots = kernels[dom]["avg_us"] * 1e-6 * 2.4e9 * 256 * 4
-                    valu = {"valu_insts_per_launch": vi["valu_insts"], "issue_slot_frac": round(vi["valu_insts"] * 4 / slots, 4),
-                            "note": "wave64 VALU instructions x 4 cycles / (launch duration x 1024 SIMDs x 2.4 GHz)"}
+            mpath = os.path.join(ROOT, "profiles", "valu_mix.json")
+            if work and os.path.exists(mpath):
+                mj = json.load(open(mpath))
+                if mj.get("source_sha") == lib_sha:
+                    valu = {"note": "instruction-mix VALU roofline: (block, splat) iterations x static cycles per iteration of the hot block "
+                                    "(measured issue costs, cycles at 2.4 GHz per wave-instruction per SIMD: VOP2 2.8, VOP3 3.3, v_cmp / "
+                                    "v_cndmask 4.15, transcendental 8.5; scripts/mb_valu_peak.hip) / 1024 SIMDs / 2.4 GHz, over the measured "
+                                    "launch duration; prologue, chunk and moment code are not in the static figure"}
+                    for kn, its in (("blend_forward", work["forward_block_splat_iterations"]), ("blend_backward", work["backward_block_splat_iterations"])):
+                        if kn in kernels and kn in mj:
+                            cyc = mj[kn]["valu_cycles_per_hit"] + mj[kn]["mfma_cycles_per_hit"]
+                            bound_us = its * cyc / 1024 / 2.4e9 * 1e6
+                            valu[kn] = {"valu_insts_per_iteration": mj[kn]["valu_insts_per_hit"], "cycles_per_iteration": round(cyc, 1),
+                                        "bound_us": round(bound_us, 1), "measured_us": kernels[kn]["avg_us"],
+                                        "issue_slot_frac": round(bound_us / kernels[kn]["avg_us"], 4)}
+                else:
+                    valu = {"note": f"profiles/valu_mix.json is for kernel sources {mj.get('source_sha')}, the library is {lib_sha}: run scripts/isa_mix.py"}
             roof = dict(bound="hbm", kernel=dom, achieved=kernels[dom]["GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(kernels[dom]["GBs"] / HBM_PEAK_GBS, 5), traffic=traffic,
                         avg_launch_us=kernels[dom]["avg_us"], algorithmic_bytes=int(kernel_algorithmic_bytes(dom, N, Nvis_mean, K, HW, D_mean)),
                         valu=valu,
                         note="dominant kernel timed live in the timed region; the other kernels' averages come from the "
-                             "bracketed warm-up steps. Blend kernels are VALU-issue bound, not HBM bound (DESIGN.md)")
+                             "bracketed warm-up steps. The blend kernels are bound by VALU issue (roofline.valu) and by the rate of "
+                             "memory-side float atomics, not by HBM bytes (DESIGN.md)")
+            if traffic_note:
+                roof["traffic_note"] = traffic_note
         B_view = N * 720 + HW * 40 + 28 * D_mean
         line = {
             "metric": "fwd+bwd views/sec @1M Gaussians 1600x1200 SH3" if args.scene == "S3" else f"fwd+bwd views/sec ({args.scene}{', 2DGS surfels' if surfels else ''})",
@@ -335,7 +430,18 @@ def main():
                        "step": "render fwd + 0.8*L1+0.2*(1-SSIM) + backward to 59 params/Gaussian; no optimizer step",
                        "views_per_rank": args.steps, "distinct_cameras_per_rank": len(my_cams),
                        "pairs_per_view_D": round(D_mean), "D_over_N": round(D_mean / N, 3), "visible": round(Nvis_mean),
+                       "pixel_splat_pairs_P": (64 * work["forward_block_splat_iterations"] if work else None),
+                       "pixel_splat_pairs_P_backward": (64 * work["backward_block_splat_iterations"] if work else None),
                        "parallelism": f"view-sharded replicas x{world}"},
+            "pairs_per_s": (round(value * 64 * (work["forward_block_splat_iterations"] + work["backward_block_splat_iterations"]))
+                            if work else None),
+            "pairs_note": "P = pixel-splat pairs EVALUATED per view (64 per (8x8 block, splat) iteration, after exact ellipse-vs-block culling), "
+                          "forward and backward listed apart; pairs_per_s = views/s x (P_forward + P_backward)",
+            "precision": {"arithmetic": "f32",
+                          "backward_pixel_to_splat_reduction": ("fp32 MFMA (v_mfma_f32_16x16x4_f32), SCORP_BACKWARD_EXACT_FP32" if args.exact_backward else
+                                                                 "two-term fp16 split of both factors (22 bits, exact products) on v_mfma_f32_16x16x32_f16, "
+                                                                 "fp32 accumulation; the all-fp32 form is scorp_gs3d_backward_ex(flags=1), "
+                                                                 "compared in tests/test_gs3d_gpu.py::test_split_backward_equals_exact_fp32_backward")},
             "roofline": roof,
             "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4),
             "step_call": "scorp_gs3d_train_view" if fused_view else "render + fused_l1_ssim_loss + autograd backward",
@@ -367,6 +473,8 @@ def main():
                     got = t_h[nm].grad.detach().cpu().numpy().reshape(ref.shape)
                     rel[nm] = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-20))
                 line["parity"]["full_size"]["grad_max_rel_err"] = rel
+        if world == 1 and args.scene == "S3" and not args.no_secondary and not args.exact_backward:
+            line["secondary"] = {"S6": secondary_s6(dev)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

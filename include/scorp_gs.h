@@ -91,6 +91,9 @@ typedef struct ScorpGs3dGrads {
 } ScorpGs3dGrads;
 
 int scorp_version(void);
+/* First 16 hex digits of the sha256 over the kernel sources (csrc/ *.hip, *.hpp, this header) the library was built
+ * from; profiles/traffic.json and profiles/valu.json carry the same stamp. */
+const char *scorp_source_sha(void);
 const char *scorp_last_error(void);
 
 /* ---- workspace sizing (pure host arithmetic) ---- */
@@ -147,6 +150,11 @@ int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *state, const v
 int scorp_gs3d_debug_geom(const void *state, int32_t num_gaussians, int32_t image_width, int32_t image_height,
                           float *xy, float *depth, float *conic_opacity, float *rgb, int32_t *rect,
                           scorp_stream_t stream);
+/* Work statistics of the last scorp_gs3d_render on this state: out3[0] = (8x8 block, splat) iterations the blend forward
+ * ran (each evaluates 64 pixel-splat pairs: P = 64 * out3[0]), out3[1] = those the blend backward replays (per block, up
+ * to its deepest last contributor), out3[2] = number of blocks. */
+int scorp_gs3d_debug_work(const void *state, int32_t num_gaussians, int32_t image_width, int32_t image_height,
+                          uint64_t *out3, scorp_stream_t stream);
 /* tile_start[tiles+1] (uint32) and the sorted splat list point_list[num_pairs] (uint32). */
 int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint64_t capacity, int32_t num_gaussians,
                            int32_t image_width, int32_t image_height, uint32_t *tile_start, uint32_t *point_list,

@@ -47,10 +47,10 @@ class ScorpAdamTensor(ctypes.Structure):
 
 
 EXPORTS = [
-    "scorp_version", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
+    "scorp_version", "scorp_source_sha", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
     "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
     "scorp_gs3d_render_image",
-    "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_backward_ex", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles",
+    "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_backward_ex", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles", "scorp_gs3d_debug_work",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
     "scorp_knn_dist2", "scorp_adam_step", "scorp_adam_step_guarded", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
@@ -81,6 +81,7 @@ def lib():
     vp, u64, i32, sz = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_size_t
     L.scorp_version.restype = ctypes.c_int
     L.scorp_last_error.restype = ctypes.c_char_p
+    L.scorp_source_sha.restype = ctypes.c_char_p
     L.scorp_gs3d_state_bytes.restype = sz
     L.scorp_gs3d_state_bytes.argtypes = [i32, i32, i32]
     L.scorp_gs3d_pairs_bytes.restype = sz
@@ -98,6 +99,7 @@ def lib():
                                          ctypes.POINTER(ScorpGs3dGrads), vp, sz, ctypes.c_uint32, vp]
     L.scorp_gs3d_debug_geom.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.scorp_gs3d_debug_tiles.argtypes = [vp, vp, u64, i32, i32, i32, vp, vp, vp]
+    L.scorp_gs3d_debug_work.argtypes = [vp, i32, i32, i32, ctypes.POINTER(u64 * 3), vp]
     L.scorp_loss_workspace_bytes.restype = sz
     L.scorp_loss_workspace_bytes.argtypes = [i32, i32, i32]
     L.scorp_loss_l1_ssim_forward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, sz, i32, vp]

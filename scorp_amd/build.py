@@ -19,6 +19,19 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def source_sha():
+    """sha256 over the kernel sources and the C header, first 16 hex digits (stamped into the library and into the
+    PMC-derived files under profiles/)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+    files.append(os.path.join(ROOT, "include", "scorp_gs.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -41,6 +54,8 @@ def build(force=False, verbose=False):
         # S6 +14 % views/s without it)
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-c", f"-I{os.path.join(ROOT, 'include')}",
                f"-I{CSRC}", src, "-o", obj]
+        if os.path.basename(src) == "api.hip":
+            cmd.insert(1, f'-DSCORP_SOURCE_SHA="{source_sha()}"')
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -95,4 +95,11 @@ extern "C" int scorp_prof_collect(double *total_ms, uint64_t *launches) {
 }
 
 extern "C" int scorp_version(void) { return 100; /* 0.1.0 */ }
+
+#ifndef SCORP_SOURCE_SHA
+#define SCORP_SOURCE_SHA "unknown"
+#endif
+// sha256 (first 16 hex digits) of the kernel sources this library was built from (scorp_amd/build.py): lets bench.py
+// tell whether the PMC-derived figures under profiles/ were collected on the code that is running
+extern "C" const char *scorp_source_sha(void) { return SCORP_SOURCE_SHA; }
 extern "C" const char *scorp_last_error(void) { return scorp::g_error; }

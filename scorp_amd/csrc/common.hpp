@@ -130,7 +130,7 @@ constexpr int kBinBlocksMax = 256;    // blocks of the LDS-histogram binning (ea
 inline int bin_blocks(int N) { int b = (N + 4095) / 4096; return b < 1 ? 1 : (b > kBinBlocksMax ? kBinBlocksMax : b); }
 
 struct StateLayout {
-  size_t header, rec, bin, tile_mask, tile_count, tile_start, final_T, n_contrib, block_hist, total;
+  size_t header, rec, bin, tile_mask, tile_count, tile_start, final_T, n_contrib, block_hits, block_hist, total;
   int tiles_x, tiles_y, tiles, nb;
   bool lds_binning;
   StateLayout(int N, int W, int H, bool mode2d = false) {
@@ -147,6 +147,7 @@ struct StateLayout {
     tile_start = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
     final_T = off; off = align_up(off + hw * 4 * (mode2d ? 3 : 1), 256);     // 2DGS also keeps M1, M2 per pixel
     n_contrib = off; off = align_up(off + hw * 4 * (mode2d ? 2 : 1), 256);   // ... and the median contributor
+    block_hits = off; off = align_up(off + (size_t)tiles * 4 * 4, 256);      // per 8x8 block: hits the blend forward replayed
     nb = bin_blocks(N);
     lds_binning = tiles <= kMaxLdsTiles;
     block_hist = off; off = align_up(off + (lds_binning ? (size_t)nb * tiles * 4 : 0), 256);

@@ -455,7 +455,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
                           float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                          uint32_t *__restrict__ hits) {
+                          uint32_t *__restrict__ hits, uint32_t *__restrict__ block_hits) {
   // ring entries: the record's (x, y, A, B), (C, log2 opacity, r, g), (b, depth) as preprocess stored them:
   // alpha = exp2(A dx^2 + C dy^2 + B dx dy + log2 opacity), one v_exp and no multiply
   __shared__ float4 q_a[kFRing], q_b[kFRing];
@@ -523,6 +523,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       const float2 *gc = q_c + hv;
       const uint32_t *gp = q_pos + hv;
       float al[kFGroup];
+      bool live[kFGroup];   // lane masks (SGPR pairs): the alpha test's verdict is reused for the last-contributor bookkeeping
       static_assert(kFGroup % 4 == 0, "positions are fetched as 16-byte LDS reads");
       uint32_t pos[kFGroup];
 #pragma unroll
@@ -536,7 +537,8 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
         const float2 co = *reinterpret_cast<const float2 *>(&gb[i]);
         const float e = splat_exponent(qa.x - pxf, qa.y - pyf, qa.z, qa.w, co.x, co.y);   // log2(opacity * G)
         const float alpha = fminf(kAlphaMax, __builtin_amdgcn_exp2f(e));
-        al[i] = ((kFull || i < nslots) & (e <= co.y) & (alpha >= kAlphaMin)) ? alpha : 0.0f;   // e <= log2 o: power <= 0
+        live[i] = (kFull || i < nslots) & (e <= co.y) & (alpha >= kAlphaMin);   // e <= log2 o: power <= 0
+        al[i] = live[i] ? alpha : 0.0f;
       }
 #pragma unroll
       for (int i = 0; i < kFGroup; i++) {
@@ -554,15 +556,23 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
           C0 += rg.x * w; C1 += rg.y * w; C2 += bz.x * w;
           Dp += bz.y * w;
           T = ok ? test_T : -fabsf(T);
-          if constexpr (kForBackward) last = ae > 0.0f ? pos[i] : last;
+          if constexpr (kForBackward) last = (ok & live[i]) ? pos[i] : last;   // ae > 0, from the two masks (no third compare)
         }
       }
       head = (head + kFGroup) & (kFRing - 1);
       count -= nslots;
     };
-    while (count >= kFGroup) blend_group(std::true_type{}, kFGroup);
+    bool all_done = false;   // every pixel saturated: checked after every group, not only once per 64 list entries
+    while (count >= kFGroup) {
+      blend_group(std::true_type{}, kFGroup);
+      if (__ballot(T > 0.0f) == 0) { all_done = true; break; }
+    }
+    if (all_done) break;
     if (last_chunk && count > 0) blend_group(std::false_type{}, count);
     id0 = id1; a = a1; b = b1; c = c1; id1 = id2;
+  }
+  if constexpr (kForBackward) {
+    if (lane == 0) block_hits[tile * 4 + quad] = nh - (uint32_t)count;   // (block, splat) iterations this wave ran: the P statistic
   }
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
@@ -748,7 +758,7 @@ static int render_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint
     bk<<<blocks, 64, 0, stream>>>(
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
         out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib),
-        (uint32_t *)(pb + P.hits));
+        (uint32_t *)(pb + P.hits), (uint32_t *)(base + L.block_hits));
   }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;
@@ -791,6 +801,33 @@ extern "C" int scorp_gs3d_debug_geom(const void *state, int32_t N, int32_t W, in
     if (rect) { rect[4 * i] = vis ? hbin[i].x0 : 0; rect[4 * i + 1] = vis ? hbin[i].y0 : 0; rect[4 * i + 2] = vis ? hbin[i].x1 : 0; rect[4 * i + 3] = vis ? hbin[i].y1 : 0; }
   }
   free(hrec); free(hbin);
+  return SCORP_OK;
+}
+
+extern "C" int scorp_gs3d_debug_work(const void *state, int32_t N, int32_t W, int32_t H, uint64_t *out3, scorp_stream_t stream_) {
+  if (!state || !out3) { set_error("NULL argument to scorp_gs3d_debug_work"); return SCORP_ERR_INVALID; }
+  hipStream_t stream = (hipStream_t)stream_;
+  const StateLayout L(N, W, H);
+  const size_t nb = (size_t)L.tiles * 4, hw = (size_t)W * H;
+  uint32_t *hb = (uint32_t *)malloc(nb * 4), *hc = (uint32_t *)malloc(hw * 4);
+  if (!hb || !hc) { free(hb); free(hc); set_error("host allocation failed"); return SCORP_ERR_INVALID; }
+  hipError_t e = hipMemcpyAsync(hb, (const char *)state + L.block_hits, nb * 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(hc, (const char *)state + L.n_contrib, hw * 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) { free(hb); free(hc); set_error("debug_work copy failed: %s", hipGetErrorString(e)); return SCORP_ERR_HIP; }
+  uint64_t fwd = 0, bwd = 0;
+  for (size_t b = 0; b < nb; b++) fwd += hb[b];
+  const int tiles_x = L.tiles_x;
+  for (int t = 0; t < L.tiles; t++)
+    for (int q = 0; q < 4; q++) {   // the backward replays, per block, up to the deepest last contributor of its pixels
+      const int bx = (t % tiles_x) * kTile + (q & 1) * 8, by = (t / tiles_x) * kTile + (q >> 1) * 8;
+      uint32_t m = 0;
+      for (int y = by; y < by + 8 && y < H; y++)
+        for (int x = bx; x < bx + 8 && x < W; x++) m = hc[(size_t)y * W + x] > m ? hc[(size_t)y * W + x] : m;
+      bwd += m;
+    }
+  out3[0] = fwd; out3[1] = bwd; out3[2] = (uint64_t)nb;
+  free(hb); free(hc);
   return SCORP_OK;
 }
 

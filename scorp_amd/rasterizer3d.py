@@ -133,6 +133,8 @@ def backward_precision(mode):
         _tls.backward_flags = prev
 
 
+KEEP_LAST_FORWARD = False   # diagnostics (bench.py): keep (state, N, W, H) of the most recent forward in LAST_FORWARD
+LAST_FORWARD = None
 LAST_NUM_PAIRS_LOG = []   # pair counts of the most recent "exact"-mode forwards (diagnostics / bench bookkeeping)
 
 
@@ -271,6 +273,9 @@ def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opaciti
              "scorp_gs3d_render")
     if PairPolicy.mode != "exact":
         PairPolicy.pend(state, N, H, W)   # what drain() will look at: a copy of the StateHeader the render just filled in
+    if KEEP_LAST_FORWARD:
+        global LAST_FORWARD
+        LAST_FORWARD = (state, N, W, H)
     ctx.settings, ctx.capacity = settings, capacity
     ctx.backward_flags = getattr(_tls, "backward_flags", 0)
     ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward: the kernels skip those terms

@@ -47,5 +47,8 @@ for scene, fpath, wpath in zip(args[0::3], args[1::3], args[2::3]):
     f, w = per_launch(fpath, "FETCH_SIZE"), per_launch(wpath, "WRITE_SIZE")
     out[scene] = {k: int((2 * f[k] + w.get(k, 0.0)) * 1024) for k in f}
     out["_detail_" + scene] = {k: {"FETCH_SIZE_KB": round(f[k], 1), "WRITE_SIZE_KB": round(w.get(k, 0.0), 1)} for k in f}
+sys.path.insert(0, root)
+from scorp_amd.build import source_sha  # noqa: E402
+out["source_sha"] = source_sha()   # bench.py reports roofline.traffic only while the loaded library carries the same stamp
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_")}, indent=1))
