@@ -23,12 +23,12 @@ class _Pipe:
 
 
 @torch.no_grad()
-def render_views(model, cameras, bg):
-    return [render(c, model, _Pipe(), bg) for c in cameras]
+def render_views(model, cameras, bg, render_fn=render):
+    return [render_fn(c, model, _Pipe(), bg) for c in cameras]
 
 
 @torch.no_grad()
-def hypothesis_fitness(model, R, cameras, targets, bg):
+def hypothesis_fitness(model, R, cameras, targets, bg, render_fn=render):
     """Higher is better: minus the mean |alpha - alpha*| + |depth - depth*| over the cameras."""
     m = copy.copy(model)
     m._xyz, m._rotation = model._xyz.detach().clone(), model._rotation.detach().clone()
@@ -36,93 +36,111 @@ def hypothesis_fitness(model, R, cameras, targets, bg):
     gaussians_rotate(m, R, fix_center=True)
     err = 0.0
     for cam, tgt in zip(cameras, targets):
-        out = render(cam, m, _Pipe(), bg)
+        out = render_fn(cam, m, _Pipe(), bg)
         err = err + (out["render_alpha"] - tgt["render_alpha"]).abs().mean() + \
             (out["render_depth"] - tgt["render_depth"]).abs().mean()
     return -(err / len(cameras))
 
 
-def _sweep_eager(model, rotations, ids, cameras, targets, bg, dev):
-    """Renders issued without host synchronisation (`PairPolicy` "reserve"), verified once per hypothesis; a hypothesis
-    whose reservation overflowed is re-scored with exact sizing."""
-    out = []
-    for i in ids:
-        R = torch.as_tensor(rotations[i], dtype=torch.float32, device=dev)
-        prev = PairPolicy.mode
+class SweepPlan:
+    """Everything of a rotation sweep that does not depend on the hypothesis, built once: on a GPU one hypothesis (rotate
+    + len(cameras) renders + comparison) is captured as a HIP graph and `score()` replays it per rotation - the sweep's
+    kernels are tens of microseconds each, so eager launches are CPU-bound (3.1k renders/s eager, 5.1k replayed at 100k
+    Gaussians / 800x800).  The pair reservation is learned from an eager pass; every replay's overflow flags are folded
+    into a device-side maximum and checked once per `score()`.  With `use_graph=False` (CPU stand-in renderers, capture
+    failures) hypotheses are scored with eager launches, each verified by PairPolicy.drain()."""
+
+    def __init__(self, model, cameras, targets, bg, use_graph=None, render_fn=render):
+        self.model, self.cameras, self.targets, self.bg, self.render_fn = model, cameras, targets, bg, render_fn
+        self.dev = model._xyz.device
+        self.graph = None
+        if use_graph is None:
+            use_graph = self.dev.type == "cuda" and render_fn is render
+        if use_graph:
+            try:
+                self._capture()
+            except Exception:   # capture unsupported: the eager path is always correct
+                torch.cuda.synchronize()
+                self.graph = None
+
+    def _capture(self):
+        prev, pend_before = PairPolicy.mode, PairPolicy._pending
         PairPolicy.mode = "reserve"
         try:
-            f = hypothesis_fitness(model, R, cameras, targets, bg)
-            PairPolicy.drain()
-        except RuntimeError:
-            PairPolicy.mode = "exact"
-            f = hypothesis_fitness(model, R, cameras, targets, bg)
+            PairPolicy._pending = []
+            self.Rbuf = torch.eye(3, dtype=torch.float32, device=self.dev)
+            hypothesis_fitness(self.model, self.Rbuf, self.cameras, self.targets, self.bg)
+            worst = PairPolicy.drain()                       # sizes the reservation (raises if the default was too small)
+            PairPolicy.reserve = max(PairPolicy.reserve, int(2.0 * worst) + 4096)   # other rotations see other pair counts
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                hypothesis_fitness(self.model, self.Rbuf, self.cameras, self.targets, self.bg)
+                PairPolicy.drain()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.fit = hypothesis_fitness(self.model, self.Rbuf, self.cameras, self.targets, self.bg)
+                states, PairPolicy._pending = PairPolicy._pending, []
+                # StateHeader: num_pairs u32 @0, overflow u32 @4
+                self.flags = torch.stack([p.header[:8].view(torch.int32) for p in states]).amax(0)
+            self.graph = graph
         finally:
             PairPolicy.mode = prev
-        out.append(f.reshape(1).float())
-    return out
+            PairPolicy._pending = pend_before
 
+    def score(self, rotations, ids):
+        """Fitness (1-element float tensors) of the hypotheses `ids` of `rotations`."""
+        if self.graph is not None:
+            try:
+                worst_flags = torch.zeros(2, dtype=torch.int32, device=self.dev)
+                out = []
+                for i in ids:
+                    self.Rbuf.copy_(torch.as_tensor(rotations[i], dtype=torch.float32), non_blocking=True)
+                    self.graph.replay()
+                    out.append(self.fit.reshape(1).float().clone())
+                    worst_flags = torch.maximum(worst_flags, self.flags)
+                n_pairs, overflow = (int(v) for v in worst_flags.tolist())   # the sweep's one synchronisation
+                if not overflow:
+                    return out
+                PairPolicy.reserve = max(PairPolicy.reserve, int(1.25 * n_pairs) + 4096)
+            except Exception:
+                torch.cuda.synchronize()
+            self.graph = None   # reservation overflowed during replay / replay failed: eager from here on
+        return self._score_eager(rotations, ids)
 
-def _sweep_graph(model, rotations, ids, cameras, targets, bg, dev):
-    """One hypothesis (rotate + len(cameras) renders + comparison) captured as a HIP graph and replayed per rotation:
-    the sweep's kernels are tens of microseconds each, so eager launches are CPU-bound (3.1k renders/s eager, 5.1k
-    replayed at 100k Gaussians / 800x800).  The pair reservation is learned from an eager pass; every replay's
-    overflow flags are folded into a device-side maximum and checked once at the end."""
-    prev = PairPolicy.mode
-    PairPolicy.mode = "reserve"
-    pend_before = PairPolicy._pending
-    try:
-        PairPolicy._pending = []
-        Rbuf = torch.as_tensor(rotations[ids[0]], dtype=torch.float32, device=dev).clone()
-        hypothesis_fitness(model, Rbuf, cameras, targets, bg)
-        worst = PairPolicy.drain()                       # sizes the reservation (raises if the default was too small)
-        PairPolicy.reserve = max(PairPolicy.reserve, int(2.0 * worst) + 4096)   # other rotations see other pair counts
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            hypothesis_fitness(model, Rbuf, cameras, targets, bg)
-            PairPolicy.drain()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            fit = hypothesis_fitness(model, Rbuf, cameras, targets, bg)
-            states, PairPolicy._pending = PairPolicy._pending, []
-            # StateHeader: num_pairs u32 @0, overflow u32 @4
-            flags = torch.stack([p.header[:8].view(torch.int32) for p in states]).amax(0)
-        worst_flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    def _score_eager(self, rotations, ids):
+        """Renders issued without host synchronisation (`PairPolicy` "reserve"), verified once per hypothesis; a hypothesis
+        whose reservation overflowed is re-scored with exact sizing."""
         out = []
+        on_gpu = self.dev.type == "cuda"
         for i in ids:
-            Rbuf.copy_(torch.as_tensor(rotations[i], dtype=torch.float32), non_blocking=True)
-            graph.replay()
-            out.append(fit.reshape(1).float().clone())
-            worst_flags = torch.maximum(worst_flags, flags)
-        n_pairs, overflow = (int(v) for v in worst_flags.tolist())   # the sweep's one synchronisation
-        if overflow:
-            PairPolicy.reserve = max(PairPolicy.reserve, int(1.25 * n_pairs) + 4096)
-            raise RuntimeError("pair reservation overflowed during graph replay")
+            R = torch.as_tensor(rotations[i], dtype=torch.float32, device=self.dev)
+            prev = PairPolicy.mode
+            PairPolicy.mode = "reserve" if on_gpu else prev
+            try:
+                f = hypothesis_fitness(self.model, R, self.cameras, self.targets, self.bg, self.render_fn)
+                if on_gpu:
+                    PairPolicy.drain()
+            except RuntimeError:
+                PairPolicy.mode = "exact"
+                f = hypothesis_fitness(self.model, R, self.cameras, self.targets, self.bg, self.render_fn)
+            finally:
+                PairPolicy.mode = prev
+            out.append(f.reshape(1).float())
         return out
-    finally:
-        PairPolicy.mode = prev
-        PairPolicy._pending = pend_before
 
 
-def rotation_sweep(model, rotations, cameras, targets, bg, use_graph=None):
-    """Score every rotation hypothesis (sharded over ranks); returns (ids, fitness[n,1], best id).  On a GPU the
-    hypotheses of this rank are replayed from a captured HIP graph (`use_graph=False`, or any capture failure, falls
-    back to eager launches)."""
+def rotation_sweep(model, rotations, cameras, targets, bg, use_graph=None, plan=None, render_fn=render):
+    """Score every rotation hypothesis (hypothesis j -> rank j mod world, one all-gather of (id, fitness) at the end);
+    returns (ids, fitness[n,1], best id) on every rank.  `plan`: a SweepPlan built earlier (its graph capture is then
+    outside the caller's timed region)."""
     from .parallel import gather_results, shard_indices
     dev = model._xyz.device
     mine = shard_indices(len(rotations))
-    if use_graph is None:
-        use_graph = dev.type == "cuda"
-    vals = None
-    if use_graph and mine:
-        try:
-            vals = _sweep_graph(model, rotations, mine, cameras, targets, bg, dev)
-        except Exception:   # capture unsupported / reservation overflow: the eager path is always correct
-            torch.cuda.synchronize()
-            vals = None
-    if vals is None:
-        vals = _sweep_eager(model, rotations, mine, cameras, targets, bg, dev)
+    if plan is None:
+        plan = SweepPlan(model, cameras, targets, bg, use_graph=use_graph, render_fn=render_fn)
+    vals = plan.score(rotations, mine) if mine else []
     v = torch.stack(vals) if vals else torch.zeros((0, 1), dtype=torch.float32, device=dev)
     ids, scores = gather_results(mine, v.to(dev))
     best = int(ids[torch.argmax(scores[:, 0])]) if ids.numel() else -1

@@ -21,11 +21,21 @@ def shard_indices(n, rank=None, world_size=None):
 
 
 def broadcast_tensors(tensors, src=0):
-    """In-place broadcast of a dict of equally-shaped tensors (the scene: N x 236 B = 236 MB at 1 M Gaussians, SH3)."""
-    _, w = world()
-    if w > 1:
-        for k in sorted(tensors):
-            dist.broadcast(tensors[k], src=src)
+    """In-place broadcast of a dict of float32 tensors (the scene: N x 236 B = 236 MB at 1 M Gaussians, SH3) as ONE flat
+    buffer: one collective instead of one per tensor (xGMI is point-to-point - few, large messages).  Every
+    rank passes tensors of the same shapes; the source's values arrive in place."""
+    r, w = world()
+    if w > 1 and tensors:
+        keys = sorted(tensors)
+        flat = torch.cat([tensors[k].reshape(-1) for k in keys]) if r == src else \
+            torch.empty(sum(tensors[k].numel() for k in keys), dtype=tensors[keys[0]].dtype, device=tensors[keys[0]].device)
+        dist.broadcast(flat, src=src)
+        if r != src:
+            off = 0
+            for k in keys:
+                n = tensors[k].numel()
+                tensors[k].copy_(flat[off:off + n].view_as(tensors[k]))
+                off += n
     return tensors
 
 

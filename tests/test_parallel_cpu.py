@@ -214,3 +214,81 @@ def test_two_rank_data_parallel_training_keeps_replicas_identical():
     ref = torch.cat([p.detach().reshape(-1) for p in (m._xyz, m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation)])
     assert ref.numel() == flat.numel()
     assert (ref - flat).abs().max() < 1e-5
+
+
+# ---- rotation_sweep itself on two gloo ranks (a stand-in renderer replaces the HIP rasterizer on CPU) ----
+def _standin_render(cam, pc, pipe, bg, **_):
+    """Orthographic depth / alpha splat of the points onto a 16x16 grid: enough for the fitness to prefer the planted
+    rotation, differentiability not needed."""
+    import torch
+    xyz = pc.get_xyz @ cam.R.T
+    ij = ((xyz[:, :2] * 4.0) + 8.0).long().clamp(0, 15)
+    flat = ij[:, 1] * 16 + ij[:, 0]
+    alpha = torch.zeros(256).index_add_(0, flat, torch.ones(flat.numel())).clamp(max=1.0)
+    depth = torch.zeros(256).index_add_(0, flat, xyz[:, 2]) / torch.zeros(256).index_add_(0, flat, torch.ones(flat.numel())).clamp(min=1.0)
+    return {"render_alpha": alpha.view(1, 16, 16), "render_depth": depth.view(1, 16, 16)}
+
+
+class _SweepCam:
+    def __init__(self, k):
+        import math
+        import torch
+        c, s_ = math.cos(0.7 * k), math.sin(0.7 * k)
+        self.R = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+def _sweep_setup():
+    import copy
+    import numpy as np
+    import torch
+    from scorp_amd.align import render_views
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.synthetic import make_gaussians
+    from scorp_amd.transforms import gaussians_rotate
+    rots = np.load(os.path.join(os.path.dirname(__file__), "golden", "rotations_128.npz"))["rotations"][:12]
+    raw = make_gaussians(400, 0, 8, extent=0.8)
+    raw["xyz"][:, 0] *= 1.8
+    obj = GaussianModel.from_raw(raw, 0, device="cpu")
+    cams = [_SweepCam(k) for k in range(3)]
+    tgt = copy.copy(obj)
+    tgt._xyz, tgt._rotation, tgt._features_rest = obj._xyz.detach().clone(), obj._rotation.detach().clone(), obj._features_rest.detach().clone()
+    gaussians_rotate(tgt, torch.tensor(rots[7], dtype=torch.float32), fix_center=True)
+    targets = render_views(tgt, cams, torch.zeros(3), render_fn=_standin_render)
+    return obj, rots, cams, targets
+
+
+def _sweep_worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from scorp_amd.align import rotation_sweep
+        obj, rots, cams, targets = _sweep_setup()
+        ids, fit, best = rotation_sweep(obj, rots, cams, targets, torch.zeros(3), use_graph=False, render_fn=_standin_render)
+        q.put((rank, "ok", ids.tolist(), fit[:, 0].tolist(), best))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), [], [], -1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rotation_sweep_itself_on_two_gloo_ranks():
+    """scorp_amd.align.rotation_sweep (hypothesis j -> rank j mod 2, one all-gather): both ranks end with all twelve
+    fitness values in id order, equal to the single-process sweep, and pick the planted rotation."""
+    from scorp_amd.align import rotation_sweep
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    obj, rots, cams, targets = _sweep_setup()
+    ids1, fit1, best1 = rotation_sweep(obj, rots, cams, targets, torch.zeros(3), use_graph=False, render_fn=_standin_render)
+    for r in res:
+        assert r[2] == list(range(12)) == ids1.tolist()
+        assert r[3] == fit1[:, 0].tolist()
+        assert r[4] == best1 == 7
