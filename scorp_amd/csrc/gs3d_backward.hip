@@ -81,7 +81,10 @@ constexpr int kChunk = 64;
 #ifndef SCORP_BWD_WAVES
 #define SCORP_BWD_WAVES 4
 #endif
-template <bool kHasDA, bool kExact>  // kHasDA false: no upstream gradient on the depth / alpha images (the photometric-loss-only step)
+// kHasDA false: no upstream gradient on the depth / alpha images (the photometric-loss-only step).
+// kColorOnly: only dL/dcolour is wanted (post_refine_gs.py:53-56 freezes xyz / scale / rotation / opacity and trains SH0):
+// no dL/dalpha, no "blended behind" recurrence, no v; the matrix rows carry w alone, three sums per splat leave.
+template <bool kHasDA, bool kExact, bool kColorOnly = false>
 __global__ void __launch_bounds__(64, SCORP_BWD_WAVES)
 blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ hits,
                            const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
@@ -254,16 +257,23 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
             const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
             T *= rinv;
             const float w = alpha * T;
-            R = last_alpha * (s_last - R) + R;
-            const float sc = kHasDA ? b.z * dpix0 + b.w * dpix1 + bz.x * dpix2 + bz.y * ddep + dalp
-                                    : b.z * dpix0 + b.w * dpix1 + bz.x * dpix2;
-            const float dL_dal = (sc - R) * T - tf_bg * rinv;
-            s_last = sc;
-            last_alpha = alpha;
-            const float v = Go * dL_dal;
+            float v = 0.0f;
+            if constexpr (!kColorOnly) {
+              R = last_alpha * (s_last - R) + R;
+              const float sc = kHasDA ? b.z * dpix0 + b.w * dpix1 + bz.x * dpix2 + bz.y * ddep + dalp
+                                      : b.z * dpix0 + b.w * dpix1 + bz.x * dpix2;
+              const float dL_dal = (sc - R) * T - tf_bg * rinv;
+              s_last = sc;
+              last_alpha = alpha;
+              v = Go * dL_dal;
+            }
             if constexpr (kExact) {
               xm[i8 * kXStride + lane] = __float_as_uint(v);
               xm[(8 + i8) * kXStride + lane] = __float_as_uint(w);
+            } else if constexpr (kColorOnly) {
+              const uint32_t p1 = pack_rtz16(0.0f, w);
+              xm[i8 * kXStride + lane] = p1;
+              xm[(8 + i8) * kXStride + lane] = pack_rtz16(0.0f, __builtin_fmaf(half_hi(p1), -1.0f, w));
             } else {   // x = h1 + h2, two fp16 terms (round toward zero, saturating); v and w share the dwords
               const uint32_t p1 = pack_rtz16(v, w);
               const uint32_t p2 = pack_rtz16(__builtin_fmaf(half_lo(p1), -1.0f, v), __builtin_fmaf(half_hi(p1), -1.0f, w));
@@ -334,15 +344,21 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
           mm[8] = ((u2.x + w2.x) + (u3.x + w3.x)) * inv_w; mm[9] = ((u2.y + w2.y) + (u3.y + w3.y)) * inv_w;
         }
       }
-      const float m0 = mm[0], mx = mm[1], my = mm[2], mxx = mm[3], mxy = mm[4], myy = mm[5];
-      const float svdx = xl * m0 - mx, svdy = yl * m0 - my;
-      const float svdx2 = xl * xl * m0 - 2.0f * xl * mx + mxx;
-      const float svdxdy = xl * yl * m0 - xl * my - yl * mx + mxy;
-      const float svdy2 = yl * yl * m0 - 2.0f * yl * my + myy;
-      *reinterpret_cast<float4 *>(m) = make_float4(0.5f * W * (-cA * svdx - cB * svdy), 0.5f * H * (-cC * svdy - cB * svdx),
-                                                   -0.5f * svdx2, -svdxdy);
-      *reinterpret_cast<float4 *>(m + 4) = make_float4(-0.5f * svdy2, m0 / opac, mm[6], mm[7]);
-      *reinterpret_cast<float2 *>(m + 8) = make_float2(mm[8], mm[9]);
+      if constexpr (kColorOnly) {
+        *reinterpret_cast<float4 *>(m) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        *reinterpret_cast<float4 *>(m + 4) = make_float4(0.0f, 0.0f, mm[6], mm[7]);
+        *reinterpret_cast<float2 *>(m + 8) = make_float2(mm[8], 0.0f);
+      } else {
+        const float m0 = mm[0], mx = mm[1], my = mm[2], mxx = mm[3], mxy = mm[4], myy = mm[5];
+        const float svdx = xl * m0 - mx, svdy = yl * m0 - my;
+        const float svdx2 = xl * xl * m0 - 2.0f * xl * mx + mxx;
+        const float svdxdy = xl * yl * m0 - xl * my - yl * mx + mxy;
+        const float svdy2 = yl * yl * m0 - 2.0f * yl * my + myy;
+        *reinterpret_cast<float4 *>(m) = make_float4(0.5f * W * (-cA * svdx - cB * svdy), 0.5f * H * (-cC * svdy - cB * svdx),
+                                                     -0.5f * svdx2, -svdxdy);
+        *reinterpret_cast<float4 *>(m + 4) = make_float4(-0.5f * svdy2, m0 / opac, mm[6], mm[7]);
+        *reinterpret_cast<float2 *>(m + 8) = make_float2(mm[8], mm[9]);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -356,7 +372,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     for (int k = 0; k < 4; k++) {
       const int sl = 4 * k + (lane >> 4), col = lane & 15;
       park_v[k] = 0.0f;
-      if (sl < nslots && col < 10) {
+      if (sl < nslots && (kColorOnly ? (col >= 6 && col < 9) : col < 10)) {
         park_v[k] = dbuf[sl * kDStride + col];
         park_o[k] = q_id[head + sl] * (uint32_t)kAccStride + col;
       }
@@ -448,8 +464,12 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
     ProfScope prof(kKBlendBackward, stream);
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
     const bool da = dL_ddepth || dL_dalpha, exact = (flags & SCORP_BACKWARD_EXACT_FP32) != 0;
-    auto wk = exact ? (da ? blend_backward_wave_kernel<true, true> : blend_backward_wave_kernel<false, true>)
-                    : (da ? blend_backward_wave_kernel<true, false> : blend_backward_wave_kernel<false, false>);
+    // nothing but colour gradients wanted (every geometry / opacity output NULL): the colour-only replay
+    const bool color_only = !exact && !grads->means3D && !grads->means2D && !grads->opacities && !grads->scales &&
+                            !grads->rotations && !grads->cov3D_precomp;
+    auto wk = color_only ? blend_backward_wave_kernel<false, false, true>
+              : exact ? (da ? blend_backward_wave_kernel<true, true> : blend_backward_wave_kernel<false, true>)
+                      : (da ? blend_backward_wave_kernel<true, false> : blend_backward_wave_kernel<false, false>);
     wk<<<blocks, 64, 0, stream>>>(
         (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.hits), (const SplatRec *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),

@@ -307,7 +307,22 @@ __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float 
   for (int q = 0; q < 10; q++) a_[q] = 0.0f;
   float g_op = 0.0f;
   const ShRow row = sh_row(s_sh, threadIdx.x, lin);
-  if (visible) {
+  // colour-only calls (post_refine_gs.py:53-56: every geometry / opacity leaf frozen) skip the whole geometry chain
+  const bool want_geom = g.means3D || g.means2D || g.opacities || g.scales || g.rotations || g.cov3D_precomp;
+  if (visible && !want_geom) {
+#pragma unroll
+    for (int q = 6; q < 9; q++) a_[q] = LIN ? pre_acc[q] : acc[(size_t)i * kAccStride + q];
+    if (a.shs) {
+      const float p0 = LIN ? pre[0] : a.means3D[3 * (size_t)i], p1 = LIN ? pre[1] : a.means3D[3 * (size_t)i + 1],
+                  p2 = LIN ? pre[2] : a.means3D[3 * (size_t)i + 2];
+      const float d0 = p0 - ((const CFloat *)a.campos)[0], d1 = p1 - ((const CFloat *)a.campos)[1], d2_ = p2 - ((const CFloat *)a.campos)[2];
+      shinv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2_ * d2_);
+      shx = d0 * shinv; shy = d1 * shinv; shz = d2_ * shinv;
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) gr3[ch] = ((rad_bits >> (kClampShift + ch)) & 1) ? 0.0f : a_[6 + ch];
+    }
+  }
+  if (visible && want_geom) {
     float p0, p1, p2;
     if constexpr (LIN) {
 #pragma unroll

@@ -15,7 +15,7 @@ from .sh import eval_sh
 _ZEROS = {}
 
 
-def _grad_sink(xyz):
+def _grad_sink(xyz, requires_grad=True):
     """A fresh leaf of zeros shaped like xyz (the screen-space gradient sink) over a cached, never-written storage."""
     key = (xyz.shape[0], xyz.dtype, xyz.device)
     z = _ZEROS.get(key)
@@ -23,7 +23,7 @@ def _grad_sink(xyz):
         if len(_ZEROS) > 8:
             _ZEROS.clear()
         z = _ZEROS[key] = torch.zeros_like(xyz, requires_grad=False)
-    return z.detach().requires_grad_(True)
+    return z.detach().requires_grad_(True) if requires_grad else z
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
@@ -32,7 +32,10 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     # (gaussian_renderer/__init__.py:39-43) — a leaf with requires_grad gives the caller the same `.grad` without the
     # extra 12 MB add kernel per view; the zeros themselves are shared between views (nothing ever writes them), so
     # not even a fill kernel runs: every view gets a fresh leaf over the same storage
-    screenspace_points = _grad_sink(xyz)
+    # ... unless the positions are frozen (post_refine_gs.py:53-56 freezes xyz / scale / rotation / opacity): nothing
+    # densifies then and nobody reads the screen-space gradient (post_refine_gs.py:99,178-180 are commented out), and
+    # without it the backward only has colour gradients to produce and takes its colour-only path.
+    screenspace_points = _grad_sink(xyz, xyz.requires_grad)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     w, h = viewpoint_camera.resolution

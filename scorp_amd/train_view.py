@@ -68,7 +68,9 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     need = [p.requires_grad for p in leaves]          # frozen leaves (post-refine) get no gradient buffer: NULL = not wanted
     need[1] = need[2] = need[1] or need[2]            # the SH gradient is written as a whole
     g = [torch.empty_like(x) if n else None for x, n in zip(t, need)]
-    g_means2D = new((N, 3))
+    # the screen-space gradient feeds the densification statistics: not produced when the positions are frozen
+    # (renderer.render does the same), which leaves the backward with colour gradients only -> its colour-only path
+    g_means2D = new((N, 3)) if xyz.requires_grad else None
     grads = _C.ScorpGs3dGrads()
     grads.means3D, grads.means2D, grads.shs, grads.shs_rest = _ptr(g[0]), _ptr(g_means2D), _ptr(g[1]), _ptr(g[2])
     grads.opacities, grads.scales, grads.rotations = _ptr(g[3]), _ptr(g[4]), _ptr(g[5])

@@ -253,3 +253,41 @@ def test_reserve_mode_pends_headers_not_states_and_train_view_checks_its_buffers
     v = _C.ScorpGs3dTrainView()          # everything NULL
     assert L.scorp_gs3d_train_view(ctypes.byref(v), None) != 0
     assert b"NULL" in L.scorp_last_error()
+
+
+def test_colour_only_backward_equals_the_full_backward(dev):
+    """With xyz / scale / rotation / opacity frozen (post_refine_gs.py:53-56) the backward runs its colour-only path (no
+    dL/dalpha, no geometry chain): the SH gradients must equal those of the full backward on the same view to float-
+    atomics noise, the frozen leaves get no gradient, and no screen-space gradient is produced - through autograd
+    render() and through the one-call view."""
+    from scorp_amd.fused_loss import fused_l1_ssim_loss
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.renderer import render
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams
+    from scorp_amd.train_view import train_view
+    raw = make_gaussians(8000, 3, 31, log_scale_mean=math.log(0.03))
+    cam = ring_cameras(5, 208, 144, 3, radius=3.5, device=dev)[1]
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    gt = torch.rand(3, 144, 208, device=dev)
+    pipe = PipelineParams()
+    full = GaussianModel.from_raw(raw, 3, device=dev); full.active_sh_degree = 3
+    fused_l1_ssim_loss(render(cam, full, pipe, bg)["render"], gt, 0.2).backward()
+    for path in ("autograd", "one_call"):
+        m = GaussianModel.from_raw(raw, 3, device=dev); m.active_sh_degree = 3
+        for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
+            getattr(m, n).requires_grad_(False)
+        if path == "autograd":
+            pkg = render(cam, m, pipe, bg)
+            fused_l1_ssim_loss(pkg["render"], gt, 0.2).backward()
+        else:
+            pkg = train_view(cam, m, pipe, bg, gt, 0.2)
+            PairPolicy.drain()
+        assert pkg["viewspace_points"].grad is None
+        for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
+            assert getattr(m, n).grad is None, n
+        for n in ("_features_dc", "_features_rest"):
+            ga, gb = getattr(full, n).grad, getattr(m, n).grad
+            assert gb is not None and float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max()), (path, n)
+    PairPolicy.reset()
