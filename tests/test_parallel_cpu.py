@@ -292,3 +292,22 @@ def test_rotation_sweep_itself_on_two_gloo_ranks():
         assert r[2] == list(range(12)) == ids1.tolist()
         assert r[3] == fit1[:, 0].tolist()
         assert r[4] == best1 == 7
+
+
+def test_sh_rotation_blocks_match_the_independent_wigner_table():
+    """scorp_amd.transforms.sh_rotation_blocks (a least-squares fit on sampled directions) against tests/golden/wigner_d.npz,
+    generated by tests/golden/make_wigner_golden.py from the Ivanic-Ruedenberg recurrence AND by quadrature (the two agree
+    to 1e-10 there): D_1, D_2, D_3 for eight rotations; and for l = 1 the block IS the permuted rotation,
+    D_1 = S (P R P^T) S with P: (x, y, z) -> (y, z, x) and S the basis signs (-1)^m (utils/gaussians.py:67-72's
+    `inv(P) @ R @ P`)."""
+    import numpy as np
+    import torch
+    from scorp_amd.transforms import sh_rotation_blocks
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "wigner_d.npz"))
+    P = np.zeros((3, 3)); P[0, 1] = P[1, 2] = P[2, 0] = 1.0
+    S = np.diag([-1.0, 1.0, -1.0])
+    for k, R in enumerate(g["rotations"]):
+        blocks = sh_rotation_blocks(torch.tensor(R, dtype=torch.float64), 3)
+        for l, name in ((1, "D1"), (2, "D2"), (3, "D3")):
+            assert np.abs(blocks[l - 1].double().numpy() - g[name][k]).max() < 2e-6, (k, l)
+        assert np.abs(g["D1"][k] - S @ (P @ R @ P.T) @ S).max() < 1e-12
