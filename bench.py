@@ -139,11 +139,10 @@ def secondary_s6(dev, steps=40, warmup=8, cams=4):
             gts.append((img + 0.05 * torch.randn(img.shape, device=dev, generator=g)).clamp(0, 1))
     Ds = list(R.LAST_NUM_PAIRS_LOG[-len(my_cams):])
 
-    def step(i):
-        out = render2d(my_cams[i % cams], model, pipe, bg)
-        loss = fused_l1_ssim_loss(out["render"], gts[i % cams], 0.2)
-        nl, dl = fused_surfel_regularizers(out, 0.05, 100.0)
-        (loss + nl + dl).backward()
+    from scorp_amd.train_view import train_view2d
+
+    def step(i):   # one library call per view (scorp_gs2d_train_view): render + L1/SSIM + regularisers + backward
+        train_view2d(my_cams[i % cams], model, pipe, bg, gts[i % cams], 0.2, 0.05, 100.0)
         for p in params:
             p.grad = None
 
@@ -165,7 +164,7 @@ def secondary_s6(dev, steps=40, warmup=8, cams=4):
     return {"metric": "fwd+bwd views/sec (S6, 2DGS surfels)", "value": round(steps / dt, 3), "unit": "views/s", "steps": steps,
             "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
             "config": {"workload": f"S6: {N} surfels, {W}x{H}, SH degree {deg} (BASELINE config #5)",
-                       "step": "2DGS render + L1/SSIM + normal/distortion regularisers + backward (autograd call pattern)",
+                       "step": "2DGS render + L1/SSIM + normal/distortion regularisers + backward, one call (scorp_gs2d_train_view)",
                        "pairs_per_view_D": round(float(np.mean(Ds)))},
             "kernels_us": {k: round(ms / cnt * 1e3, 1) for k, (ms, cnt) in kern.items() if cnt}}
 

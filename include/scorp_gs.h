@@ -281,6 +281,40 @@ typedef struct ScorpGs3dTrainView {
 } ScorpGs3dTrainView;
 int scorp_gs3d_train_view(const ScorpGs3dTrainView *view, scorp_stream_t stream);
 
+/* The 2DGS twin: one iteration of train_2dgs.py:95-150 for the plain photometric loss plus its two regularisers,
+ *   scorp_gs2d_preprocess -> scorp_gs2d_render -> scorp_loss_l1_ssim_forward -> scorp_gs2d_regularizers_forward ->
+ *   scorp_loss_l1_ssim_backward -> scorp_gs2d_regularizers_backward -> scorp_gs2d_backward,
+ * enqueued by one call; total loss = out_loss3[0] + out_reg2[0] + out_reg2[1].  With lambda_normal = lambda_dist = 0
+ * (iterations <= 3000, train_2dgs.py:142-143) the regulariser kernels are skipped and no allmap gradient is formed.
+ * rays_d[H*W,3] / rays_o[3]: the camera's ray table (see scorp_gs2d_maps_forward).  Every buffer is the caller's. */
+typedef struct ScorpGs2dTrainView {
+  const ScorpGs3dInputs *in;
+  int32_t *out_radii;            /* [N] */
+  void *state;                   /* scorp_gs2d_state_bytes(), 256-byte aligned */
+  size_t state_bytes;
+  void *pairs;                   /* scorp_gs3d_pairs_bytes(capacity) */
+  uint64_t capacity;
+  float *out_color;              /* [3,H,W] */
+  float *out_allmap;             /* [7,H,W] */
+  const float *gt;               /* [3,H,W] */
+  const float *mask;             /* [H,W] or NULL */
+  const float *rays_d;           /* [H*W,3] */
+  const float *rays_o;           /* [3] */
+  float lambda_dssim, depth_ratio, lambda_normal, lambda_dist;
+  float *out_loss3;              /* device: {photometric loss, l1, ssim} */
+  float *out_reg2;               /* device: {normal loss, distortion loss} (zeros if both lambdas are 0) */
+  void *loss_workspace;          /* scorp_loss_workspace_bytes(3, H, W) */
+  size_t loss_workspace_bytes;
+  void *reg_workspace;           /* scorp_gs2d_regularizers_workspace_bytes(W, H) */
+  size_t reg_workspace_bytes;
+  float *grad_color;             /* [3,H,W] scratch */
+  float *grad_allmap;            /* [7,H,W] scratch */
+  const ScorpGs3dGrads *grads;
+  void *backward_scratch;        /* scorp_gs2d_backward_scratch_bytes(N) */
+  size_t backward_scratch_bytes;
+} ScorpGs2dTrainView;
+int scorp_gs2d_train_view(const ScorpGs2dTrainView *view, scorp_stream_t stream);
+
 /* ---- simple_knn replacement ----
  * out[i] = mean of the squared distances from point i to its 3 nearest other points, as
  * `simple_knn._C.distCUDA2(points)` (gs3dgs/scene/gaussian_model.py:177).  xyz[N,3], out[N]. */

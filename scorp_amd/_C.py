@@ -41,6 +41,19 @@ class ScorpGs3dTrainView(ctypes.Structure):
                 ("backward_scratch_bytes", ctypes.c_size_t)]
 
 
+class ScorpGs2dTrainView(ctypes.Structure):
+    _fields_ = [("inputs", ctypes.c_void_p), ("out_radii", ctypes.c_void_p), ("state", ctypes.c_void_p),
+                ("state_bytes", ctypes.c_size_t), ("pairs", ctypes.c_void_p), ("capacity", ctypes.c_uint64),
+                ("out_color", ctypes.c_void_p), ("out_allmap", ctypes.c_void_p), ("gt", ctypes.c_void_p),
+                ("mask", ctypes.c_void_p), ("rays_d", ctypes.c_void_p), ("rays_o", ctypes.c_void_p),
+                ("lambda_dssim", ctypes.c_float), ("depth_ratio", ctypes.c_float), ("lambda_normal", ctypes.c_float),
+                ("lambda_dist", ctypes.c_float), ("out_loss3", ctypes.c_void_p), ("out_reg2", ctypes.c_void_p),
+                ("loss_workspace", ctypes.c_void_p), ("loss_workspace_bytes", ctypes.c_size_t),
+                ("reg_workspace", ctypes.c_void_p), ("reg_workspace_bytes", ctypes.c_size_t),
+                ("grad_color", ctypes.c_void_p), ("grad_allmap", ctypes.c_void_p), ("grads", ctypes.c_void_p),
+                ("backward_scratch", ctypes.c_void_p), ("backward_scratch_bytes", ctypes.c_size_t)]
+
+
 class ScorpAdamTensor(ctypes.Structure):
     _fields_ = [("param", c_float_p), ("grad", c_float_p), ("exp_avg", c_float_p), ("exp_avg_sq", c_float_p),
                 ("numel", ctypes.c_uint64), ("lr", ctypes.c_float), ("_pad", ctypes.c_float)]
@@ -57,7 +70,7 @@ EXPORTS = [
     "scorp_gs2d_render_image",
     "scorp_gs2d_backward", "scorp_gs2d_debug_geom", "scorp_gs2d_debug_tiles", "scorp_gs2d_maps_forward",
     "scorp_gs2d_maps_backward", "scorp_gs2d_regularizers_workspace_bytes", "scorp_gs2d_regularizers_forward",
-    "scorp_gs2d_regularizers_backward", "scorp_gs3d_train_view",
+    "scorp_gs2d_regularizers_backward", "scorp_gs3d_train_view", "scorp_gs2d_train_view",
     "scorp_prof_enable", "scorp_prof_select", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
 ]
 
@@ -123,6 +136,7 @@ def lib():
     L.scorp_gs2d_regularizers_forward.argtypes = [i32, i32, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, sz, vp]
     L.scorp_gs2d_regularizers_backward.argtypes = [i32, i32, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp]
     L.scorp_gs3d_train_view.argtypes = [ctypes.POINTER(ScorpGs3dTrainView), vp]
+    L.scorp_gs2d_train_view.argtypes = [ctypes.POINTER(ScorpGs2dTrainView), vp]
     L.scorp_knn_dist2.argtypes = [vp, i32, vp, vp]
     L.scorp_adam_step.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i32, vp]
     L.scorp_adam_step_guarded.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double,

@@ -106,6 +106,19 @@ __device__ __forceinline__ float dpp_add(float v) {
   return v + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xF, 0xF, false));
 }
 
+// Wave-wide maximum of a u32 (also of non-negative floats, through their bits), uniform result: four DPP steps inside
+// each row of 16 lanes (xor 1, xor 2, half-mirror, mirror), then the four rows through v_readlane.  No LDS round trips
+// (the __shfl_xor form is six dependent ds_bpermute).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                 c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+
 // Tile mask convention: bit (ty - y0) * 8 + (tx - x0) for rectangles of at most 8 x 8 tiles; ~0 = whole rectangle.
 constexpr uint64_t kMaskAll = ~0ull;
 template <typename F>

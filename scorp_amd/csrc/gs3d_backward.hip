@@ -84,6 +84,29 @@ constexpr int kChunk = 64;
 // kHasDA false: no upstream gradient on the depth / alpha images (the photometric-loss-only step).
 // kColorOnly: only dL/dcolour is wanted (post_refine_gs.py:53-56 freezes xyz / scale / rotation / opacity and trains SH0):
 // no dL/dalpha, no "blended behind" recurrence, no v; the matrix rows carry w alone, three sums per splat leave.
+// fp16 bits of the V columns of the B operand: kBasisV[bn][q] = column bn (1, x, y, x^2, xy, y^2 in the block frame, half-
+// integer coordinates: exact) at pixel q of the 8x8 block.  A lane's sixteen values are consecutive (q = 16 bk .. + 15).
+struct BasisTable { uint16_t v[6][64]; };
+constexpr uint16_t f16_bits_small(float x) {   // exact for the multiples of 0.25 below 16 that occur here
+  if (x == 0.0f) return 0;
+  const uint16_t sign = x < 0.0f ? 0x8000u : 0u;
+  float a = x < 0.0f ? -x : x;
+  int e = 15;
+  while (a >= 2.0f) { a *= 0.5f; e++; }
+  while (a < 1.0f) { a *= 2.0f; e--; }
+  return (uint16_t)(sign | (e << 10) | (uint16_t)((a - 1.0f) * 1024.0f));
+}
+constexpr BasisTable make_basis_table() {
+  BasisTable t{};
+  for (int q = 0; q < 64; q++) {
+    const float xl = (float)(q & 7) - 3.5f, yl = (float)(q >> 3) - 3.5f;
+    const float col[6] = {1.0f, xl, yl, xl * xl, xl * yl, yl * yl};
+    for (int c = 0; c < 6; c++) t.v[c][q] = f16_bits_small(col[c]);
+  }
+  return t;
+}
+__device__ const BasisTable kBasisV = make_basis_table();
+
 template <bool kHasDA, bool kExact, bool kColorOnly = false>
 __global__ void __launch_bounds__(64, SCORP_BWD_WAVES)
 blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ hits,
@@ -127,19 +150,14 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     if (kHasDA && dL_dalpha) dalp = dL_dalpha[pix];
   }
   if (last == 0) { dpix0 = dpix1 = dpix2 = ddep = dalp = 0.0f; }
-  uint32_t todo = last;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
-  todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // tell the compiler it is wave-uniform: the chunk loop,
-  if (todo == 0) return;                                        // ring head / count and slot indices then live in SGPRs
+  const uint32_t todo = wave_max_u32(last);   // wave-uniform (SGPR): the chunk loop and the slot indices live in SGPRs
+  if (todo == 0) return;
   // split form: one power-of-two scale per wave from the block's largest upstream gradient
   float sv = 1.0f, inv_sv = 1.0f;
   if constexpr (!kExact) {
     float amax = fmaxf(fmaxf(fabsf(dpix0), fabsf(dpix1)), fabsf(dpix2));
     if (kHasDA) amax = fmaxf(amax, fmaxf(fabsf(ddep), fabsf(dalp)));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
-    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xFFu);            // biased exponent; 0: zero / denormal
+    const int eb = (int)((wave_max_u32(__float_as_uint(amax)) >> 23) & 0xFFu);   // biased exponent (|x| orders like its bits); 0: zero / denormal
     int sb = eb == 0 ? 127 : 254 + (kHasDA ? kVTargetExpDA : kVTargetExp) - eb;   // biased exponent of the scale
     sb = min(max(sb, 1), 253);
     sv = __uint_as_float((uint32_t)sb << 23);
@@ -173,19 +191,24 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       bb[t] = v;
     }
   } else {
+    // fp16 MFMA m covers pixels 16 bk + 4 m + j, j = 0..3: element 2j = v slot, 2j + 1 = w slot.  V columns (bn < 6) come
+    // from the constant table (two 16-byte loads per lane), W columns from the exchanged gradients.
+    uint4 tv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    if (bn < 6) {
+      const uint4 *tp = reinterpret_cast<const uint4 *>(&kBasisV.v[bn][16 * bk]);
+      tv[0] = tp[0]; tv[1] = tp[1];
+    }
+    const uint32_t tw[8] = {tv[0].x, tv[0].y, tv[0].z, tv[0].w, tv[1].x, tv[1].y, tv[1].z, tv[1].w};
 #pragma unroll
-    for (int m = 0; m < 4; m++)      // fp16 MFMA m covers pixels 16 bk + 4 m + j, j = 0..3: element 2j = v slot, 2j + 1 = w slot
+    for (int m = 0; m < 4; m++)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const int q = 16 * bk + 4 * m + j;
-        const float xl = (float)(q & 7) - 3.5f, yl = (float)(q >> 3) - 3.5f;
-        float v = 0.0f;
-        v = bn == 0 ? 1.0f : v; v = bn == 1 ? xl : v; v = bn == 2 ? yl : v;
-        v = bn == 3 ? xl * xl : v; v = bn == 4 ? xl * yl : v; v = bn == 5 ? yl * yl : v;
+        const int q = 16 * bk + 4 * m + j, e = 4 * m + j;
+        const uint32_t vbits = (e & 1) ? tw[e >> 1] >> 16 : tw[e >> 1] & 0xFFFFu;
         const float g = (bn >= 6 && bn <= 13) ? xs[q * 4 + ((bn - 6) & 3)] : 0.0f;
         const uint32_t g1 = pack_rtz16(g, 0.0f);
         const float gw = bn <= 9 ? half_lo(g1) : g - half_lo(g1);     // columns 6..9: first term, 10..13: the remainder
-        bh[m].d[j] = pack_rtz16(v, gw);
+        bh[m].d[j] = vbits | (pack_rtz16(gw, 0.0f) << 16);
       }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -26,3 +26,38 @@ extern "C" int scorp_gs3d_train_view(const ScorpGs3dTrainView *v, scorp_stream_t
   return scorp_gs3d_backward(in, v->state, v->pairs, v->capacity, v->grad_color, nullptr, nullptr, v->grads,
                              v->backward_scratch, v->backward_scratch_bytes, stream);
 }
+
+extern "C" int scorp_gs2d_train_view(const ScorpGs2dTrainView *v, scorp_stream_t stream) {
+  if (!v || !v->in || !v->grads) { set_error("NULL argument to scorp_gs2d_train_view"); return SCORP_ERR_INVALID; }
+  if (!v->out_color || !v->out_allmap || !v->out_radii || !v->gt || !v->out_loss3 || !v->out_reg2 || !v->grad_color) {
+    set_error("scorp_gs2d_train_view: an output / ground-truth / scratch pointer is NULL");
+    return SCORP_ERR_INVALID;
+  }
+  const ScorpGs3dInputs *in = v->in;
+  const int W = in->image_width, H = in->image_height;
+  const bool reg = v->lambda_normal != 0.0f || v->lambda_dist != 0.0f;
+  if (reg && (!v->rays_d || !v->rays_o || !v->grad_allmap || !v->reg_workspace)) {
+    set_error("scorp_gs2d_train_view: the regularisers need rays_d, rays_o, grad_allmap and reg_workspace");
+    return SCORP_ERR_INVALID;
+  }
+  hipStream_t hs = (hipStream_t)stream;
+  if (int e = scorp_gs2d_preprocess(in, v->out_radii, v->state, v->state_bytes, stream)) return e;
+  if (int e = scorp_gs2d_render(in, v->state, v->pairs, v->capacity, v->out_color, v->out_allmap, stream)) return e;
+  if (int e = scorp_loss_l1_ssim_forward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->out_loss3,
+                                         v->loss_workspace, v->loss_workspace_bytes, 1, stream)) return e;
+  if (reg) {
+    if (int e = scorp_gs2d_regularizers_forward(W, H, v->out_allmap, in->viewmatrix, v->rays_d, v->rays_o, v->depth_ratio,
+                                                v->lambda_normal, v->lambda_dist, v->out_reg2, v->reg_workspace,
+                                                v->reg_workspace_bytes, stream)) return e;
+  } else {
+    SCORP_HIP_CHECK(hipMemsetAsync(v->out_reg2, 0, 2 * sizeof(float), hs));
+  }
+  if (int e = scorp_loss_l1_ssim_backward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,
+                                          v->grad_color, stream)) return e;
+  if (reg) {
+    if (int e = scorp_gs2d_regularizers_backward(W, H, v->out_allmap, in->viewmatrix, v->rays_d, v->rays_o, v->depth_ratio,
+                                                 v->lambda_normal, v->lambda_dist, nullptr, v->grad_allmap, stream)) return e;
+  }
+  return scorp_gs2d_backward(in, v->state, v->pairs, v->capacity, v->grad_color, reg ? v->grad_allmap : nullptr, v->grads,
+                             v->backward_scratch, v->backward_scratch_bytes, stream);
+}

@@ -58,7 +58,18 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
     bg = torch.rand(3, device=background.device) if opt.random_background else background
     extra_terms = iteration > getattr(opt, "depth_from_iter", 1 << 30) and (
         gt_depth is not None or gt_depth_est is not None or getattr(opt, "lambda_isotropic", 0.0) > 0)
-    if (fused_view and not surfels and not extra_terms and render_fn is render and loss_fn is fused_l1_ssim_loss
+    if (fused_view and surfels and not extra_terms and loss_fn is fused_l1_ssim_loss and getattr(pipe, "fused_activations", False)
+            and hasattr(gaussians, "raw_leaves")):
+        # the 2DGS iteration (train_2dgs.py:95-150) by ONE library call: render + loss + regularisers + backward
+        from .train_view import train_view2d
+        lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
+        lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
+        pkg = train_view2d(cam, gaussians, pipe, bg, gt_image, opt.lambda_dssim, lambda_normal, lambda_dist)
+        loss = pkg["loss"]
+        if hasattr(gaussians.optimizer, "skip_flag"):
+            gaussians.optimizer.skip_flag = pkg["overflow"]
+        pkg["visibility_filter"] = pkg["visibility_filter"] & (pkg["overflow"] == 0)
+    elif (fused_view and not surfels and not extra_terms and render_fn is render and loss_fn is fused_l1_ssim_loss
             and getattr(pipe, "fused_activations", False)):
         # plain photometric iteration: render + loss + backward enqueued by ONE library call (train_view.py); same
         # kernels and results, no autograd graph.  The pair buffer is reserved, the caller drains (see train()).

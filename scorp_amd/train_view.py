@@ -101,3 +101,75 @@ class _ViewspaceGrad:
 
     def __init__(self, grad):
         self.grad = grad
+
+
+def train_view2d(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2, lambda_normal=0.0, lambda_dist=0.0,
+                 mask=None, scaling_modifier=1.0):
+    """The 2DGS twin of `train_view`: one iteration of train_2dgs.py:95-150 for the plain photometric loss plus the
+    normal-consistency / depth-distortion regularisers (train_2dgs.py:142-150), enqueued by ONE library call
+    (`scorp_gs2d_train_view`).  Returns "render", "allmap", "radii", "visibility_filter", "viewspace_points",
+    "loss" (= photometric + normal + distortion, a 0-d device tensor), "l1", "ssim", "normal_loss", "dist_loss",
+    "overflow"; parameter gradients are accumulated into the surfel model's leaves."""
+    from .renderer2d import _camera_rays
+    L = _C.lib()
+    xyz = pc.get_xyz
+    if not xyz.is_cuda:
+        raise RuntimeError("train_view2d needs GPU tensors (scorp_amd has no CPU path)")
+    f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw = pc.raw_leaves()
+    leaves = (xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw)
+    dev = xyz.device
+    w, h = viewpoint_camera.resolution
+    W, H, N = int(w), int(h), xyz.shape[0]
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
+        tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+    t = [_prep(x.detach(), n) for x, n in zip(leaves, ("means3D", "features_dc", "features_rest", "opacity", "scaling", "rotation"))]
+    keep = []
+    args = _inputs_struct(settings, t[0], t[1], None, t[3], t[4], t[5], None, keep, t[2], 7)
+    gt = _prep(gt_image, "gt_image")
+    if mask is not None:
+        mask = _prep(mask.expand(1, H, W), "mask")
+    new = lambda shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=dev)
+    color, allmap = new((3, H, W)), new((7, H, W))
+    radii = new((N,), torch.int32)
+    loss5, grad_color, grad_allmap = new((5,)), new((3, H, W)), new((7, H, W))
+    state_bytes = L.scorp_gs2d_state_bytes(N, W, H)
+    state = new((state_bytes,), torch.uint8)
+    capacity = PairPolicy.capacity(N, H, W)
+    pairs = new((L.scorp_gs3d_pairs_bytes(capacity),), torch.uint8)
+    ws_bytes = L.scorp_loss_workspace_bytes(3, H, W)
+    ws = new((ws_bytes,), torch.uint8)
+    rws_bytes = L.scorp_gs2d_regularizers_workspace_bytes(W, H)
+    rws = new((rws_bytes,), torch.uint8)
+    scratch_bytes = L.scorp_gs2d_backward_scratch_bytes(N)
+    scratch = new((scratch_bytes,), torch.uint8)
+    need = [p.requires_grad for p in leaves]
+    need[1] = need[2] = need[1] or need[2]
+    g = [torch.empty_like(x) if n else None for x, n in zip(t, need)]
+    g_means2D = new((N, 3)) if xyz.requires_grad else None
+    grads = _C.ScorpGs3dGrads()
+    grads.means3D, grads.means2D, grads.shs, grads.shs_rest = _ptr(g[0]), _ptr(g_means2D), _ptr(g[1]), _ptr(g[2])
+    grads.opacities, grads.scales, grads.rotations = _ptr(g[3]), _ptr(g[4]), _ptr(g[5])
+    rays_d, rays_o = _camera_rays(viewpoint_camera, dev)
+    v = _C.ScorpGs2dTrainView()
+    v.inputs = ctypes.addressof(args)
+    v.out_radii, v.state, v.state_bytes, v.pairs, v.capacity = radii.data_ptr(), state.data_ptr(), state_bytes, pairs.data_ptr(), capacity
+    v.out_color, v.out_allmap = color.data_ptr(), allmap.data_ptr()
+    v.gt, v.mask = gt.data_ptr(), (None if mask is None else mask.data_ptr())
+    v.rays_d, v.rays_o = rays_d.data_ptr(), rays_o.data_ptr()
+    v.lambda_dssim, v.depth_ratio = float(lambda_dssim), float(getattr(pipe, "depth_ratio", 1.0))
+    v.lambda_normal, v.lambda_dist = float(lambda_normal), float(lambda_dist)
+    v.out_loss3, v.out_reg2 = loss5.data_ptr(), loss5[3:].data_ptr()
+    v.loss_workspace, v.loss_workspace_bytes, v.reg_workspace, v.reg_workspace_bytes = ws.data_ptr(), ws_bytes, rws.data_ptr(), rws_bytes
+    v.grad_color, v.grad_allmap, v.grads = grad_color.data_ptr(), grad_allmap.data_ptr(), ctypes.addressof(grads)
+    v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes
+    _C.check(L.scorp_gs2d_train_view(ctypes.byref(v), _stream()), "scorp_gs2d_train_view")
+    header = PairPolicy.pend(state, N, H, W)
+    for p, gp in zip(leaves, g):
+        if p.requires_grad:
+            _accumulate(p, gp.view_as(p))
+    return {"render": color, "allmap": allmap, "viewspace_points": _ViewspaceGrad(g_means2D), "visibility_filter": radii > 0,
+            "radii": radii, "loss": loss5[0] + loss5[3] + loss5[4], "l1": loss5[1], "ssim": loss5[2],
+            "normal_loss": loss5[3], "dist_loss": loss5[4], "overflow": header.view(torch.int32)[1:2]}

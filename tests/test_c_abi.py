@@ -59,12 +59,13 @@ def test_header_is_plain_c(tmp_path):
     from scorp_amd import _C
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "t.c"
-    src.write_text('#include <stdio.h>\n#include "scorp_gs.h"\nint main(void) { printf("%zu %zu %zu\\n", '
-                   'sizeof(ScorpGs3dInputs), sizeof(ScorpGs3dGrads), sizeof(ScorpGs3dTrainView)); return 0; }\n')
+    src.write_text('#include <stdio.h>\n#include "scorp_gs.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", '
+                   'sizeof(ScorpGs3dInputs), sizeof(ScorpGs3dGrads), sizeof(ScorpGs3dTrainView), sizeof(ScorpGs2dTrainView)); return 0; }\n')
     exe = tmp_path / "t"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
-    a, b, c = (int(x) for x in subprocess.check_output([str(exe)]).split())
-    assert (a, b, c) == (ctypes.sizeof(_C.ScorpGs3dInputs), ctypes.sizeof(_C.ScorpGs3dGrads), ctypes.sizeof(_C.ScorpGs3dTrainView))
+    a, b, c, d = (int(x) for x in subprocess.check_output([str(exe)]).split())
+    assert (a, b, c, d) == (ctypes.sizeof(_C.ScorpGs3dInputs), ctypes.sizeof(_C.ScorpGs3dGrads), ctypes.sizeof(_C.ScorpGs3dTrainView),
+                            ctypes.sizeof(_C.ScorpGs2dTrainView))
 
 
 def test_shim_packages_expose_reference_names(built_lib):

@@ -291,3 +291,47 @@ def test_colour_only_backward_equals_the_full_backward(dev):
             ga, gb = getattr(full, n).grad, getattr(m, n).grad
             assert gb is not None and float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max()), (path, n)
     PairPolicy.reset()
+
+
+def test_train_view2d_equals_render_loss_regularizers_backward(dev):
+    """scorp_gs2d_train_view (one library call) against renderer2d.render() + fused_l1_ssim_loss +
+    fused_surfel_regularizers + loss.backward(): same image, allmap, radii bit for bit; the three loss terms equal;
+    parameter / screen-space gradients equal up to the order of the float atomics; with both lambdas 0 the regulariser
+    kernels are skipped and the result equals the photometric-only backward."""
+    from scorp_amd.fused_loss import fused_l1_ssim_loss
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.renderer2d import GaussianModel2D, fused_surfel_regularizers, render as render2d
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams
+    from scorp_amd.train_view import train_view2d
+    raw = make_gaussians(6000, 3, 23, log_scale_mean=math.log(0.04), scale_dims=2)
+    cam = ring_cameras(5, 200, 136, 3, radius=3.5, device=dev)[2]
+    bg = torch.tensor([0.1, 0.3, 0.2], device=dev)
+    pipe = PipelineParams()
+    gt = torch.rand(3, 136, 200, device=dev)
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    for ln, ld in ((0.05, 100.0), (0.0, 0.0)):
+        a = GaussianModel2D.from_raw(raw, 3, device=dev); a.active_sh_degree = 3
+        b = GaussianModel2D.from_raw(raw, 3, device=dev); b.active_sh_degree = 3
+        pa = render2d(cam, a, pipe, bg)
+        la = fused_l1_ssim_loss(pa["render"], gt, 0.2)
+        if ln or ld:
+            nl, dl = fused_surfel_regularizers(pa, ln, ld)
+            tot = la + nl + dl
+        else:
+            nl = dl = torch.zeros((), device=dev)
+            tot = la
+        tot.backward()
+        pb = train_view2d(cam, b, pipe, bg, gt, 0.2, ln, ld)
+        PairPolicy.drain()
+        assert torch.equal(pa["render"], pb["render"]) and torch.equal(pa["radii"], pb["radii"])
+        assert torch.equal(pa.allmap, pb["allmap"])
+        assert float(la) == float(pb["loss"] - pb["normal_loss"] - pb["dist_loss"]) or abs(float(tot) - float(pb["loss"])) < 1e-6
+        assert abs(float(nl) - float(pb["normal_loss"])) < 1e-7 and abs(float(dl) - float(pb["dist_loss"])) < 1e-7
+        for n in names:
+            ga, gb = getattr(a, n).grad, getattr(b, n).grad
+            assert gb is not None and gb.shape == ga.shape, n
+            assert float((ga - gb).abs().max()) <= 2e-3 * float(ga.abs().max()) + 1e-12, n
+        va, vb = pa["viewspace_points"].grad, pb["viewspace_points"].grad
+        assert float((va - vb).abs().max()) <= 2e-3 * float(va.abs().max()) + 1e-12
+    PairPolicy.reset()
