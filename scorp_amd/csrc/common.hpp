@@ -137,7 +137,10 @@ __device__ __forceinline__ void for_each_tile(int x0, int y0, int x1, int y1, ui
 #endif
 
 // Forward state layout (one caller-owned blob, 256-byte aligned sub-buffers).
-constexpr int kMaxLdsTiles = 16384;   // per-block tile histograms live in LDS up to this many tiles (64 KiB)
+constexpr int kMaxLdsTiles = 36864;   // tiles per pass of the LDS-histogram binning (144 KiB of the CU's 160 KiB): up to
+                                      // 3072 x 3072 pixels in ONE pass; larger images (the align loop renders at up to
+                                      // 1.5^3 x the base resolution, cameras.py:139-148) take ceil(tiles / this) passes
+                                      // over the Gaussians, each pass owning a contiguous range of tiles
 constexpr int kBinBlocksMax = 256;    // blocks of the LDS-histogram binning (each owns a contiguous Gaussian range)
 
 inline int bin_blocks(int N) { int b = (N + 4095) / 4096; return b < 1 ? 1 : (b > kBinBlocksMax ? kBinBlocksMax : b); }
@@ -146,6 +149,8 @@ struct StateLayout {
   size_t header, rec, bin, tile_mask, tile_count, tile_start, final_T, n_contrib, block_hits, block_hist, total;
   int tiles_x, tiles_y, tiles, nb;
   bool lds_binning;
+  int bin_passes() const { return (tiles + kMaxLdsTiles - 1) / kMaxLdsTiles; }
+  int tiles_per_pass() const { return tiles < kMaxLdsTiles ? tiles : kMaxLdsTiles; }
   StateLayout(int N, int W, int H, bool mode2d = false) {
     tiles_x = (W + kTile - 1) / kTile;
     tiles_y = (H + kTile - 1) / kTile;
@@ -162,7 +167,7 @@ struct StateLayout {
     n_contrib = off; off = align_up(off + hw * 4 * (mode2d ? 2 : 1), 256);   // ... and the median contributor
     block_hits = off; off = align_up(off + (size_t)tiles * 4 * 4, 256);      // per 8x8 block: hits the blend forward replayed
     nb = bin_blocks(N);
-    lds_binning = tiles <= kMaxLdsTiles;
+    lds_binning = tiles <= 64 * kMaxLdsTiles;   // (beyond: the global-atomic fallback; 150 M pixels)
     block_hist = off; off = align_up(off + (lds_binning ? (size_t)nb * tiles * 4 : 0), 256);
     total = off;
   }

@@ -117,23 +117,30 @@ scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__re
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kBinThreads = 1024;   // few Gaussians per thread: the count / scatter loops are latency chains (load -> LDS atomic -> store)
 
+// Images with more tiles than one LDS histogram holds are binned in passes: workgroup (pass, block) owns the tile range
+// [pass * tpp, (pass + 1) * tpp) of bin block `block` (blockIdx.x = pass * nb + block).
 __global__ void __launch_bounds__(kBinThreads)
-count_tiles_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
-                       int tiles, int tiles_x, uint32_t *__restrict__ block_hist) {
+count_tiles_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__restrict__ bin,
+                       const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x, uint32_t *__restrict__ block_hist) {
   extern __shared__ uint32_t s_hist[];
-  for (int t = threadIdx.x; t < tiles; t += kBinThreads) s_hist[t] = 0;
+  const int pass = blockIdx.x / nb, blk = blockIdx.x - pass * nb;
+  const int t_lo = pass * tpp, nt = min(tiles - t_lo, tpp);
+  for (int t = threadIdx.x; t < nt; t += kBinThreads) s_hist[t] = 0;
   __syncthreads();
-  const int lo = blockIdx.x * per_block, hi = min(N, lo + per_block);
+  const int lo = blk * per_block, hi = min(N, lo + per_block);
   for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
     const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
     const uint64_t mask = tile_mask[i];   // issued with the record, not after the visibility test
     const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
     if ((br.radius & kRadiusMask) == 0) continue;
-    for_each_tile(br.x0, br.y0, br.x1, br.y1, mask, tiles_x, [&](int t) { atomicAdd(&s_hist[t], 1u); });
+    for_each_tile(br.x0, br.y0, br.x1, br.y1, mask, tiles_x, [&](int t) {
+      const uint32_t r = (uint32_t)(t - t_lo);
+      if (r < (uint32_t)nt) atomicAdd(&s_hist[r], 1u);
+    });
   }
   __syncthreads();
-  uint32_t *row = block_hist + (size_t)blockIdx.x * tiles;
-  for (int t = threadIdx.x; t < tiles; t += kBinThreads) row[t] = s_hist[t];
+  uint32_t *row = block_hist + (size_t)blk * tiles + t_lo;
+  for (int t = threadIdx.x; t < nt; t += kBinThreads) row[t] = s_hist[t];
 }
 
 // 32 tiles x 32 segments of the block range per workgroup (235 workgroups at 7500 tiles — enough to cover every CU;
@@ -175,8 +182,8 @@ scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uin
 }
 
 __global__ void __launch_bounds__(kBinThreads)
-scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
-                         int tiles, int tiles_x,
+scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__restrict__ bin,
+                         const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x,
                          const uint32_t *__restrict__ block_hist, const uint32_t *__restrict__ tile_start,
                          uint64_t *__restrict__ keys, uint32_t capacity, StateHeader *__restrict__ header) {
   extern __shared__ uint32_t s_cur[];
@@ -184,10 +191,12 @@ scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, c
     header->capacity = capacity;
     if (header->num_pairs > capacity) header->overflow = 1;
   }
-  const uint32_t *row = block_hist + (size_t)blockIdx.x * tiles;
-  for (int t = threadIdx.x; t < tiles; t += kBinThreads) s_cur[t] = tile_start[t] + row[t];
+  const int pass = blockIdx.x / nb, blk = blockIdx.x - pass * nb;
+  const int t_lo = pass * tpp, nt = min(tiles - t_lo, tpp);
+  const uint32_t *row = block_hist + (size_t)blk * tiles + t_lo;
+  for (int t = threadIdx.x; t < nt; t += kBinThreads) s_cur[t] = tile_start[t_lo + t] + row[t];
   __syncthreads();
-  const int lo = blockIdx.x * per_block, hi = min(N, lo + per_block);
+  const int lo = blk * per_block, hi = min(N, lo + per_block);
   for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
     const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
     const uint64_t mask = tile_mask[i];
@@ -195,8 +204,11 @@ scatter_pairs_lds_kernel(int N, int per_block, const BinRec *__restrict__ bin, c
     if ((br.radius & kRadiusMask) == 0) continue;
     const uint64_t key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
     for_each_tile(br.x0, br.y0, br.x1, br.y1, mask, tiles_x, [&](int t) {
-      const uint32_t slot = atomicAdd(&s_cur[t], 1u);
-      if (slot < capacity) keys[slot] = key;
+      const uint32_t r = (uint32_t)(t - t_lo);
+      if (r < (uint32_t)nt) {
+        const uint32_t slot = atomicAdd(&s_cur[r], 1u);
+        if (slot < capacity) keys[slot] = key;
+      }
     });
   }
 }
@@ -636,9 +648,16 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
     uint32_t *block_hist = (uint32_t *)(base + L.block_hist);
     {
       ProfScope prof(kKCountTiles, stream);
-      count_tiles_lds_kernel<<<L.nb, kBinThreads, (size_t)L.tiles * 4, stream>>>(N, per_block, (const BinRec *)(base + L.bin),
-                                                                        (const uint64_t *)(base + L.tile_mask), L.tiles,
-                                                                        L.tiles_x, block_hist);
+      const int tpp = L.tiles_per_pass();
+      static bool lds_attr_set = false;   // histograms above 64 KiB need the kernels' dynamic-LDS limit raised (once)
+      if (!lds_attr_set) {
+        (void)hipFuncSetAttribute((const void *)count_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4);
+        (void)hipFuncSetAttribute((const void *)scatter_pairs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4);
+        lds_attr_set = true;
+      }
+      count_tiles_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
+          N, per_block, L.nb, tpp, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
+          block_hist);
       scan_block_hist_kernel<<<(L.tiles + kScanTiles - 1) / kScanTiles, kScanTiles * kScanSegs, 0, stream>>>(L.nb, L.tiles, block_hist, tile_count);
     }
     SCORP_KERNEL_CHECK("count_tiles", debug, stream);
@@ -662,8 +681,9 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
     ProfScope prof(kKScatterPairs, stream);
     if (L.lds_binning) {
       const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
-      scatter_pairs_lds_kernel<<<L.nb, kBinThreads, (size_t)L.tiles * 4, stream>>>(
-          N, per_block, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
+      const int tpp = L.tiles_per_pass();
+      scatter_pairs_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
+          N, per_block, L.nb, tpp, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
           (const uint32_t *)(base + L.block_hist), tile_start, keys, capacity, header);
     } else {
       scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(

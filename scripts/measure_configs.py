@@ -110,6 +110,28 @@ def main():
                       "hypotheses_per_s": round(nh / dt, 2), "renders_per_s": round(nh * 15 / dt, 1), "best_id": best,
                       "planted_id": 77 if nh > 77 else None}), flush=True)
 
+    # ---- config #3, the align loop's high-resolution renders (align_3dgs_clpe_9dof.py:157-169: cam.scale_resolution(1.5) up
+    # to three times, cameras.py:139-148): forward-only renders of the object at 1600x1200 x 1.5^k.  The binning's LDS
+    # histogram holds 36864 tiles per pass: 2400x1800 (16950 tiles) and 3600x2700 (38025, two passes) and 5400x4050
+    # (85852, three passes) all stay on the LDS path.
+    hi_cams = ring_cameras(4, 1600, 1200, 4, radius=3.0, device=dev)
+    for k in range(4):
+        w, h = hi_cams[0].resolution
+        with torch.no_grad():
+            for c in hi_cams:
+                render(c, obj, pipe, bg)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_r = 12
+            for i in range(n_r):
+                render(hi_cams[i % 4], obj, pipe, bg)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_r
+        print(json.dumps({"config": f"#3 align-loop render, S4 object (100k Gaussians, SH0) at {w}x{h} ({((w + 15) // 16) * ((h + 15) // 16)} tiles), forward only, exact pair sizing",
+                          "renders_per_s": round(1 / dt, 1), "ms_per_render": round(dt * 1e3, 3)}), flush=True)
+        for c in hi_cams:
+            c.scale_resolution(1.5)
+
     # ---- config #4: post-refinement iterations (colours only, masked loss), 4 objects merged ----
     raws = [make_gaussians(100_000, 0, 50 + k, extent=0.5, log_scale_mean=math.log(0.01)) for k in range(4)]
     for k, r in enumerate(raws):

@@ -122,7 +122,8 @@ CASES = {
     "tiny_splats": dict(N=20000, W=256, H=192, deg=3, seed=5, log_scale=math.log(0.006)),
     "huge_splats": dict(N=6000, W=64, H=64, deg=0, seed=6, log_scale=math.log(0.6)),  # >4096 per tile: global sort path
     "long_lists": dict(N=2500, W=64, H=64, deg=1, seed=11, log_scale=math.log(0.6)),     # 1024 < n <= 4096: second sort launch, in LDS
-    "many_tiles": dict(N=3000, W=2320, H=1800, deg=1, seed=10, log_scale=math.log(0.03)),  # 16385+ tiles: global-atomic binning fallback
+    "many_tiles": dict(N=3000, W=2320, H=1800, deg=1, seed=10, log_scale=math.log(0.03)),  # 16385 tiles: a 64 KiB+ LDS histogram
+    "two_pass_tiles": dict(N=2000, W=3104, H=3072, deg=0, seed=12, log_scale=math.log(0.03)),  # 37248 tiles > kMaxLdsTiles: binned in two tile-range passes
 }
 
 
@@ -223,7 +224,7 @@ def _raw_forward(kw, dev, capacity=None):
                 alpha=alpha, keep=(keep, ten), stream=stream, N=N, W=W, H=H)
 
 
-@pytest.mark.parametrize("name", ["sh3_bg_mod", "sh2_ragged", "inside_cloud", "huge_splats", "long_lists", "many_tiles"])
+@pytest.mark.parametrize("name", ["sh3_bg_mod", "sh2_ragged", "inside_cloud", "huge_splats", "long_lists", "many_tiles", "two_pass_tiles"])
 def test_stage_parity_geom_and_tile_lists(name, dev):
     """Projection records match the oracle to float rounding; tile rectangles, pair count, per-tile ranges and the
     depth-sorted splat lists match exactly (integer work: bit-exact)."""
