@@ -343,6 +343,20 @@ int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t num_tensors, double 
 int scorp_adam_step_guarded(const ScorpAdamTensor *tensors, int32_t num_tensors, double beta1, double beta2, double eps,
                             int32_t step, const uint32_t *skip_if_nonzero, scorp_stream_t stream);
 
+/* ---- densify / prune compaction (row f2 of the hot-path scope; gs3dgs/scene/gaussian_model.py:412-601) ----
+ * Re-indexes up to SCORP_ROWS_MAX_TENSORS row-major float tensors in one launch: dst row j = src row
+ * (src_index[j] & 0x7fffffff).  Bit 31 of an index marks a FRESH row (a cloned or split Gaussian): tensors with
+ * zero_if_fresh != 0 (the Adam moments) get zeros there instead of a copy.  src and dst must not overlap. */
+#define SCORP_ROWS_MAX_TENSORS 24
+typedef struct ScorpRowTensor {
+  const float *src;
+  float *dst;
+  uint32_t row_floats;
+  uint32_t zero_if_fresh;
+} ScorpRowTensor;
+int scorp_gather_rows(const ScorpRowTensor *tensors, int32_t num_tensors, const int32_t *src_index, uint64_t num_out_rows,
+                      scorp_stream_t stream);
+
 /* ---- in-library kernel timing: hipEvent pairs recorded on the launch stream around every kernel ---- */
 /* Off by default. scorp_prof_enable(1) clears the accumulators and starts recording; collect() synchronises the
  * recorded events and returns, per kernel id, the summed duration in ms and the number of launches. */

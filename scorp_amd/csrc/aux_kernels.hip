@@ -113,6 +113,48 @@ adam_kernel(AdamPack pk, float omb1, float beta2, float omb2, float eps, float b
 
 using namespace scorp;
 
+// ---- densify / prune compaction: every parameter tensor and both Adam moments of a model re-indexed in ONE launch ----
+namespace scorp {
+namespace {
+struct RowPack { ScorpRowTensor t[SCORP_ROWS_MAX_TENSORS]; int n; };
+// blockIdx.y = tensor; a thread moves one float: out row j <- row (src_index[j] & 0x7fffffff), zeros for a fresh row
+// (bit 31 of the index) of a tensor that asks for it (the Adam moments of cloned / split Gaussians start at zero,
+// gaussian_model.py:452-470 `densification_postfix`)
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(RowPack pk, const int32_t *__restrict__ src_index, uint64_t n_out) {
+  const ScorpRowTensor T = pk.t[blockIdx.y];
+  const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_out * T.row_floats) return;
+  const uint64_t j = e / T.row_floats;
+  const uint32_t c = (uint32_t)(e - j * T.row_floats);
+  const uint32_t s = (uint32_t)src_index[j];
+  const bool fresh = (s >> 31) != 0;
+  T.dst[e] = (fresh && T.zero_if_fresh) ? 0.0f : T.src[(uint64_t)(s & 0x7FFFFFFFu) * T.row_floats + c];
+}
+}  // namespace
+}  // namespace scorp
+
+extern "C" int scorp_gather_rows(const ScorpRowTensor *tensors, int32_t n, const int32_t *src_index, uint64_t num_out_rows,
+                                 scorp_stream_t stream_) {
+  if (n < 0 || n > SCORP_ROWS_MAX_TENSORS || (n > 0 && !tensors) || (num_out_rows > 0 && !src_index)) {
+    set_error("bad arguments to scorp_gather_rows (n=%d)", n); return SCORP_ERR_INVALID;
+  }
+  if (n == 0 || num_out_rows == 0) return SCORP_OK;
+  RowPack pk;
+  pk.n = n;
+  uint64_t most = 0;
+  for (int k = 0; k < n; k++) {
+    if (!tensors[k].src || !tensors[k].dst || tensors[k].row_floats == 0) { set_error("scorp_gather_rows: bad tensor %d", k); return SCORP_ERR_INVALID; }
+    pk.t[k] = tensors[k];
+    most = most > tensors[k].row_floats ? most : tensors[k].row_floats;
+  }
+  const uint64_t blocks = (num_out_rows * most + 255) / 256;
+  if (blocks > 0x7FFFFFFFull) { set_error("scorp_gather_rows: too many rows"); return SCORP_ERR_INVALID; }
+  gather_rows_kernel<<<dim3((unsigned)blocks, (unsigned)n), 256, 0, (hipStream_t)stream_>>>(pk, src_index, num_out_rows);
+  SCORP_KERNEL_CHECK("gather_rows", 0, (hipStream_t)stream_);
+  return SCORP_OK;
+}
+
 extern "C" int scorp_knn_dist2(const float *xyz, int32_t N, float *out, scorp_stream_t stream_) {
   if (N < 0 || (N > 0 && (!xyz || !out))) { set_error("bad arguments to scorp_knn_dist2"); return SCORP_ERR_INVALID; }
   if (N == 0) return SCORP_OK;

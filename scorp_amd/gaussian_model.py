@@ -353,15 +353,122 @@ class GaussianModel:
         sel = (padded >= grad_threshold) & (torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
         xyz, f_dc, f_rest, opac, _, rot = self._take(sel, N)
         stds = self.get_scaling[sel].repeat(N, 1)
-        samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
+        # surfels: the third axis has no extent - the reference draws it with std 0 (gs2dgs/scene/gaussian_model.py:446-449)
+        stds3 = stds if stds.shape[1] == 3 else torch.cat([stds, torch.zeros_like(stds[:, :1])], dim=-1)
+        samples = torch.normal(mean=torch.zeros_like(stds3), std=stds3)
         new_xyz = torch.bmm(build_rotation(rot), samples.unsqueeze(-1)).squeeze(-1) + xyz
         new_scaling = self.scaling_inverse_activation(stds / (0.8 * N))
         self.densification_postfix(new_xyz, f_dc, f_rest, opac, new_scaling, rot)
         self.prune_points(torch.cat((sel, torch.zeros(N * int(sel.sum()), device=self.device, dtype=torch.bool))))
 
+    # ---- the same surgery as ONE plan and ONE gather launch (GPU models) ----
+    def _gather(self, src_index, n_out):
+        """Re-index every parameter tensor and both Adam moments by `src_index` (int32[n_out]; bit 31 = fresh row whose
+        moments start at zero) with one launch of scorp_gather_rows, into the spare half of a growable ping-pong arena
+        (no allocation while the model fits its capacity; 1.5x growth when it does not), then swap."""
+        import ctypes
+        from . import _C
+        L = _C.lib()
+        arena = self.__dict__.setdefault("_arena", {})
+        jobs, swaps = [], []
+        for group in self.optimizer.param_groups:
+            old = group["params"][0]
+            state = self.optimizer.state.get(old)
+            for kind, src in (("p", old.detach()), ("m", None if not state else state.get("exp_avg")),
+                              ("v", None if not state else state.get("exp_avg_sq"))):
+                if src is None:
+                    continue
+                src = src.contiguous()
+                row = src[0].numel() if src.shape[0] else int(torch.tensor(src.shape[1:]).prod()) if src.dim() > 1 else 1
+                key = (group["name"], kind)
+                spare = arena.get(key)
+                if spare is None or spare.shape[0] < n_out or spare.data_ptr() == src.data_ptr():
+                    cap = max(int(1.5 * n_out) + 1024, 1)
+                    spare = torch.empty((cap,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+                dst = spare[:n_out]
+                jobs.append((src, dst, row, 0 if kind == "p" else 1))
+                swaps.append((group, kind, src, spare, dst, key))
+        arr = (_C.ScorpRowTensor * len(jobs))()
+        for k, (src, dst, row, z) in enumerate(jobs):
+            arr[k].src, arr[k].dst, arr[k].row_floats, arr[k].zero_if_fresh = src.data_ptr(), dst.data_ptr(), row, z
+        if n_out > 0:
+            _C.check(L.scorp_gather_rows(arr, len(jobs), ctypes.c_void_p(src_index.data_ptr()), n_out,
+                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "scorp_gather_rows")
+        for group in self.optimizer.param_groups:
+            old = group["params"][0]
+            state = self.optimizer.state.pop(old, None)
+            mine = {kind: (src, spare, dst, key) for g, kind, src, spare, dst, key in swaps if g is group}
+            src, spare, dst, key = mine["p"]
+            new = nn.Parameter(dst.requires_grad_(old.requires_grad))
+            arena[key] = src._base if src._base is not None else src          # the old storage becomes the spare half
+            if state is not None:
+                for kind, field in (("m", "exp_avg"), ("v", "exp_avg_sq")):
+                    if kind in mine:
+                        s_, _, d_, k_ = mine[kind]
+                        state[field] = d_
+                        arena[k_] = s_._base if s_._base is not None else s_
+                self.optimizer.state[new] = state
+            group["params"][0] = new
+            setattr(self, _ATTR[group["name"]], new)
+
+    @torch.no_grad()
+    def _densify_and_prune_fused(self, grads, max_grad, min_opacity, extent, max_screen_size, N=2):
+        """densify_and_clone + densify_and_split + prune_points (gaussian_model.py:528-584) as one row plan: the rows the
+        three sequential steps would leave, in the order they would leave them - originals that are neither split nor
+        pruned, then the clones, then the two copies of every split Gaussian - gathered by ONE launch for all parameters
+        and Adam moments (fresh rows get zero moments).  Same selections, same random draw (one torch.normal of the same
+        shape), same result as the sequential form; tests/test_aux_gpu.py compares them element for element."""
+        dev = self.device
+        n0 = self.get_xyz.shape[0]
+        scal = self.get_scaling
+        max_s = scal.max(dim=1).values
+        gn = torch.norm(grads, dim=-1)
+        sel_clone = (gn >= max_grad) & (max_s <= self.percent_dense * extent)
+        sel_split = (grads.squeeze(-1) >= max_grad) & (max_s > self.percent_dense * extent)
+        idx = torch.arange(n0, device=dev, dtype=torch.int32)
+        i_clone, i_split = idx[sel_clone], idx[sel_split]
+        ns = int(i_split.numel())
+        # the split's new positions and scales: the reference's draw, on the 2 ns repeated rows
+        stds = scal[sel_split].repeat(N, 1)
+        # surfels: the third axis has no extent - the reference draws it with std 0 (gs2dgs/scene/gaussian_model.py:446-449)
+        stds3 = stds if stds.shape[1] == 3 else torch.cat([stds, torch.zeros_like(stds[:, :1])], dim=-1)
+        samples3 = torch.normal(mean=torch.zeros_like(stds3), std=stds3)
+        rot_s = self._rotation[sel_split].repeat(N, 1)
+        new_xyz = torch.bmm(build_rotation(rot_s), samples3.unsqueeze(-1)).squeeze(-1) + self._xyz[sel_split].repeat(N, 1)
+        new_scaling = self.scaling_inverse_activation(stds / (0.8 * N))
+        # candidates in the order of the sequential result, with what the final prune test looks at
+        FRESH = -(1 << 31)
+        cand = torch.cat([idx[~sel_split], i_clone | FRESH, i_split.repeat(N) | FRESH])
+        src = cand & 0x7FFFFFFF
+        opac = self.get_opacity.squeeze(-1)[src.long()]
+        smax = max_s[src.long()]
+        n_keep_orig_clone = cand.numel() - N * ns
+        if ns:
+            smax = torch.cat([smax[:n_keep_orig_clone], torch.exp(new_scaling).max(dim=1).values])
+        prune = opac < min_opacity
+        if max_screen_size:
+            # (max_radii2D was just reset to zeros by the densification: the screen-size test cannot fire, as in the
+            # reference, where densification_postfix zeroes it before the prune looks at it)
+            prune = prune | (smax > 0.1 * extent)
+        keep = ~prune
+        final = cand[keep].contiguous()
+        n_out = int(final.numel())
+        self._gather(final, n_out)
+        if ns:   # the kept split rows take their sampled position and shrunken scale
+            kept_split = keep[n_keep_orig_clone:]
+            pos = torch.nonzero(keep, as_tuple=False).squeeze(-1)   # candidate index of every output row
+            out_rows = torch.nonzero(pos >= n_keep_orig_clone, as_tuple=False).squeeze(-1)
+            self._xyz.data[out_rows] = new_xyz[kept_split]
+            self._scaling.data[out_rows] = new_scaling[kept_split]
+        self.xyz_gradient_accum = torch.zeros((n_out, 1), device=dev)
+        self.denom = torch.zeros((n_out, 1), device=dev)
+        self.max_radii2D = torch.zeros(n_out, device=dev)
+
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
+        if self._xyz.is_cuda and self.optimizer is not None and getattr(self, "fused_densify", True):
+            return self._densify_and_prune_fused(grads, max_grad, min_opacity, extent, max_screen_size)
         self.densify_and_clone(grads, max_grad, extent)
         self.densify_and_split(grads, max_grad, extent)
         prune = (self.get_opacity < min_opacity).squeeze()

@@ -210,3 +210,48 @@ def test_render_tail_matches_torch(dev):
     ok = ~empty
     assert torch.allclose(d1.grad[ok], d0.grad[ok], rtol=1e-6, atol=0) and torch.allclose(a1.grad[ok], a0.grad[ok], rtol=1e-6, atol=0)
     assert bool((d1.grad[empty] == 0).all()) and bool((a1.grad[empty] == 0).all())   # torch leaves NaN there
+
+
+@pytest.mark.parametrize("surfels", [False, True])
+def test_fused_densify_and_prune_equals_the_sequential_surgery(dev, surfels):
+    """One row plan + ONE scorp_gather_rows launch (parameters and both Adam moments, ping-pong arena) against
+    densify_and_clone -> densify_and_split -> prune_points done with torch.cat / indexing (the reference's sequence,
+    gaussian_model.py:528-584): same row order, same values bit for bit (same random draw), zero moments on the new
+    rows, statistics reset; twice in a row, so the second pass runs inside the arena's spare half."""
+    import math
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.renderer2d import GaussianModel2D
+    from scorp_amd.synthetic import make_gaussians
+    cls = GaussianModel2D if surfels else GaussianModel
+    raw = make_gaussians(5000, 2, 41, log_scale_mean=math.log(0.05), scale_dims=2 if surfels else 3)
+    models = []
+    for fused in (False, True):
+        m = cls.from_raw(raw, 2, device=dev)
+        m.training_setup(OptimizationParams())
+        m.fused_densify = fused
+        models.append(m)
+    g = torch.Generator(device=dev).manual_seed(3)
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    for rnd in range(2):
+        n = models[0].get_xyz.shape[0]
+        grads_acc = torch.rand(n, 1, device=dev, generator=g) * 4e-4
+        denom = torch.randint(0, 3, (n, 1), device=dev, generator=g).float()          # zeros -> NaN -> 0, as in training
+        fake_grads = [torch.randn(getattr(models[0], nm).shape, device=dev, generator=g) for nm in names]
+        for m in models:
+            for nm, fg in zip(names, fake_grads):   # two optimizer steps: non-trivial Adam moments on every row
+                getattr(m, nm).grad = fg.clone()
+            m.optimizer.step()
+            m.optimizer.zero_grad(set_to_none=True)
+            m.xyz_gradient_accum, m.denom = grads_acc.clone(), denom.clone()
+            m.max_radii2D = torch.zeros(n, device=dev)
+            torch.manual_seed(77 + rnd)
+            m.densify_and_prune(2e-4, 0.3, 2.0, 20)
+        a, b = models
+        assert a.get_xyz.shape[0] == b.get_xyz.shape[0] != n
+        for nm in names:
+            pa, pb = getattr(a, nm), getattr(b, nm)
+            assert torch.equal(pa.detach(), pb.detach()), nm
+            sa, sb = a.optimizer.state[pa], b.optimizer.state[pb]
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), nm
+            assert pb.requires_grad and pb.is_contiguous()
+        assert float(b.denom.sum()) == 0.0 and b.max_radii2D.shape[0] == b.get_xyz.shape[0]
