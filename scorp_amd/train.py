@@ -24,7 +24,7 @@ import torch.distributed as dist
 from .fused_loss import fused_l1_ssim_loss
 from .rasterizer3d import PairPolicy
 from .loss import depth_losses, isotropic_loss, psnr
-from .parallel import average_gradients, world
+from .parallel import average_gradients, average_gradients_sparse, world
 from .renderer import render
 
 
@@ -48,7 +48,7 @@ def _sync_densification_stats(gaussians):
 
 def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteration, scene_extent=4.0, densify=True,
                        render_fn=render, loss_fn=fused_l1_ssim_loss, data_parallel=False, gt_depth=None, gt_depth_est=None,
-                       surfels=False, fused_view=False, white_background=False):
+                       surfels=False, fused_view=False, white_background=False, sparse_gradients=False):
     """Returns (loss tensor, render package). Mirrors train_3dgs.py:74-193 for one camera.  With `data_parallel` the
     caller hands each rank a different camera; gradients are averaged over ranks before the optimizer step and the
     densification statistics are reduced before they are used, so the replicas stay bit-identical."""
@@ -102,7 +102,11 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
         loss.backward()
     with torch.no_grad():
         if data_parallel:
-            average_gradients([g["params"][0] for g in gaussians.optimizer.param_groups])
+            ps = [g["params"][0] for g in gaussians.optimizer.param_groups]
+            if sparse_gradients:   # only the rows some rank rendered travel (parallel.average_gradients_sparse)
+                average_gradients_sparse(ps, pkg["visibility_filter"])
+            else:
+                average_gradients(ps)
         if densify and iteration < opt.densify_until_iter:
             vis, radii = pkg["visibility_filter"], pkg["radii"]
             gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis].float())

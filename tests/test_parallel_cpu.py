@@ -311,3 +311,52 @@ def test_sh_rotation_blocks_match_the_independent_wigner_table():
         for l, name in ((1, "D1"), (2, "D2"), (3, "D3")):
             assert np.abs(blocks[l - 1].double().numpy() - g[name][k]).max() < 2e-6, (k, l)
         assert np.abs(g["D1"][k] - S @ (P @ R @ P.T) @ S).max() < 1e-12
+
+
+# ---- visibility-sparse gradient averaging against the dense bucketed all-reduce, two gloo ranks ----
+def _sparse_worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from scorp_amd.parallel import average_gradients, average_gradients_sparse
+        g = torch.Generator().manual_seed(11)
+        N = 97
+        shapes = [(N, 3), (N, 1, 3), (N, 15, 3), (N, 1), (N, 3), (N, 4)]
+        base = [torch.randn(s, generator=g) for s in shapes]
+        # rank-dependent visibility: some rows seen by both ranks, some by one, some by none
+        vis = ((torch.arange(N) % 4) == rank) | ((torch.arange(N) % 4) == 2)
+        out = []
+        for sparse in (False, True):
+            params = [torch.nn.Parameter(b.clone()) for b in base]
+            loss = sum(((p * (rank + 1.5)) ** 2).reshape(N, -1).sum(1) for p in params)   # per-Gaussian terms
+            (loss * vis.float()).sum().backward()                                        # invisible rows: zero gradient
+            if sparse:
+                moved = average_gradients_sparse(params, vis)
+                assert moved == int((((torch.arange(N) % 4) <= 2)).sum())
+            else:
+                average_gradients(params, bucket_bytes=1 << 10)
+            out.append([p.grad.clone() for p in params])
+        ok = all(torch.allclose(a, b, rtol=0, atol=1e-6) for a, b in zip(*out))
+        never = (torch.arange(N) % 4) == 3
+        zero = all(float(gr.reshape(N, -1)[never].abs().max()) == 0.0 for gr in out[1])
+        q.put((rank, "ok" if ok and zero else "mismatch"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sparse_gradient_average_equals_dense_on_two_gloo_ranks():
+    """parallel.average_gradients_sparse (union of the ranks' visibility masks, only those rows travel) gives the same
+    averaged gradients as the dense bucketed all-reduce; rows no rank rendered stay exactly zero."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
