@@ -9,8 +9,6 @@ out=gpurun_out/$tag
 mkdir -p $out
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-python3 bench.py > $out/bench_S3.json 2> $out/bench_S3.err
-python3 bench.py --scene S6 --steps 50 --warmup 10 > $out/bench_S6.json 2> $out/bench_S6.err
 for sc in S3 S6; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$sc -- python3 bench.py --scene $sc --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $out/stats_$sc.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -23,6 +21,9 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VA
 f() { find $out/$1 -name '*counter_collection.csv' | head -1; }
 python3 scripts/make_traffic.py S3 "$(f pmc_S3_FETCH_SIZE)" "$(f pmc_S3_WRITE_SIZE)" S6 "$(f pmc_S6_FETCH_SIZE)" "$(f pmc_S6_WRITE_SIZE)" > $out/traffic_summary.json
 cp profiles/traffic.json $out/traffic.json
+# the bench lines last: roofline.traffic comes from the profiles/traffic.json just written (same kernel-source hash)
+python3 bench.py > $out/bench_S3.json 2> $out/bench_S3.err
+python3 bench.py --scene S6 --steps 50 --warmup 10 > $out/bench_S6.json 2> $out/bench_S6.err
 python3 scripts/pmc_summary.py $(f sq1) $(f sq2) > $out/pmc_sq.json
 for sc in S3 S6; do cp "$(find $out/stats_$sc -name '*kernel_stats.csv' | head -1)" $out/kernel_stats_$sc.csv; done
 echo done > $out/DONE
