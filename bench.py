@@ -394,6 +394,34 @@ def main():
     PairPolicy.drain()
     torch.cuda.synchronize()
     fwd_only = nf / (time.perf_counter() - tf0)
+    # extra (not part of `value`): the same step with TWO views in flight on two HIP streams - the batch-of-views form of
+    # training (data-parallel ranks sharing a GPU, multi-view evaluation): the second view's kernels fill the SIMDs that
+    # the first one's latency-bound kernels (binning, loss) and kernel tails leave idle
+    in_flight2 = None
+    if fused_view and side_streams is None and not args.no_secondary:
+        pair = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for st_ in pair:
+            st_.wait_stream(torch.cuda.current_stream())
+
+        def step2(i):
+            with torch.cuda.stream(pair[i & 1]):
+                train_view(my_cams[i % len(my_cams)], model, pipe, bg, gts[i % len(my_cams)], 0.2)
+                for p in params:
+                    p.grad = None
+        for i in range(8):
+            step2(i)
+        PairPolicy.drain()
+        torch.cuda.synchronize()
+        t20 = time.perf_counter()
+        for i in range(args.steps):
+            step2(i)
+        PairPolicy.drain()
+        torch.cuda.synchronize()
+        in_flight2 = args.steps / (time.perf_counter() - t20)
+        if world > 1:
+            t2 = torch.tensor([in_flight2], device=cdev, dtype=torch.float64)
+            dist.all_reduce(t2, op=dist.ReduceOp.SUM)
+            in_flight2 = float(t2.item())
     PairPolicy.mode = "exact"
     # work statistics of view 0 (SURVEY §8d asks for an honest pixel-splat figure next to HBM): (8x8 block, splat)
     # iterations of the two blend kernels, each of which evaluates 64 pixel-splat pairs
@@ -508,6 +536,7 @@ def main():
                          "frac_of_8TBs": round(value / world * B_view / 8e12, 5)},
             "kernels": kernels,
             "forward_only_views_per_s_per_gpu": round(fwd_only, 1),
+            "views_per_s_two_in_flight": None if in_flight2 is None else round(in_flight2, 1),
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"], orc = cpu_baseline(raw, my_cams[0].to("cpu"), deg, W, H)
