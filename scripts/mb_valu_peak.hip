@@ -47,6 +47,27 @@ __global__ void __launch_bounds__(256) k_mix(float *out, unsigned long long *cyc
       asm volatile("v_cmp_le_f32 vcc, %8, %0\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_le_f32 vcc, %8, %2\n v_cndmask_b32 %3, %3, %9, vcc\n"
                    "v_cmp_le_f32 vcc, %8, %4\n v_cndmask_b32 %5, %5, %9, vcc\n v_cmp_le_f32 vcc, %8, %6\n v_cndmask_b32 %7, %7, %9, vcc\n"
                    : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");
+    } else if constexpr (MIX == 8) { // v_permlane32_swap (the 2DGS backward's first fold level)
+      asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                   "v_permlane32_swap_b32 %1, %2\n v_permlane32_swap_b32 %3, %4\n v_permlane32_swap_b32 %5, %6\n v_permlane32_swap_b32 %7, %0\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+    } else if constexpr (MIX == 9) { // v_permlane16_swap
+      asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                   "v_permlane16_swap_b32 %1, %2\n v_permlane16_swap_b32 %3, %4\n v_permlane16_swap_b32 %5, %6\n v_permlane16_swap_b32 %7, %0\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+    } else if constexpr (MIX == 10) { // v_add_f32 with a DPP source (row_ror:8), 8 independent chains
+      asm volatile("s_nop 1\n v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                   "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                   "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                   "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+    } else if constexpr (MIX == 11) { // ds_bpermute_b32 (LDS crossbar) + the add that consumes it
+      float t0_, t1_, t2_, t3_;
+      const int addr = ((threadIdx.x ^ 32) & 63) << 2;
+      asm volatile("ds_bpermute_b32 %8, %12, %0\n ds_bpermute_b32 %9, %12, %1\n ds_bpermute_b32 %10, %12, %2\n ds_bpermute_b32 %11, %12, %3\n"
+                   "s_waitcnt lgkmcnt(0)\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %9\n v_add_f32 %6, %6, %10\n v_add_f32 %7, %7, %11\n"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_)
+                   : "v"(addr));
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -156,6 +177,10 @@ int main() {
   run_mix<4>("exp2", d, c);
   run_mix<6>("7fma+exp", d, c);
   run_mix<7>("cmp+cnd", d, c);
+  run_mix<8>("perml32sw", d, c);
+  run_mix<9>("perml16sw", d, c);
+  run_mix<10>("add_dpp", d, c);
+  run_mix<11>("bperm+add", d, c);   // 8 instructions per iteration: 4 ds_bpermute + 4 v_add
   run_blend<8>(d, c);
   run_blend<16>(d, c);
   return 0;
