@@ -196,6 +196,14 @@ int scorp_gs3d_render_tail(const float *depth, const float *alpha, int64_t num_p
 int scorp_gs3d_render_tail_backward(const float *g_out_depth, const float *depth, const float *alpha, int64_t num_pixels,
                                     float *g_depth, float *g_alpha, scorp_stream_t stream);
 
+/* ---- scoring one pose hypothesis against a target view (the render-and-compare form of the rotation sweep,
+ * align_3dgs_clpe_9dof.py:80-111 / :336-368), straight from the rasterizer's raw outputs, one launch:
+ * acc[0] += scale * sum over the pixels of |alpha - tgt_alpha| + |nan_to_num(depth / alpha, 0, 0) - tgt_depth|
+ * (tgt_depth is a NORMALISED depth as scorp_gs3d_render_tail writes it).  One float atomic per workgroup: the order of
+ * the partial sums is not fixed. */
+int scorp_gs3d_pose_score_accumulate(const float *depth, const float *alpha, const float *tgt_depth, const float *tgt_alpha,
+                                     int64_t num_pixels, float scale, float *acc, scorp_stream_t stream);
+
 /* ---- per-pixel tail of the 2DGS render(): gs2dgs/gaussian_renderer/__init__.py:131-160 over
  * gs2dgs/utils/point_utils.py:9-40 (depths_to_points, depth_to_normal) ----
  * allmap[7,H,W] -> render_alpha[1,H,W], render_normal[3,H,W] (rotated to world space by viewmatrix[:3,:3]),

@@ -70,6 +70,7 @@ EXPORTS = [
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_backward_ex", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles", "scorp_gs3d_debug_work",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
     "scorp_knn_dist2", "scorp_adam_step", "scorp_adam_step_guarded", "scorp_gather_rows", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
+    "scorp_gs3d_pose_score_accumulate",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
     "scorp_gs2d_render_image",
     "scorp_gs2d_backward", "scorp_gs2d_debug_geom", "scorp_gs2d_debug_tiles", "scorp_gs2d_maps_forward",
@@ -123,6 +124,7 @@ def lib():
     L.scorp_loss_l1_ssim_backward.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, vp, vp]
     L.scorp_gs3d_render_tail.argtypes = [vp, vp, ctypes.c_int64, vp, i32, vp, vp, vp]
     L.scorp_gs3d_render_tail_backward.argtypes = [vp, vp, vp, ctypes.c_int64, vp, vp, vp]
+    L.scorp_gs3d_pose_score_accumulate.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, vp, vp]
     L.scorp_gs2d_state_bytes.restype = sz
     L.scorp_gs2d_state_bytes.argtypes = [i32, i32, i32]
     L.scorp_gs2d_backward_scratch_bytes.restype = sz

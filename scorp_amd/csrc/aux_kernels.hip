@@ -231,8 +231,42 @@ render_tail_backward_kernel(const float *__restrict__ g_out, const float *__rest
   g_depth[i] = pass ? g / a : 0.0f;
   g_alpha[i] = pass ? -g * d / (a * a) : 0.0f;
 }
+// One pose hypothesis' disagreement with a target view, from the rasterizer's raw outputs: sum over the pixels of
+// |alpha - alpha*| + |nan_to_num(depth / alpha) - depth*| (the normalisation of render_tail_kernel, not stored), scaled
+// and added to one device float: a grid-stride pass, wave and workgroup sums, one float atomic per workgroup.
+__global__ void __launch_bounds__(256)
+pose_score_kernel(const float *__restrict__ depth, const float *__restrict__ alpha, const float *__restrict__ tgt_depth,
+                  const float *__restrict__ tgt_alpha, size_t HW, float scale, float *__restrict__ acc) {
+  __shared__ float s_part[4];
+  float sum = 0.0f;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += stride) {
+    const float a = alpha[i];
+    sum += fabsf(a - tgt_alpha[i]) + fabsf(nan_to_num00(depth[i] / a) - tgt_depth[i]);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, scale * (s_part[0] + s_part[1] + s_part[2] + s_part[3]));
+}
 }  // namespace
 }  // namespace scorp
+
+extern "C" int scorp_gs3d_pose_score_accumulate(const float *depth, const float *alpha, const float *tgt_depth,
+                                                const float *tgt_alpha, int64_t HW, float scale, float *acc,
+                                                scorp_stream_t stream_) {
+  if (HW < 0 || !acc || (HW > 0 && (!depth || !alpha || !tgt_depth || !tgt_alpha))) {
+    set_error("bad argument to scorp_gs3d_pose_score_accumulate"); return SCORP_ERR_INVALID;
+  }
+  if (HW == 0) return SCORP_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t want = ((size_t)HW + 1023) / 1024;   // ~4 pixels per thread
+  pose_score_kernel<<<(unsigned)(want < 1024 ? want : 1024), 256, 0, stream>>>(depth, alpha, tgt_depth, tgt_alpha, (size_t)HW,
+                                                                               scale, acc);
+  SCORP_KERNEL_CHECK("pose_score", 0, stream);
+  return SCORP_OK;
+}
 
 extern "C" int scorp_gs3d_render_tail(const float *depth, const float *alpha, int64_t HW, const int32_t *radii, int32_t N,
                                       float *out_depth, uint8_t *out_visible, scorp_stream_t stream_) {

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
+from . import rasterizer3d as R3
 from .rasterizer3d import (GaussianRasterizationSettings, LAST_NUM_PAIRS_LOG, PairPolicy, _inputs_struct, _prep, _ptr,
                            _stream)
 
@@ -36,7 +37,7 @@ def _forward2d(ctx, settings, means3D, sh, sh_rest, colors_precomp, opacities, s
     else:
         capacity = PairPolicy.capacity(N, H, W)
     pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
-    fn = L.scorp_gs2d_render if any(ctx.needs_input_grad) else L.scorp_gs2d_render_image   # nothing to differentiate
+    fn = L.scorp_gs2d_render if R3.want_backward(ctx) else L.scorp_gs2d_render_image   # nothing to differentiate
     _C.check(fn(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(allmap), stream), "scorp_gs2d_render")
     if PairPolicy.mode != "exact":
         PairPolicy.pend(state, N, H, W)   # the StateHeader only (see rasterizer3d.PairPolicy.pend)
@@ -138,6 +139,7 @@ class _RasterizeSurfelsRaw(torch.autograd.Function):
 
 
 def rasterize_surfels_raw(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings):
+    R3._tls.grad_mode = torch.is_grad_enabled()
     return _RasterizeSurfelsRaw.apply(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings)
 
 
@@ -158,6 +160,7 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        R3._tls.grad_mode = torch.is_grad_enabled()
         return _RasterizeSurfels.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                        self.raster_settings)
 

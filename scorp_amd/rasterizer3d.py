@@ -268,7 +268,7 @@ def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opaciti
     pairs = torch.empty(L.scorp_gs3d_pairs_bytes(capacity), dtype=torch.uint8, device=dev)
     # nothing to differentiate (the calls the reference makes under torch.no_grad()): the image-only render, which
     # leaves no state for a backward pass
-    fn = L.scorp_gs3d_render if any(ctx.needs_input_grad) else L.scorp_gs3d_render_image
+    fn = L.scorp_gs3d_render if want_backward(ctx) else L.scorp_gs3d_render_image
     _C.check(fn(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(color), _ptr(depth), _ptr(alpha), stream),
              "scorp_gs3d_render")
     if PairPolicy.mode != "exact":
@@ -332,11 +332,20 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         return (g_means3D, g_means2D, g_dc if need[2] else None, g_rest if need[3] else None, g_op, g_sc, g_rot, None)
 
 
+def want_backward(ctx):
+    """True if a backward pass can follow this forward.  `ctx.needs_input_grad` alone says yes for every leaf parameter
+    even under torch.no_grad() (it ignores the grad mode, and inside Function.forward the mode is always off), so the
+    wrappers below note the caller's grad mode before `apply`."""
+    return bool(getattr(_tls, "grad_mode", True)) and any(ctx.needs_input_grad)
+
+
 def rasterize_gaussians_raw(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings):
+    _tls.grad_mode = torch.is_grad_enabled()
     return _RasterizeGaussiansRaw.apply(means3D, means2D, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    _tls.grad_mode = torch.is_grad_enabled()
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings)
 

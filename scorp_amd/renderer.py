@@ -53,6 +53,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw = pc.raw_leaves()
         rendered_image, radii, rendered_depth, rendered_alpha = rasterize_gaussians_raw(
             xyz, screenspace_points, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw, raster_settings)
+        if getattr(pipe, "raw_outputs", False):   # scorp_amd.align scores poses from the un-normalised depth (one launch less per view)
+            return {"render": rendered_image, "radii": radii, "render_depth_raw": rendered_depth, "render_alpha": rendered_alpha}
         rendered_depth, visible = render_tail(rendered_depth, rendered_alpha, radii)   # D / A with NaN -> 0, radii > 0
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": visible,
                 "radii": radii, "render_depth": rendered_depth, "render_alpha": rendered_alpha}

@@ -182,6 +182,15 @@ def test_rotation_sweep_recovers_the_planted_rotation(dev):
     ids_e, fit_e, best_e = rotation_sweep(m, rots, cams, targets, bg, use_graph=False)   # eager launches
     assert best_e == planted and torch.equal(ids, ids_e)
     assert (fit - fit_e).abs().max() < 1e-6
+    # the one-launch score (scorp_gs3d_pose_score_accumulate on the raw depth / alpha) against the torch formulation
+    # on render()'s normalised outputs
+    from scorp_amd.align import hypothesis_fitness
+    from scorp_amd.renderer import render
+    for j in (0, planted, 127):
+        Rj = torch.tensor(rots[j], dtype=torch.float32, device=dev)
+        fused = float(hypothesis_fitness(m, Rj, cams, targets, bg))
+        plain = float(hypothesis_fitness(m, Rj, cams, targets, bg, render_fn=lambda *a: render(*a)))
+        assert abs(fused - plain) <= 1e-5 * max(1.0, abs(plain)), (j, fused, plain)
     # the model itself is untouched by the sweep
     assert torch.equal(tgt_model._features_dc, m._features_dc)
 
