@@ -236,13 +236,21 @@ render_tail_backward_kernel(const float *__restrict__ g_out, const float *__rest
 // and added to one device float: a grid-stride pass, wave and workgroup sums, one float atomic per workgroup.
 __global__ void __launch_bounds__(256)
 pose_score_kernel(const float *__restrict__ depth, const float *__restrict__ alpha, const float *__restrict__ tgt_depth,
-                  const float *__restrict__ tgt_alpha, size_t HW, float scale, float *__restrict__ acc) {
+                  const float *__restrict__ tgt_alpha, size_t HW, float scale, float *__restrict__ acc, bool vec4) {
   __shared__ float s_part[4];
   float sum = 0.0f;
   const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += stride) {
-    const float a = alpha[i];
-    sum += fabsf(a - tgt_alpha[i]) + fabsf(nan_to_num00(depth[i] / a) - tgt_depth[i]);
+  auto term = [](float d, float a, float td, float ta) { return fabsf(a - ta) + fabsf(nan_to_num00(d / a) - td); };
+  if (vec4) {   // all four maps 16-byte aligned: one 16-byte load per map and thread, all in flight together
+    const size_t Q = HW / 4;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < Q; q += stride) {
+      const float4 d = reinterpret_cast<const float4 *>(depth)[q], a = reinterpret_cast<const float4 *>(alpha)[q];
+      const float4 td = reinterpret_cast<const float4 *>(tgt_depth)[q], ta = reinterpret_cast<const float4 *>(tgt_alpha)[q];
+      sum += (term(d.x, a.x, td.x, ta.x) + term(d.y, a.y, td.y, ta.y)) + (term(d.z, a.z, td.z, ta.z) + term(d.w, a.w, td.w, ta.w));
+    }
+    for (size_t i = 4 * Q + (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += stride) sum += term(depth[i], alpha[i], tgt_depth[i], tgt_alpha[i]);
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += stride) sum += term(depth[i], alpha[i], tgt_depth[i], tgt_alpha[i]);
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
@@ -261,9 +269,10 @@ extern "C" int scorp_gs3d_pose_score_accumulate(const float *depth, const float 
   }
   if (HW == 0) return SCORP_OK;
   hipStream_t stream = (hipStream_t)stream_;
-  const size_t want = ((size_t)HW + 1023) / 1024;   // ~4 pixels per thread
-  pose_score_kernel<<<(unsigned)(want < 1024 ? want : 1024), 256, 0, stream>>>(depth, alpha, tgt_depth, tgt_alpha, (size_t)HW,
-                                                                               scale, acc);
+  const size_t want = ((size_t)HW + 1023) / 1024;   // 4 pixels per thread
+  const bool vec4 = (((uintptr_t)depth | (uintptr_t)alpha | (uintptr_t)tgt_depth | (uintptr_t)tgt_alpha) & 15) == 0;
+  pose_score_kernel<<<(unsigned)(want < 2048 ? want : 2048), 256, 0, stream>>>(depth, alpha, tgt_depth, tgt_alpha, (size_t)HW,
+                                                                               scale, acc, vec4);
   SCORP_KERNEL_CHECK("pose_score", 0, stream);
   return SCORP_OK;
 }

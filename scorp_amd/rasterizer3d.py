@@ -81,9 +81,13 @@ class PairPolicy:
     @classmethod
     def pend(cls, state, N, H, W):
         """Queue a forward for drain(): copies the header on the current stream and records an event behind the copy."""
-        hdr = state[:64].clone()     # not the state itself, or every pending view would pin ~100 MB until the drain
         ev = None
-        if not torch.cuda.is_current_stream_capturing():   # (a captured replay is checked by its capturer: align._sweep_graph)
+        if torch.cuda.is_current_stream_capturing():
+            # a captured replay is checked by its capturer (align.SweepPlan), which reads the live headers at the end of
+            # the graph: a view of the state (kept alive by the graph's pool anyway) instead of a copy node per view
+            hdr = state[:64]
+        else:
+            hdr = state[:64].clone()     # not the state itself, or every pending view would pin ~100 MB until the drain
             ev = torch.cuda.Event()
             ev.record()
         cls._pending.append(_Pending(hdr, ev, cls.key(N, H, W)))
