@@ -160,6 +160,9 @@ struct StateLayout {
   bool lds_binning;
   int bin_passes() const { return (tiles + kMaxLdsTiles - 1) / kMaxLdsTiles; }
   int tiles_per_pass() const { return tiles < kMaxLdsTiles ? tiles : kMaxLdsTiles; }
+  // up to 8192 tiles (one pass, 8 counts per thread) every scatter workgroup scans the tile totals itself while it sets
+  // up its LDS cursors, and the one-workgroup scan launch between the count and the scatter is dropped
+  bool scan_in_scatter() const { return lds_binning && tiles <= 8192; }
   StateLayout(int N, int W, int H, bool mode2d = false) {
     tiles_x = (W + kTile - 1) / kTile;
     tiles_y = (H + kTile - 1) / kTile;

@@ -121,8 +121,10 @@ constexpr int kBinThreads = 1024;   // few Gaussians per thread: the count / sca
 // [pass * tpp, (pass + 1) * tpp) of bin block `block` (blockIdx.x = pass * nb + block).
 __global__ void __launch_bounds__(kBinThreads)
 count_tiles_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__restrict__ bin,
-                       const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x, uint32_t *__restrict__ block_hist) {
+                       const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x, uint32_t *__restrict__ block_hist,
+                       StateHeader *__restrict__ header) {
   extern __shared__ uint32_t s_hist[];
+  if (header && blockIdx.x == 0 && threadIdx.x == 0) { header->num_pairs = 0; header->overflow = 0; }   // scan_block_hist adds the totals up
   const int pass = blockIdx.x / nb, blk = blockIdx.x - pass * nb;
   const int t_lo = pass * tpp, nt = min(tiles - t_lo, tpp);
   for (int t = threadIdx.x; t < nt; t += kBinThreads) s_hist[t] = 0;
@@ -148,7 +150,8 @@ count_tiles_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__re
 // rows), the segment totals are exchanged through LDS, then the prefixes are written in place.
 constexpr int kScanTiles = 32, kScanSegs = 32;
 __global__ void __launch_bounds__(kScanTiles * kScanSegs)
-scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uint32_t *__restrict__ tile_count) {
+scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uint32_t *__restrict__ tile_count,
+                       StateHeader *__restrict__ header) {
   __shared__ uint32_t s_seg[kScanSegs][kScanTiles];
   const int tl = threadIdx.x % kScanTiles, seg = threadIdx.x / kScanTiles;
   const int t = blockIdx.x * kScanTiles + tl;
@@ -179,13 +182,21 @@ scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uin
     }
     if (seg == kScanSegs - 1) tile_count[t] = run;
   }
+  if (header && seg == kScanSegs - 1) {   // D = the sum of the tile totals: this workgroup's 32 (lanes 32..63 of its last wave)
+    static_assert(kScanTiles == 32, "the last segment is the upper half of a wave");
+    uint32_t tot = t < tiles ? run : 0u;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off, 64);
+    if (tl == 0 && tot) atomicAdd(&header->num_pairs, tot);
+  }
 }
 
 __global__ void __launch_bounds__(kBinThreads)
 scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__restrict__ bin,
                          const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x,
-                         const uint32_t *__restrict__ block_hist, const uint32_t *__restrict__ tile_start,
-                         uint64_t *__restrict__ keys, uint32_t capacity, StateHeader *__restrict__ header) {
+                         const uint32_t *__restrict__ block_hist, uint32_t *__restrict__ tile_start,
+                         const uint32_t *__restrict__ tile_count, uint64_t *__restrict__ keys, uint32_t capacity,
+                         StateHeader *__restrict__ header) {
   extern __shared__ uint32_t s_cur[];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     header->capacity = capacity;
@@ -194,7 +205,51 @@ scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__
   const int pass = blockIdx.x / nb, blk = blockIdx.x - pass * nb;
   const int t_lo = pass * tpp, nt = min(tiles - t_lo, tpp);
   const uint32_t *row = block_hist + (size_t)blk * tiles + t_lo;
-  for (int t = threadIdx.x; t < nt; t += kBinThreads) s_cur[t] = tile_start[t_lo + t] + row[t];
+  if (tile_count) {
+    // (one pass, tiles <= 8192) tile_start is not there yet: every workgroup takes the exclusive prefix of the tile
+    // totals itself - 8 counts per thread, wave scans, the 16 wave totals through LDS - straight into its cursors;
+    // workgroup 0 also writes it out for the sort and the blend kernels
+    static_assert(kBinThreads == 1024, "8 counts per thread cover 8192 tiles");
+    __shared__ uint32_t s_wave[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t cnt[8], rw[8], sum = 0;
+    if ((tiles & 3) == 0 && 8 * t + 8 <= tiles) {   // rows of the histogram matrix are 16-byte aligned when tiles % 4 == 0
+      const uint4 c0 = reinterpret_cast<const uint4 *>(tile_count)[2 * t], c1 = reinterpret_cast<const uint4 *>(tile_count)[2 * t + 1];
+      const uint4 r0 = reinterpret_cast<const uint4 *>(row)[2 * t], r1 = reinterpret_cast<const uint4 *>(row)[2 * t + 1];
+      cnt[0] = c0.x; cnt[1] = c0.y; cnt[2] = c0.z; cnt[3] = c0.w; cnt[4] = c1.x; cnt[5] = c1.y; cnt[6] = c1.z; cnt[7] = c1.w;
+      rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w; rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const bool in = 8 * t + j < tiles;
+        cnt[j] = in ? tile_count[8 * t + j] : 0u;
+        rw[j] = in ? row[8 * t + j] : 0u;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) sum += cnt[j];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; w++) run += s_wave[w];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (8 * t + j < tiles) {
+        s_cur[8 * t + j] = run + rw[j];
+        if (blockIdx.x == 0) tile_start[8 * t + j] = run;
+      }
+      run += cnt[j];
+    }
+    if (blockIdx.x == 0 && t == kBinThreads - 1) tile_start[tiles] = run;
+  } else {
+    for (int t = threadIdx.x; t < nt; t += kBinThreads) s_cur[t] = tile_start[t_lo + t] + row[t];
+  }
   __syncthreads();
   const int lo = blk * per_block, hi = min(N, lo + per_block);
   for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
@@ -657,12 +712,13 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
       }
       count_tiles_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
           N, per_block, L.nb, tpp, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
-          block_hist);
-      scan_block_hist_kernel<<<(L.tiles + kScanTiles - 1) / kScanTiles, kScanTiles * kScanSegs, 0, stream>>>(L.nb, L.tiles, block_hist, tile_count);
+          block_hist, L.scan_in_scatter() ? (StateHeader *)(base + L.header) : nullptr);
+      scan_block_hist_kernel<<<(L.tiles + kScanTiles - 1) / kScanTiles, kScanTiles * kScanSegs, 0, stream>>>(
+          L.nb, L.tiles, block_hist, tile_count, L.scan_in_scatter() ? (StateHeader *)(base + L.header) : nullptr);
     }
     SCORP_KERNEL_CHECK("count_tiles", debug, stream);
   }
-  {
+  if (!L.scan_in_scatter()) {
     ProfScope prof(kKScanTiles, stream);
     scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, (uint32_t *)(base + L.tile_start), L.tiles,
                                               (StateHeader *)(base + L.header));
@@ -684,7 +740,8 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
       const int tpp = L.tiles_per_pass();
       scatter_pairs_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
           N, per_block, L.nb, tpp, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
-          (const uint32_t *)(base + L.block_hist), tile_start, keys, capacity, header);
+          (const uint32_t *)(base + L.block_hist), tile_start, L.scan_in_scatter() ? tile_count : nullptr, keys, capacity,
+          header);
     } else {
       scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(
           N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), tile_count, tile_start, L.tiles_x,
