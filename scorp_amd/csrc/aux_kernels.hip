@@ -205,12 +205,6 @@ extern "C" int scorp_adam_step_guarded(const ScorpAdamTensor *tensors, int32_t n
 
 namespace scorp {
 namespace {
-__device__ __forceinline__ float nan_to_num00(float x) {   // torch.nan_to_num(x, 0, 0)
-  if (x != x) return 0.0f;
-  if (x == __builtin_inff()) return 0.0f;
-  if (x == -__builtin_inff()) return -3.402823466e+38f;
-  return x;
-}
 __global__ void __launch_bounds__(256)
 render_tail_kernel(const float *__restrict__ depth, const float *__restrict__ alpha, size_t HW, const int32_t *__restrict__ radii,
                    int N, float *__restrict__ out_depth, uint8_t *__restrict__ out_visible) {

@@ -217,9 +217,25 @@ struct ProfScope {  // brackets one kernel launch with an event pair when profil
   ~ProfScope() { if (g_prof_on) prof_end(id, s); }
 };
 
+// torch.nan_to_num(x, 0, 0): what render() applies to depth / alpha (gaussian_renderer/__init__.py:113-120)
+__device__ __forceinline__ float nan_to_num00(float x) {
+  if (x != x) return 0.0f;
+  if (x == __builtin_inff()) return 0.0f;
+  if (x == -__builtin_inff()) return -3.402823466e+38f;
+  return x;
+}
+
 // ---- per-Gaussian kernels (gs3d_pergaussian.hip) ----
+// out_visible (optional): radii > 0 as bytes, what scorp_gs3d_render_tail would write
 void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec *rec, BinRec *bin, uint64_t *tile_mask,
-                       int32_t *radii, uint32_t *tile_count, hipStream_t stream);
+                       int32_t *radii, uint32_t *tile_count, uint8_t *out_visible, hipStream_t stream);
+// ---- the public preprocess / render with the outputs of scorp_gs3d_render_tail produced on the way (gs3d_forward.hip):
+// out_visible by the per-Gaussian kernel, out_depth_norm = nan_to_num(depth / alpha) by the blend forward's epilogue;
+// either may be NULL.  scorp_gs3d_train_view uses them instead of a tail launch.
+int preprocess3d_impl(const ScorpGs3dInputs *in, int32_t *out_radii, uint8_t *out_visible, void *state, size_t state_bytes,
+                      scorp_stream_t stream);
+int render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color, float *out_depth,
+                  float *out_alpha, float *out_depth_norm, scorp_stream_t stream, bool for_backward);
 void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L, const BinRec *bin, const float *acc,
                                 const ScorpGs3dGrads *grads, hipStream_t stream);
 

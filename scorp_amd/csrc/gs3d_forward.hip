@@ -522,7 +522,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
                           float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                          uint32_t *__restrict__ hits, uint32_t *__restrict__ block_hits) {
+                          uint32_t *__restrict__ hits, uint32_t *__restrict__ block_hits, float *__restrict__ out_depth_norm) {
   // ring entries: the record's (x, y, A, B), (C, log2 opacity, r, g), (b, depth) as preprocess stored them:
   // alpha = exp2(A dx^2 + C dy^2 + B dx dy + log2 opacity), one v_exp and no multiply
   __shared__ float4 q_a[kFRing], q_b[kFRing];
@@ -653,6 +653,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     out_color[2 * HW + pix] = C2 + T * bg[2];
     out_depth[pix] = Dp;
     out_alpha[pix] = 1.0f - T;   // = sum of the blend weights (sum_i alpha_i T_i telescopes to 1 - T)
+    if (out_depth_norm) out_depth_norm[pix] = nan_to_num00(Dp / (1.0f - T));   // render()'s depth, as render_tail_kernel forms it
   }
 }
 
@@ -765,7 +766,12 @@ extern "C" size_t scorp_gs3d_state_bytes(int32_t N, int32_t W, int32_t H) { retu
 extern "C" size_t scorp_gs3d_pairs_bytes(uint64_t capacity) { return PairLayout(capacity).total; }
 
 extern "C" int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_radii, void *state, size_t state_bytes,
-                                     scorp_stream_t stream_) {
+                                     scorp_stream_t stream) {
+  return preprocess3d_impl(in, out_radii, nullptr, state, state_bytes, stream);
+}
+
+int scorp::preprocess3d_impl(const ScorpGs3dInputs *in, int32_t *out_radii, uint8_t *out_visible, void *state,
+                             size_t state_bytes, scorp_stream_t stream_) {
   if (int e = validate(in)) return e;
   hipStream_t stream = (hipStream_t)stream_;
   const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
@@ -781,7 +787,7 @@ extern "C" int scorp_gs3d_preprocess(const ScorpGs3dInputs *in, int32_t *out_rad
   if (N > 0) {
     ProfScope prof(kKPreprocess, stream);
     launch_preprocess(in, L, (SplatRec *)(base + L.rec), (BinRec *)(base + L.bin), (uint64_t *)(base + L.tile_mask), out_radii,
-                      tile_count, stream);
+                      tile_count, out_visible, stream);
     SCORP_KERNEL_CHECK("preprocess", in->debug, stream);
   }
   if (int e = bin_count_and_scan(L, base, N, in->debug, stream)) return e;
@@ -812,8 +818,8 @@ extern "C" int scorp_gs3d_check_overflow(const void *state, scorp_stream_t strea
   return SCORP_OK;
 }
 
-static int render_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
-                       float *out_depth, float *out_alpha, scorp_stream_t stream_, bool for_backward) {
+int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
+                         float *out_depth, float *out_alpha, float *out_depth_norm, scorp_stream_t stream_, bool for_backward) {
   if (int e = validate(in)) return e;
   hipStream_t stream = (hipStream_t)stream_;
   const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
@@ -835,7 +841,7 @@ static int render_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint
     bk<<<blocks, 64, 0, stream>>>(
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
         out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib),
-        (uint32_t *)(pb + P.hits), (uint32_t *)(base + L.block_hits));
+        (uint32_t *)(pb + P.hits), (uint32_t *)(base + L.block_hits), out_depth_norm);
   }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;
@@ -843,12 +849,12 @@ static int render_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint
 
 extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
                                  float *out_color, float *out_depth, float *out_alpha, scorp_stream_t stream) {
-  return render_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, stream, true);
+  return render3d_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, nullptr, stream, true);
 }
 
 extern "C" int scorp_gs3d_render_image(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
                                        float *out_color, float *out_depth, float *out_alpha, scorp_stream_t stream) {
-  return render_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, stream, false);
+  return render3d_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, nullptr, stream, false);
 }
 
 extern "C" int scorp_gs3d_debug_geom(const void *state, int32_t N, int32_t W, int32_t H, float *xy, float *depth,

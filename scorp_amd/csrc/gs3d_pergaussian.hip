@@ -27,6 +27,7 @@ struct PgArgs {
   float tanfovx, tanfovy, scale_mod;
   const float *view, *proj, *campos;
   const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+  uint8_t *visible;   // optional: radii > 0 as bytes (render()'s visibility_filter)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -162,6 +163,7 @@ __device__ __forceinline__ void emit_splat(const PgArgs &a, int i, const SplatGe
   reinterpret_cast<uint4 *>(bin)[i] = *reinterpret_cast<const uint4 *>(&br);
   tile_mask[i] = g.mask;
   radii[i] = radius_out;
+  if (a.visible) a.visible[i] = radius_out > 0 ? 1 : 0;
 }
 
 // LIN: a full block of the split K = 16 layout, whose SH rows go to LDS with direct global -> LDS loads.  It is a
@@ -532,14 +534,16 @@ PgArgs make_args(const ScorpGs3dInputs *in, const StateLayout &L) {
   a.view = in->viewmatrix; a.proj = in->projmatrix; a.campos = in->campos;
   a.means3D = in->means3D; a.shs = in->shs; a.shs_rest = in->shs_rest; a.colors_precomp = in->colors_precomp;
   a.opacities = in->opacities; a.scales = in->scales; a.rotations = in->rotations; a.cov3D_precomp = in->cov3D_precomp;
+  a.visible = nullptr;
   return a;
 }
 
 }  // namespace
 
 void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec *rec, BinRec *bin, uint64_t *tile_mask,
-                       int32_t *radii, uint32_t *tile_count, hipStream_t stream) {
-  const PgArgs a = make_args(in, L);
+                       int32_t *radii, uint32_t *tile_count, uint8_t *out_visible, hipStream_t stream) {
+  PgArgs a = make_args(in, L);
+  a.visible = out_visible;
   const dim3 grid((a.N + 255) / 256), block(256);
   const int deg = in->shs ? in->sh_degree : 0;
   const bool split = in->shs_rest != nullptr;

@@ -13,12 +13,12 @@ extern "C" int scorp_gs3d_train_view(const ScorpGs3dTrainView *v, scorp_stream_t
   }
   const ScorpGs3dInputs *in = v->in;
   const int W = in->image_width, H = in->image_height;
-  if (int e = scorp_gs3d_preprocess(in, v->out_radii, v->state, v->state_bytes, stream)) return e;
-  if (int e = scorp_gs3d_render(in, v->state, v->pairs, v->capacity, v->out_color, v->out_depth_raw, v->out_alpha, stream)) return e;
-  if (v->out_depth && v->out_visible) {
-    if (int e = scorp_gs3d_render_tail(v->out_depth_raw, v->out_alpha, (int64_t)W * H, v->out_radii, in->num_gaussians,
-                                       v->out_depth, v->out_visible, stream)) return e;
-  }
+  // render()'s tail (normalised depth, visibility filter) comes out of the per-Gaussian kernel and the blend forward's
+  // epilogue: same values as scorp_gs3d_render_tail, one launch less per view
+  const bool tail = v->out_depth && v->out_visible;
+  if (int e = preprocess3d_impl(in, v->out_radii, tail ? v->out_visible : nullptr, v->state, v->state_bytes, stream)) return e;
+  if (int e = render3d_impl(in, v->state, v->pairs, v->capacity, v->out_color, v->out_depth_raw, v->out_alpha,
+                            tail ? v->out_depth : nullptr, stream, true)) return e;
   if (int e = scorp_loss_l1_ssim_forward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->out_loss3,
                                          v->loss_workspace, v->loss_workspace_bytes, 1, stream)) return e;
   if (int e = scorp_loss_l1_ssim_backward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,
