@@ -140,6 +140,10 @@ int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state, const void
  * SCORP_BACKWARD_EXACT_FP32 selects fp32 MFMAs throughout (the form the reference CUDA's fp32 arithmetic corresponds
  * to; ~1.3x the blend-backward time): the parity tests compare the two.  scorp_gs3d_backward == flags 0. */
 #define SCORP_BACKWARD_EXACT_FP32 1u
+/* SCORP_BACKWARD_SCRATCH_ZEROED: the caller guarantees that the first num_gaussians * 64 bytes of `scratch` (the
+ * per-Gaussian accumulator rows) are zero when the call starts, so the library skips its 64 MB-per-million fill.
+ * scorp_gs3d_train_view uses it: there the blend FORWARD's waves, whose memory pipes idle, clear the rows on the way. */
+#define SCORP_BACKWARD_SCRATCH_ZEROED 2u
 int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
                            const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
                            const ScorpGs3dGrads *grads, void *scratch, size_t scratch_bytes, uint32_t flags,

@@ -80,6 +80,7 @@ EXPORTS = [
 ]
 
 BACKWARD_EXACT_FP32 = 1   # scorp_gs3d_backward_ex flag (include/scorp_gs.h)
+BACKWARD_SCRATCH_ZEROED = 2   # scorp_gs3d_backward_ex flag: the caller cleared the accumulator rows already
 
 _lib = None
 

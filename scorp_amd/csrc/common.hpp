@@ -234,8 +234,11 @@ void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec
 // either may be NULL.  scorp_gs3d_train_view uses them instead of a tail launch.
 int preprocess3d_impl(const ScorpGs3dInputs *in, int32_t *out_radii, uint8_t *out_visible, void *state, size_t state_bytes,
                       scorp_stream_t stream);
+// zero_buf / zero_bytes (optional, a multiple of 16 bytes): memory the blend forward's waves clear on the way (the
+// backward's accumulator rows: the forward is VALU-bound and its stores are free, a separate fill is 9 us per view).
 int render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color, float *out_depth,
-                  float *out_alpha, float *out_depth_norm, scorp_stream_t stream, bool for_backward);
+                  float *out_alpha, float *out_depth_norm, void *zero_buf, size_t zero_bytes, scorp_stream_t stream,
+                  bool for_backward);
 void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L, const BinRec *bin, const float *acc,
                                 const ScorpGs3dGrads *grads, hipStream_t stream);
 

@@ -482,7 +482,7 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
   }
   const char *base = (const char *)state, *pb = (const char *)pairs;
   float *acc = (float *)scratch;
-  SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAccStride * sizeof(float), stream));
+  if (!(flags & SCORP_BACKWARD_SCRATCH_ZEROED)) SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAccStride * sizeof(float), stream));
   {
     ProfScope prof(kKBlendBackward, stream);
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;

@@ -522,13 +522,20 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
                           float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                          uint32_t *__restrict__ hits, uint32_t *__restrict__ block_hits, float *__restrict__ out_depth_norm) {
+                          uint32_t *__restrict__ hits, uint32_t *__restrict__ block_hits, float *__restrict__ out_depth_norm,
+                          float4 *__restrict__ zero_buf, uint32_t zero_per_wave, uint32_t zero_total) {
   // ring entries: the record's (x, y, A, B), (C, log2 opacity, r, g), (b, depth) as preprocess stored them:
   // alpha = exp2(A dx^2 + C dy^2 + B dx dy + log2 opacity), one v_exp and no multiply
   __shared__ float4 q_a[kFRing], q_b[kFRing];
   __shared__ float2 q_c[kFRing];
   __shared__ __attribute__((aligned(16))) uint32_t q_pos[kFRing];
   const int lane = threadIdx.x;
+  if (zero_buf) {   // this wave's share of the buffer the launch was asked to clear (every workgroup of the grid takes part)
+    const uint32_t z0 = blockIdx.x * zero_per_wave, z1 = min(z0 + zero_per_wave, zero_total);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v zero = {0.0f, 0.0f, 0.0f, 0.0f};   // streaming stores: the rows are not read before the backward, keep them out of L2
+    for (uint32_t z = z0 + lane; z < z1; z += 64) __builtin_nontemporal_store(zero, reinterpret_cast<f4v *>(zero_buf) + z);
+  }
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
   if (tile >= tiles) return;
@@ -819,7 +826,8 @@ extern "C" int scorp_gs3d_check_overflow(const void *state, scorp_stream_t strea
 }
 
 int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
-                         float *out_depth, float *out_alpha, float *out_depth_norm, scorp_stream_t stream_, bool for_backward) {
+                         float *out_depth, float *out_alpha, float *out_depth_norm, void *zero_buf, size_t zero_bytes,
+                         scorp_stream_t stream_, bool for_backward) {
   if (int e = validate(in)) return e;
   hipStream_t stream = (hipStream_t)stream_;
   const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
@@ -837,11 +845,16 @@ int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, ui
   {
     ProfScope prof(kKBlendForward, stream);
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
+    const size_t zero_total = zero_buf ? zero_bytes / 16 : 0, zero_per_wave = (zero_total + blocks - 1) / blocks;
+    if (zero_buf && (((uintptr_t)zero_buf & 15) || (zero_bytes & 15) || zero_total > 0xFFFFFFFFull)) {
+      set_error("render3d_impl: zero_buf must be 16-byte aligned, a multiple of 16 bytes, below 64 GiB"); return SCORP_ERR_INVALID;
+    }
     auto bk = for_backward ? blend_forward_wave_kernel<true> : blend_forward_wave_kernel<false>;
     bk<<<blocks, 64, 0, stream>>>(
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
         out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib),
-        (uint32_t *)(pb + P.hits), (uint32_t *)(base + L.block_hits), out_depth_norm);
+        (uint32_t *)(pb + P.hits), (uint32_t *)(base + L.block_hits), out_depth_norm, (float4 *)zero_buf,
+        (uint32_t)zero_per_wave, (uint32_t)zero_total);
   }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;
@@ -849,12 +862,12 @@ int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, ui
 
 extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
                                  float *out_color, float *out_depth, float *out_alpha, scorp_stream_t stream) {
-  return render3d_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, nullptr, stream, true);
+  return render3d_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, nullptr, nullptr, 0, stream, true);
 }
 
 extern "C" int scorp_gs3d_render_image(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
                                        float *out_color, float *out_depth, float *out_alpha, scorp_stream_t stream) {
-  return render3d_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, nullptr, stream, false);
+  return render3d_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, nullptr, nullptr, 0, stream, false);
 }
 
 extern "C" int scorp_gs3d_debug_geom(const void *state, int32_t N, int32_t W, int32_t H, float *xy, float *depth,

@@ -17,14 +17,19 @@ extern "C" int scorp_gs3d_train_view(const ScorpGs3dTrainView *v, scorp_stream_t
   // epilogue: same values as scorp_gs3d_render_tail, one launch less per view
   const bool tail = v->out_depth && v->out_visible;
   if (int e = preprocess3d_impl(in, v->out_radii, tail ? v->out_visible : nullptr, v->state, v->state_bytes, stream)) return e;
+  // ... and so do the zeros of the backward's accumulator rows (N x 64 bytes at the head of its scratch)
+  const size_t acc_bytes = (size_t)(in->num_gaussians > 0 ? in->num_gaussians : 0) * kAccStride * sizeof(float);
+  const bool zero_here = v->backward_scratch && acc_bytes > 0 && acc_bytes <= v->backward_scratch_bytes &&
+                         ((uintptr_t)v->backward_scratch & 15) == 0;
   if (int e = render3d_impl(in, v->state, v->pairs, v->capacity, v->out_color, v->out_depth_raw, v->out_alpha,
-                            tail ? v->out_depth : nullptr, stream, true)) return e;
+                            tail ? v->out_depth : nullptr, zero_here ? v->backward_scratch : nullptr, acc_bytes, stream, true)) return e;
   if (int e = scorp_loss_l1_ssim_forward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->out_loss3,
                                          v->loss_workspace, v->loss_workspace_bytes, 1, stream)) return e;
   if (int e = scorp_loss_l1_ssim_backward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,
                                           v->grad_color, stream)) return e;
-  return scorp_gs3d_backward(in, v->state, v->pairs, v->capacity, v->grad_color, nullptr, nullptr, v->grads,
-                             v->backward_scratch, v->backward_scratch_bytes, stream);
+  return scorp_gs3d_backward_ex(in, v->state, v->pairs, v->capacity, v->grad_color, nullptr, nullptr, v->grads,
+                                v->backward_scratch, v->backward_scratch_bytes, zero_here ? SCORP_BACKWARD_SCRATCH_ZEROED : 0u,
+                                stream);
 }
 
 extern "C" int scorp_gs2d_train_view(const ScorpGs2dTrainView *v, scorp_stream_t stream) {
