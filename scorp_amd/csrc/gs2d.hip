@@ -258,14 +258,23 @@ preprocess2d_kernel(Pg2Args a, Surfel *__restrict__ rec, BinRec *__restrict__ bi
 // (surfel_reaches_box); survivors are compacted into a per-wave LDS ring.
 // ---------------------------------------------------------------------------------------------------------
 // The ray-surfel intersection in linear form.  With k = x Tw - Tu, l = y Tw - Tv the reference intersects with
-// p = k x l and s = (p0, p1) / p2.  p is LINEAR in the pixel: p = x (Tv x Tw) + y (Tw x Tu) + Tu x Tv, and
-// p . Tw = det[Tu; Tv; Tw] =: D for every pixel, so the hit depth s0 Tw0 + s1 Tw1 + Tw2 = D / p2.  The lane that
-// inserts a surfel into a wave's ring computes pa = Tv x Tw, pb = Tw x Tu, pc = Tu x Tv, D once; a pixel then needs
-// six FMAs for p instead of two 3-vectors and a cross product, no reciprocal for the depth (nor for 1 / depth:
-// p2 / D), and the backward accumulates gradients of (pa, pb, pc, D) — products of dp with (x, y, 1) — which
-// preprocess2d_backward_kernel chains back to T.
+// p = k x l and s = (p0, p1) / p2.  p is LINEAR in the pixel, and p . Tw = det[Tu; Tv; Tw] =: D for every pixel, so
+// the hit depth s0 Tw0 + s1 Tw1 + Tw2 = D / p2.  A wave expands the form about the CENTRE (bxc, byc) OF ITS 8x8 BLOCK:
+// with kb = bxc Tw - Tu, lb = byc Tw - Tv (each component ONE fma, so the near-cancellation of bxc Tw2 against Tu2
+// costs a single rounding of the small result),
+//     p(x, y) = (x - bxc) pa + (y - byc) pb + pc,    pa = Tv x Tw,  pb = Tw x Tu,  pc = kb x lb,
+// and (x - bxc, y - byc) is a per-lane constant in {-3.5 .. 3.5}: six FMAs per pixel, no reciprocal for the depth (nor
+// for 1 / depth: p2 / D).  Expanded about the image origin instead (pc = Tu x Tv, round 1) p0 and p1 were differences
+// of terms ~10^2 times their size, and 2 % of random scenes held a surfel whose gradient missed the oracle's by more
+// than its tolerance.  The lane that inserts a surfel into a wave's ring computes pa, pb, pc, D once.
+// The backward accumulates the gradients of (pa, pb, pc, D) about ONE point per surfel whatever the block - its centre
+// (cx, cy) clamped into the image, (ex, ey) - as products of dp with (x - ex, y - ey, 1); preprocess2d_backward_kernel
+// chains them back to T with pc = (ex Tw - Tu) x (ey Tw - Tv), (ex, ey) held fixed (p as a function of T does not
+// depend on where it is expanded).  A splat-centred frame keeps those sums and their cross products with T free of
+// the (x, y)-weighted against (cx, cy)-weighted cancellation of the origin form; the clamp keeps a centre far outside
+// the image (a large surfel seen from close by) from re-creating it.
 struct SurfelLin { float4 e0, e1, e2, e3; };   // (pa, pb0) (pb1, pb2, pc0, pc1) (pc2, D, cx, cy) (log2 o, Tw2, 1/D, 1/Tw2)
-__device__ __forceinline__ SurfelLin surfel_lin(const float4 r0, const float4 r1, const float4 r2) {
+__device__ __forceinline__ SurfelLin surfel_lin(const float4 r0, const float4 r1, const float4 r2, float bxc, float byc) {
 #pragma clang fp contract(off)
   const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
   float pa[3], pb[3], pc[3];
@@ -274,7 +283,14 @@ __device__ __forceinline__ SurfelLin surfel_lin(const float4 r0, const float4 r1
     const int j = (i + 1) % 3, k = (i + 2) % 3;
     pa[i] = __builtin_fmaf(Tv[j], Tw[k], -(Tv[k] * Tw[j]));
     pb[i] = __builtin_fmaf(Tw[j], Tu[k], -(Tw[k] * Tu[j]));
-    pc[i] = __builtin_fmaf(Tu[j], Tv[k], -(Tu[k] * Tv[j]));
+  }
+  float kc[3], lc[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { kc[i] = __builtin_fmaf(bxc, Tw[i], -Tu[i]); lc[i] = __builtin_fmaf(byc, Tw[i], -Tv[i]); }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    pc[i] = __builtin_fmaf(kc[j], lc[k], -(kc[k] * lc[j]));
   }
   const float D = __builtin_fmaf(Tu[0], pa[0], __builtin_fmaf(Tu[1], pa[1], Tu[2] * pa[2]));
   SurfelLin L;
@@ -288,12 +304,12 @@ __device__ __forceinline__ SurfelLin surfel_lin(const float4 r0, const float4 r1
 struct Eval2 { float s0, s1, pz, rz, dx, dy, depth, rdepth, Go, alpha; bool use3d; };
 // Same decisions in forward and backward: every product-sum is written as an explicit fma and contraction is off, so
 // the two kernels cannot round the intersection differently.  Go = opacity * G (alpha before the 0.99 clamp).
-__device__ __forceinline__ bool eval_surfel(const float4 e0, const float4 e1, const float4 e2, const float4 e3, float pxf,
-                                            float pyf, Eval2 &h) {
+__device__ __forceinline__ bool eval_surfel(const float4 e0, const float4 e1, const float4 e2, const float4 e3, float qx,
+                                            float qy, float pxf, float pyf, Eval2 &h) {   // (qx, qy) = pixel - block centre
 #pragma clang fp contract(off)
-  const float p0 = __builtin_fmaf(e0.x, pxf, __builtin_fmaf(e0.w, pyf, e1.z));
-  const float p1 = __builtin_fmaf(e0.y, pxf, __builtin_fmaf(e1.x, pyf, e1.w));
-  h.pz = __builtin_fmaf(e0.z, pxf, __builtin_fmaf(e1.y, pyf, e2.x));
+  const float p0 = __builtin_fmaf(e0.x, qx, __builtin_fmaf(e0.w, qy, e1.z));
+  const float p1 = __builtin_fmaf(e0.y, qx, __builtin_fmaf(e1.x, qy, e1.w));
+  h.pz = __builtin_fmaf(e0.z, qx, __builtin_fmaf(e1.y, qy, e2.x));
   h.rz = __builtin_amdgcn_rcpf(h.pz);
   h.s0 = p0 * h.rz; h.s1 = p1 * h.rz;
   const float rho3d = __builtin_fmaf(h.s0, h.s0, h.s1 * h.s1);
@@ -330,6 +346,8 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
   const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const float bxc = (float)bx + 3.5f, byc = (float)by + 3.5f;                    // the linear form's expansion point (surfel_lin)
+  const float qxb = (float)(lane & 7) - 3.5f, qyb = (float)(lane >> 3) - 3.5f;   // this pixel about it
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t n = end - beg;
   const float fn = kFarZ / (kFarZ - kNearZ);
@@ -363,7 +381,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
     const uint64_t m = __ballot(hit);
     if (hit) {
       const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (k2FRing - 1);
-      const SurfelLin L = surfel_lin(r0, r1, r2);
+      const SurfelLin L = surfel_lin(r0, r1, r2, bxc, byc);
       q0[qi] = L.e0; q1[qi] = L.e1; q2[qi] = L.e2; q3[qi] = L.e3; q4[qi] = r3; q5[qi] = make_float2(r4.x, r4.y);
       q_pos[qi] = base + lane + 1u;
     }
@@ -387,7 +405,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
 #pragma unroll
       for (int i = 0; i < k2FGroup; i++) {
         Eval2 h;
-        const bool ok = eval_surfel(g0[i], g1[i], g2[i], g3[i], pxf, pyf, h) & (kFull || i < nslots);
+        const bool ok = eval_surfel(g0[i], g1[i], g2[i], g3[i], qxb, qyb, pxf, pyf, h) & (kFull || i < nslots);
         al[i] = ok ? h.alpha : 0.0f;
         dz[i] = ok ? h.depth : 1.0f;
         mm[i] = fn * (1.0f - kNearZ * (ok ? h.rdepth : 1.0f));
@@ -508,6 +526,8 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   const int px = bx + (lane & 7), py = by + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
+  const float bxc = (float)bx + 3.5f, byc = (float)by + 3.5f;                    // the linear form's expansion point (surfel_lin)
+  const float qxb = (float)(lane & 7) - 3.5f, qyb = (float)(lane >> 3) - 3.5f;   // this pixel about it
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   if (end == beg) return;
   const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
@@ -570,9 +590,10 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
     __builtin_amdgcn_wave_barrier();   // every lane is past the previous chunk's reads of the ring
     if (hit) {
       const int qi = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      const SurfelLin L = surfel_lin(r0, r1, r2);
+      const SurfelLin L = surfel_lin(r0, r1, r2, bxc, byc);
       q0[qi] = L.e0; q1[qi] = L.e1; q2[qi] = L.e2; q3[qi] = L.e3; q4[qi] = r3;
-      q5[qi] = make_float4(r4.x, r4.y, __builtin_amdgcn_rcpf(r2.w), 0.0f);
+      // (ox, oy) = block centre - the surfel's accumulation point (its centre clamped into the image)
+      q5[qi] = make_float4(r4.x, r4.y, bxc - fminf(fmaxf(r2.y, 0.0f), (float)(W - 1)), byc - fminf(fmaxf(r2.z, 0.0f), (float)(H - 1)));
       q_id[qi] = id; q_pos[qi] = top - (uint32_t)lane + 1u;
     }
     const int cnt = __builtin_popcountll(m);
@@ -584,7 +605,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       const uint32_t pos1 = q_pos[s];
       const float4 a0 = q0[s], a1 = q1[s], a2 = q2[s], a3 = q3[s];
       Eval2 h;
-      const bool valid = eval_surfel(a0, a1, a2, a3, pxf, pyf, h) & (pos1 <= last);
+      const bool valid = eval_surfel(a0, a1, a2, a3, qxb, qyb, pxf, pyf, h) & (pos1 <= last);
       if (__ballot(valid) == 0) continue;
       // The per-pixel recurrence runs under `valid`; it leaves three scalars (blend weight w, t = dL/dG * (-G), dL/dz)
       // that are zero on the other lanes, and the twenty sums are formed from them outside the branch with the
@@ -631,15 +652,16 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         const float dp0 = tr * s0, dp1 = tr * s1;
         const float zr = dL_dz * rz;                                        // depth = D / pz
         const float dp2 = -(dp0 * s0 + dp1 * s1) - zr * dep;
-        g[0] = dp0 * pxf; g[1] = dp1 * pxf; g[2] = dp2 * pxf;
-        g[3] = dp0 * pyf; g[4] = dp1 * pyf; g[5] = dp2 * pyf;
+        const float ax = qxb + gb.z, ay = qyb + gb.w;   // x - ex, y - ey: the pixel about the surfel's accumulation point
+        g[0] = dp0 * ax; g[1] = dp1 * ax; g[2] = dp2 * ax;
+        g[3] = dp0 * ay; g[4] = dp1 * ay; g[5] = dp2 * ay;
         g[6] = dp0; g[7] = dp1; g[8] = dp2;
         g[9] = zr;
         g[10] = z2;
         g[11] = t2 * (kFilterInvSq * h.dx);
         g[12] = t2 * (kFilterInvSq * h.dy);
         g[13] = kHasMap ? w * dn0 : 0.0f; g[14] = kHasMap ? w * dn1 : 0.0f; g[15] = kHasMap ? w * dn2 : 0.0f;
-        g[16] = -t * gb.z;                                                  // G * dL/dalpha
+        g[16] = -t;                                                         // opacity * G * dL/dalpha (the per-surfel kernel divides by the opacity)
         g[17] = w * dpix0; g[18] = w * dpix1; g[19] = w * dpix2;
       }
       const float v = reduce20(g, lane);
@@ -668,6 +690,7 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
   // LIN: pre = means 0-2, rotation 3-6, scale 7-8, opacity 10 | acc_lo = accumulators 0-10 | acc_hi = accumulators
   // 11-19 in slots 0-8, radius word in slot 10 | rec_lo = transform 0-8, depth word in slot 10
   float pre[11], acc_lo[11], acc_hi[11], rec_lo[11];
+  float lin_cx = 0.0f, lin_cy = 0.0f, lin_op = 1.0f;   // LIN: the surfel's centre and opacity (record r2.y, r2.z, r2.w)
   int32_t rad_bits = 0;
   if constexpr (LIN) {
     static_assert(kAcc2Stride == 20, "accumulator row of 20 floats");
@@ -675,7 +698,7 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
     const float4 *rp = reinterpret_cast<const float4 *>(rec + i);
     const uint4 bw = reinterpret_cast<const uint4 *>(bin)[i];
     const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3], a4 = ap[4], r0 = rp[0], r1 = rp[1];
-    const float r2x = reinterpret_cast<const float *>(rp + 2)[0];
+    const float4 r2v = rp[2];   // Tw.z, cx, cy, (opacity)
     const float4 q_in = reinterpret_cast<const float4 *>(a.rotations)[i];
     const float s_in0 = a.scales[2 * (size_t)i], s_in1 = a.scales[2 * (size_t)i + 1];
     pre[0] = a.means3D[3 * (size_t)i]; pre[1] = a.means3D[3 * (size_t)i + 1]; pre[2] = a.means3D[3 * (size_t)i + 2];
@@ -687,7 +710,8 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
     acc_hi[0] = a2.w; acc_hi[1] = a3.x; acc_hi[2] = a3.y; acc_hi[3] = a3.z; acc_hi[4] = a3.w; acc_hi[5] = a4.x; acc_hi[6] = a4.y;
     acc_hi[7] = a4.z; acc_hi[8] = a4.w;
     rec_lo[0] = r0.x; rec_lo[1] = r0.y; rec_lo[2] = r0.z; rec_lo[3] = r0.w; rec_lo[4] = r1.x; rec_lo[5] = r1.y; rec_lo[6] = r1.z;
-    rec_lo[7] = r1.w; rec_lo[8] = r2x;
+    rec_lo[7] = r1.w; rec_lo[8] = r2v.x;
+    lin_cx = r2v.y; lin_cy = r2v.z; lin_op = r2v.w;
     rec_lo[10] = __uint_as_float(bw.z);   // BinRec: x0y0 | x1y1 | depth word | radius word
     acc_hi[10] = __uint_as_float(bw.w);
     rad_bits = __float_as_int(acc_hi[10]);
@@ -724,7 +748,7 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
       a2 = make_float4(acc_lo[8], acc_lo[9], acc_lo[10], acc_hi[0]); a3 = make_float4(acc_hi[1], acc_hi[2], acc_hi[3], acc_hi[4]);
       a4 = make_float4(acc_hi[5], acc_hi[6], acc_hi[7], acc_hi[8]);
       r0 = make_float4(rec_lo[0], rec_lo[1], rec_lo[2], rec_lo[3]); r1 = make_float4(rec_lo[4], rec_lo[5], rec_lo[6], rec_lo[7]);
-      r2 = make_float4(rec_lo[8], 0.0f, 0.0f, 0.0f);
+      r2 = make_float4(rec_lo[8], lin_cx, lin_cy, lin_op);
     } else {
       const float4 *ap = reinterpret_cast<const float4 *>(acc + (size_t)i * kAcc2Stride);
       a0 = ap[0]; a1 = ap[1]; a2 = ap[2]; a3 = ap[3]; a4 = ap[4];
@@ -734,18 +758,30 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
     const float ga[3] = {a0.x, a0.y, a0.z}, gb[3] = {a0.w, a1.x, a1.y}, gc[3] = {a1.z, a1.w, a2.x};
     const float gD = a2.y, gTw2 = a2.z, gx = a2.w, gy = a3.x;
     const float gn[3] = {a3.y, a3.z, a3.w};
-    g_op = a4.x;
+    g_op = a4.x / r2.w;   // the blend kernel summed opacity * G * dL/dalpha
     grgb[0] = a4.y; grgb[1] = a4.z; grgb[2] = a4.w;
     const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r0.w, r1.x, r1.y}, Tw[3] = {r1.z, r1.w, r2.x};
-    // the blend kernels differentiate the linear form p = x pa + y pb + pc, depth = D / p.z (see surfel_lin):
-    // pa = Tv x Tw, pb = Tw x Tu, pc = Tu x Tv, D = Tu . pa; for c = u x v: dL/du = v x g, dL/dv = g x u
+    // the blend kernels hand over the gradients of the linear form p = (x - ex) pa + (y - ey) pb + pc, depth = D / p.z
+    // (see surfel_lin): pa = Tv x Tw, pb = Tw x Tu, pc = kc x lc with kc = ex Tw - Tu, lc = ey Tw - Tv, D = Tu . pa,
+    // (ex, ey) = the centre clamped into the image, held fixed.  For c = u x v: dL/du = v x g, dL/dv = g x u.
+    const float ecx = fminf(fmaxf(r2.y, 0.0f), (float)(a.W - 1)), ecy = fminf(fmaxf(r2.z, 0.0f), (float)(a.H - 1));
+    float kc[3], lc[3], gkc[3], glc[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { kc[q] = __builtin_fmaf(ecx, Tw[q], -Tu[q]); lc[q] = __builtin_fmaf(ecy, Tw[q], -Tv[q]); }
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const int j = (q + 1) % 3, k = (q + 2) % 3;
-      const float pa_q = Tv[j] * Tw[k] - Tv[k] * Tw[j], pb_q = Tw[j] * Tu[k] - Tw[k] * Tu[j], pc_q = Tu[j] * Tv[k] - Tu[k] * Tv[j];
-      gT[q] = (gb[j] * Tw[k] - gb[k] * Tw[j]) + (Tv[j] * gc[k] - Tv[k] * gc[j]) + gD * pa_q;        // d/dTu
-      gT[3 + q] = (Tw[j] * ga[k] - Tw[k] * ga[j]) + (gc[j] * Tu[k] - gc[k] * Tu[j]) + gD * pb_q;    // d/dTv
-      gT[6 + q] = (ga[j] * Tv[k] - ga[k] * Tv[j]) + (Tu[j] * gb[k] - Tu[k] * gb[j]) + gD * pc_q;    // d/dTw
+      gkc[q] = lc[j] * gc[k] - lc[k] * gc[j];   // d/dkc = lc x gc
+      glc[q] = gc[j] * kc[k] - gc[k] * kc[j];   // d/dlc = gc x kc
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int j = (q + 1) % 3, k = (q + 2) % 3;
+      const float pa_q = Tv[j] * Tw[k] - Tv[k] * Tw[j], pb_q = Tw[j] * Tu[k] - Tw[k] * Tu[j], tuv_q = Tu[j] * Tv[k] - Tu[k] * Tv[j];
+      gT[q] = (gb[j] * Tw[k] - gb[k] * Tw[j]) - gkc[q] + gD * pa_q;                                  // d/dTu
+      gT[3 + q] = (Tw[j] * ga[k] - Tw[k] * ga[j]) - glc[q] + gD * pb_q;                              // d/dTv
+      gT[6 + q] = (ga[j] * Tv[k] - ga[k] * Tv[j]) + (Tu[j] * gb[k] - Tu[k] * gb[j]) + (ecx * gkc[q] + ecy * glc[q])
+                  + gD * tuv_q;                                                                      // d/dTw (dD/dTw = Tu x Tv)
     }
     gT[8] += gTw2;
     const float depth = LIN ? rec_lo[10] : __uint_as_float(bin[i].depth_bits);

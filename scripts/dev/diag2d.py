@@ -6,8 +6,10 @@ from tests.test_gs2d_gpu import hip_render2d
 from tests.test_oracle2d_cpu import make_case2d
 from oracle.gs_oracle import OracleRender2D
 dev = torch.device('cuda:0')
-for k in (16, 2, 7):
-    case = fuzz_cases("2d", 32, 20261004)[k]
+import os
+SEED, NN = int(os.environ.get("DIAG_SEED", "20261004")), int(os.environ.get("DIAG_N", "32"))
+for k in [int(v) for v in os.environ.get("DIAG_CASES", "16,2,7").split(",")]:
+    case = fuzz_cases("2d", NN, SEED)[k]
     kw, _ = make_case2d(**case)
     o = OracleRender2D(np.float32, **kw)
     o64 = OracleRender2D(np.float64, **kw)

@@ -2,6 +2,8 @@
 import ctypes
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -120,25 +122,23 @@ def _parity_2d(case, dev, report=None, outlier_gaussians=0):
 
 
 from tests.util import fuzz_cases  # noqa: E402
-FUZZ_2D = fuzz_cases("2d", 32, 20261004)
+_FUZZ_SEED = int(os.environ.get("SCORP_FUZZ_SEED", "20261004"))   # (a longer, differently seeded draw for one-off soak runs)
+FUZZ_2D = fuzz_cases("2d", int(os.environ.get("SCORP_FUZZ_N", "32")), _FUZZ_SEED)
 
 
-# Named exceptions, each ONE surfel of the case (scripts/dev/diag2d_single.py renders it alone, pixel by pixel):
-#   2: surfel 1322, scales (0.0146, 0.0041), seen almost edge-on: at pixel (45,50) the ray-surfel intersection is so
-#      ill-conditioned that the oracle's own fp32 and float64 builds give alpha 0.01244 / 0.01227 (1.4 % apart); the HIP
-#      kernel's linear form p = x pa + y pb + pc gives 0.01288.  Every other pixel of it agrees to 1e-7.
-#   7: surfel 3836, scales (0.0149, 0.0962): at pixel (72,59), far out on its long axis, the HIP alpha is 0.0039216 - the
-#      1/255 threshold to the last digit - and passes it, the oracle's is just below and is dropped; same cause (the
-#      intersection's rounding error there is ~1e-4 of rho, not the 4e-6 the band perturbation covers).
-# Re-centring the linear form on the surfel (p from (dx, dy), which the kernel already has) would shrink both; it is the
-# first 2DGS item of DESIGN.md §8.  Until then: the one worst surfel of these two cases is held to 5 % instead.
-FUZZ_2D_EXCEPTIONS = {2: 1, 7: 1}
+# No named exceptions any more.  Round 1's linear form of the ray-surfel intersection, expanded about the image
+# origin, needed two here (surfel 1322 of case 2 seen almost edge-on, surfel 3836 of case 7 far out on its long axis:
+# scripts/dev/diag2d_single.py) and missed the tolerance in 7 of 300 differently seeded draws; expanded about the block
+# centre, with the gradients gathered about the surfel's own centre (gs2d.hip, surfel_lin), all 32 pass as they are and
+# 1-2 of 300 remain (SCORP_FUZZ_N=300 SCORP_FUZZ_SEED=1|2|777): single pixels where alpha sits on the 1/255 threshold
+# to the last digit and the two implementations' roundings fall on different sides (scripts/dev/diag2d.py).
+FUZZ_2D_EXCEPTIONS = {}
 
 
 @pytest.mark.parametrize("k", range(len(FUZZ_2D)))
 def test_fuzz_parity_2d(k, dev):
     """Randomised surfel cases (seeded), forward + backward against the 2-D oracle, same assertions as above."""
-    _parity_2d(FUZZ_2D[k], dev, outlier_gaussians=FUZZ_2D_EXCEPTIONS.get(k, 0))
+    _parity_2d(FUZZ_2D[k], dev, outlier_gaussians=FUZZ_2D_EXCEPTIONS.get(k, 0) if _FUZZ_SEED == 20261004 else 0)
 
 
 def test_stage_parity_2d(dev):
