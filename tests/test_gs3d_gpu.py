@@ -281,10 +281,11 @@ def test_stage_parity_geom_and_tile_lists(name, dev):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 9, 16, 17, 33, 64, 65, 100, 128, 129, 255, 256, 257, 511, 512, 513, 1000,
-                               1023, 1024, 1025, 1500])
+                               1023, 1024, 1025, 1500, 2047, 2048, 2049, 3000, 4095, 4096, 4097, 5000])
 def test_tile_sort_every_network_size(n, dev):
     """One 16x16 tile, n large splats all over it: the tile's list must be the splats ordered by (depth bits, index),
-    bit-exact, for every size of the sorting network (in registers up to 1024 entries, in LDS beyond)."""
+    bit-exact, for every size of the sorting network (in registers up to 1024 entries; chunks of 1024 in registers merged
+    through LDS up to 4096; on global memory beyond)."""
     kw, _ = make_case(n, 16, 16, 0, 100 + n, log_scale=math.log(0.5), log_scale_std=0.1, precomp_color=True)
     kw["opacities"] = np.full_like(kw["opacities"], 0.9)
     r = _raw_forward(kw, dev)
