@@ -282,7 +282,7 @@ typedef struct ScorpGs3dTrainView {
   const float *gt;               /* [3,H,W] */
   const float *mask;             /* [H,W] or NULL */
   float lambda_dssim;
-  float _pad;
+  uint32_t backward_flags;       /* flags of scorp_gs3d_backward_ex for the view's backward (SCORP_BACKWARD_EXACT_FP32, ...); 0 = default */
   float *out_loss3;              /* device: {loss, l1, ssim} */
   void *loss_workspace;          /* scorp_loss_workspace_bytes(3, H, W) */
   size_t loss_workspace_bytes;

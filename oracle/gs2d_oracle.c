@@ -327,6 +327,13 @@ void gs2d_oracle_tiles(const Gs2State *S, int64_t *tile_start, int *point_list) 
  * means3D[N,3], means2D[N,3] (the densification statistic: dL/dTu.z, dL/dTv.z scaled by depth*W/2, depth*H/2),
  * shs[N,K,3], colors[N,3], opacities[N], scales[N,2], rotations[N,4], transmat[N,9] (precomputed-transform path).
  */
+/* Serial by default (deterministic accumulation order).  gs2d_oracle_parallel_backward(1): tiles in parallel, the
+ * per-surfel accumulators updated atomically - same arithmetic per term, summation order no longer fixed.  For the
+ * full-size parity tests and timings only (tests/test_fullsize_gpu.py), like gs3d_oracle_parallel_backward. */
+static int g2_parallel_backward = 0;
+void gs2d_oracle_parallel_backward(int on) { g2_parallel_backward = on; }
+#define ACC2(dst, val) do { REAL v_ = (val); if (par) { _Pragma("omp atomic") dst += v_; } else { dst += v_; } } while (0)
+
 void gs2d_oracle_backward(const Gs2State *S, const REAL *dL_dcolor, const REAL *dL_dallmap, REAL *g_means3D,
                           REAL *g_means2D, REAL *g_shs, REAL *g_colors, REAL *g_opac, REAL *g_scales, REAL *g_rot,
                           REAL *g_transmat) {
@@ -337,6 +344,8 @@ void gs2d_oracle_backward(const Gs2State *S, const REAL *dL_dcolor, const REAL *
   REAL *a_rgb = (REAL *)calloc(n * 3, sizeof(REAL));
   int tiles = S->tiles_x * S->tiles_y;
   const REAL fn = GS_FAR_Z / (GS_FAR_Z - GS_NEAR_Z);
+  const int par = g2_parallel_backward;
+#pragma omp parallel for schedule(dynamic, 4) if (par)
   for (int tile = 0; tile < tiles; tile++) {
     int tx0 = (tile % S->tiles_x) * GS_TILE, ty0 = (tile / S->tiles_x) * GS_TILE;
     int64_t beg = S->tile_start[tile];
@@ -371,7 +380,7 @@ void gs2d_oracle_backward(const Gs2State *S, const REAL *dL_dcolor, const REAL *
             acc_c[c] = last_alpha * last_c[c] + (1 - last_alpha) * acc_c[c];
             last_c[c] = col;
             dL_dal += (col - acc_c[c]) * dpix[c];
-            a_rgb[3 * (size_t)g + c] += w * dpix[c];
+            ACC2(a_rgb[3 * (size_t)g + c], w * dpix[c]);
           }
           REAL m_d = fn * (1 - GS_NEAR_Z / h.depth);
           REAL dmd_dd = (GS_FAR_Z * GS_NEAR_Z) / ((GS_FAR_Z - GS_NEAR_Z) * h.depth * h.depth);
@@ -389,7 +398,7 @@ void gs2d_oracle_backward(const Gs2State *S, const REAL *dL_dcolor, const REAL *
             acc_n[c] = last_alpha * last_n[c] + (1 - last_alpha) * acc_n[c];
             last_n[c] = no[c];
             dL_dal += (no[c] - acc_n[c]) * dnrm[c];
-            a_nrm[3 * (size_t)g + c] += w * dnrm[c];
+            ACC2(a_nrm[3 * (size_t)g + c], w * dnrm[c]);
           }
           dL_dal *= T;
           last_alpha = h.alpha;
@@ -405,16 +414,16 @@ void gs2d_oracle_backward(const Gs2State *S, const REAL *dL_dcolor, const REAL *
             REAL dl[3] = {dp[1] * h.k[2] - dp[2] * h.k[1], dp[2] * h.k[0] - dp[0] * h.k[2], dp[0] * h.k[1] - dp[1] * h.k[0]};
             const REAL dz_dTw[3] = {h.s[0], h.s[1], 1};
             for (int q = 0; q < 3; q++) {
-              aT[q] += -dk[q];
-              aT[3 + q] += -dl[q];
-              aT[6 + q] += (REAL)px * dk[q] + (REAL)py * dl[q] + dL_dz * dz_dTw[q];
+              ACC2(aT[q], -dk[q]);
+              ACC2(aT[3 + q], -dl[q]);
+              ACC2(aT[6 + q], (REAL)px * dk[q] + (REAL)py * dl[q] + dL_dz * dz_dTw[q]);
             }
           } else {
-            a_xy[2 * (size_t)g] += dL_dG * (-h.G * GS_FILTER_INV_SQ * h.d[0]);
-            a_xy[2 * (size_t)g + 1] += dL_dG * (-h.G * GS_FILTER_INV_SQ * h.d[1]);
-            aT[8] += dL_dz;
+            ACC2(a_xy[2 * (size_t)g], dL_dG * (-h.G * GS_FILTER_INV_SQ * h.d[0]));
+            ACC2(a_xy[2 * (size_t)g + 1], dL_dG * (-h.G * GS_FILTER_INV_SQ * h.d[1]));
+            ACC2(aT[8], dL_dz);
           }
-          a_op[g] += h.G * dL_dal;
+          ACC2(a_op[g], h.G * dL_dal);
         }
       }
   }

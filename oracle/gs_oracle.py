@@ -42,8 +42,10 @@ def _p(a):
 
 
 def set_parallel_backward(on, dtype=np.float32):
-    """Tiles of the backward replay in parallel (atomic accumulation; order no longer deterministic). Timing only."""
+    """Tiles of the backward replay in parallel (atomic accumulation; order no longer deterministic): the CPU-baseline
+    timing and the full-size parity tests.  Both rasterizers' oracles."""
     _lib(dtype).gs3d_oracle_parallel_backward(ctypes.c_int(1 if on else 0))
+    _lib(dtype).gs2d_oracle_parallel_backward(ctypes.c_int(1 if on else 0))
 
 
 class OracleRender:

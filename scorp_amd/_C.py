@@ -35,7 +35,7 @@ class ScorpGs3dTrainView(ctypes.Structure):
                 ("state_bytes", ctypes.c_size_t), ("pairs", ctypes.c_void_p), ("capacity", ctypes.c_uint64),
                 ("out_color", ctypes.c_void_p), ("out_depth_raw", ctypes.c_void_p), ("out_alpha", ctypes.c_void_p),
                 ("out_depth", ctypes.c_void_p), ("out_visible", ctypes.c_void_p), ("gt", ctypes.c_void_p),
-                ("mask", ctypes.c_void_p), ("lambda_dssim", ctypes.c_float), ("_pad", ctypes.c_float),
+                ("mask", ctypes.c_void_p), ("lambda_dssim", ctypes.c_float), ("backward_flags", ctypes.c_uint32),
                 ("out_loss3", ctypes.c_void_p), ("loss_workspace", ctypes.c_void_p), ("loss_workspace_bytes", ctypes.c_size_t),
                 ("grad_color", ctypes.c_void_p), ("grads", ctypes.c_void_p), ("backward_scratch", ctypes.c_void_p),
                 ("backward_scratch_bytes", ctypes.c_size_t)]

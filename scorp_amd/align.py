@@ -6,7 +6,9 @@ hypothesis is scored by rendering the (SH0) object under the rotation from a han
 comparing alpha + depth with the cached target renders (the role of the original-scene renders at :336-368).
 Hypotheses are independent, so they shard over ranks (scorp_amd.parallel.sweep) with one gather at the end.
 """
+import contextlib
 import copy
+import logging
 
 import torch
 
@@ -64,6 +66,9 @@ def hypothesis_fitness(model, R, cameras, targets, bg, render_fn=render):
     return -(err / len(cameras))
 
 
+log = logging.getLogger("scorp_amd.align")
+
+
 class SweepPlan:
     """Everything of a rotation sweep that does not depend on the hypothesis, built once: on a GPU one hypothesis (rotate
     + len(cameras) renders + comparison) is captured as a HIP graph and `score()` replays it per rotation - the sweep's
@@ -76,24 +81,40 @@ class SweepPlan:
         self.model, self.cameras, self.targets, self.bg, self.render_fn = model, cameras, targets, bg, render_fn
         self.dev = model._xyz.device
         self.graph = None
+        self.reserve = 0        # this plan's pair-reservation floor: applied only inside its own calls (_reserved)
+        self.fallback_reason = None
         if use_graph is None:
             use_graph = self.dev.type == "cuda" and render_fn is render
         if use_graph:
             try:
                 self._capture()
-            except Exception:   # capture unsupported: the eager path is always correct
+            except Exception as e:   # capture unsupported: the eager path is always correct - but SAY so (1.5x slower)
                 torch.cuda.synchronize()
                 self.graph = None
+                self.fallback_reason = f"capture failed: {type(e).__name__}: {e}"
+                log.warning("SweepPlan: HIP-graph capture failed (%s); hypotheses will be scored with eager launches", self.fallback_reason)
+
+    @contextlib.contextmanager
+    def _reserved(self):
+        """PairPolicy.reserve raised to this plan's floor for the duration of one of its calls, restored afterwards (the
+        plan used to leave its small floor behind as the process-wide default of every later context)."""
+        prev = PairPolicy.reserve
+        PairPolicy.reserve = max(prev, self.reserve)
+        try:
+            yield
+        finally:
+            PairPolicy.reserve = prev
 
     def _capture(self):
-        prev, pend_before = PairPolicy.mode, PairPolicy._pending
+        prev, pend_before, reserve_before = PairPolicy.mode, PairPolicy._pending, PairPolicy.reserve
         PairPolicy.mode = "reserve"
         try:
             PairPolicy._pending = []
             self.Rbuf = torch.eye(3, dtype=torch.float32, device=self.dev)
             hypothesis_fitness(self.model, self.Rbuf, self.cameras, self.targets, self.bg)
             worst = PairPolicy.drain()                       # sizes the reservation (raises if the default was too small)
-            PairPolicy.reserve = max(PairPolicy.reserve, int(2.0 * worst) + 4096)   # other rotations see other pair counts
+            self.reserve = int(2.0 * worst) + 4096           # other rotations see other pair counts
+            PairPolicy.reserve = max(reserve_before, self.reserve)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -110,6 +131,7 @@ class SweepPlan:
         finally:
             PairPolicy.mode = prev
             PairPolicy._pending = pend_before
+            PairPolicy.reserve = reserve_before
 
     def score(self, rotations, ids):
         """Fitness (1-element float tensors) of the hypotheses `ids` of `rotations`."""
@@ -125,11 +147,15 @@ class SweepPlan:
                 n_pairs, overflow = (int(v) for v in worst_flags.tolist())   # the sweep's one synchronisation
                 if not overflow:
                     return out
-                PairPolicy.reserve = max(PairPolicy.reserve, int(1.25 * n_pairs) + 4096)
-            except Exception:
+                self.reserve = max(self.reserve, int(1.25 * n_pairs) + 4096)
+                self.fallback_reason = f"a replay needed {n_pairs} pairs, more than the captured reservation"
+            except Exception as e:
                 torch.cuda.synchronize()
+                self.fallback_reason = f"replay failed: {type(e).__name__}: {e}"
             self.graph = None   # reservation overflowed during replay / replay failed: eager from here on
-        return self._score_eager(rotations, ids)
+            log.warning("SweepPlan: leaving the captured plan (%s); eager launches from here on", self.fallback_reason)
+        with self._reserved():
+            return self._score_eager(rotations, ids)
 
     def _score_eager(self, rotations, ids):
         """Renders issued without host synchronisation (`PairPolicy` "reserve"), verified once per hypothesis; a hypothesis
@@ -164,6 +190,6 @@ def rotation_sweep(model, rotations, cameras, targets, bg, use_graph=None, plan=
         plan = SweepPlan(model, cameras, targets, bg, use_graph=use_graph, render_fn=render_fn)
     vals = plan.score(rotations, mine) if mine else []
     v = torch.stack(vals) if vals else torch.zeros((0, 1), dtype=torch.float32, device=dev)
-    ids, scores = gather_results(mine, v.to(dev))
+    ids, scores = gather_results(mine, v.to(dev), n_total=len(rotations))      # ONE fixed-size all-gather, no host sync
     best = int(ids[torch.argmax(scores[:, 0])]) if ids.numel() else -1
     return ids, scores, best

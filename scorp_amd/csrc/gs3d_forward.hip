@@ -789,11 +789,12 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
     {
       ProfScope prof(kKCountTiles, stream);
       const int tpp = L.tiles_per_pass();
-      static bool lds_attr_set = false;   // histograms above 64 KiB need the kernels' dynamic-LDS limit raised (once)
-      if (!lds_attr_set) {
-        (void)hipFuncSetAttribute((const void *)count_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4);
-        (void)hipFuncSetAttribute((const void *)scatter_pairs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4);
-        lds_attr_set = true;
+      // histograms above 64 KiB need the kernels' dynamic-LDS limit raised.  The attribute is PER DEVICE (a process that
+      // drives a second GPU must set it there too), so it is set whenever such a launch is about to happen - two cheap
+      // host calls, no process-global flag, no data race between threads - and its result is checked.
+      if ((size_t)tpp * 4 > 64 * 1024) {
+        SCORP_HIP_CHECK(hipFuncSetAttribute((const void *)count_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4));
+        SCORP_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_pairs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4));
       }
       count_tiles_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
           N, per_block, L.nb, tpp, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,

@@ -28,7 +28,8 @@ extern "C" int scorp_gs3d_train_view(const ScorpGs3dTrainView *v, scorp_stream_t
   if (int e = scorp_loss_l1_ssim_backward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,
                                           v->grad_color, stream)) return e;
   return scorp_gs3d_backward_ex(in, v->state, v->pairs, v->capacity, v->grad_color, nullptr, nullptr, v->grads,
-                                v->backward_scratch, v->backward_scratch_bytes, zero_here ? SCORP_BACKWARD_SCRATCH_ZEROED : 0u,
+                                v->backward_scratch, v->backward_scratch_bytes,
+                                (v->backward_flags & ~SCORP_BACKWARD_SCRATCH_ZEROED) | (zero_here ? SCORP_BACKWARD_SCRATCH_ZEROED : 0u),
                                 stream);
 }
 

@@ -369,7 +369,10 @@ class GaussianModel:
         import ctypes
         from . import _C
         L = _C.lib()
-        arena = self.__dict__.setdefault("_arena", {})
+        arena = self.__dict__.setdefault("_arena", {})          # key -> the spare FULL-capacity buffer
+        backing = self.__dict__.setdefault("_arena_cur", {})    # key -> the full-capacity buffer behind the live tensor
+        # (kept explicitly: nn.Parameter(buf[:n]) and .detach() have no ._base, so the capacity cannot be recovered from
+        # the live tensors, and a spare that lost its capacity made every later call allocate afresh)
         jobs, swaps = [], []
         for group in self.optimizer.param_groups:
             old = group["params"][0]
@@ -382,7 +385,7 @@ class GaussianModel:
                 row = src[0].numel() if src.shape[0] else int(torch.tensor(src.shape[1:]).prod()) if src.dim() > 1 else 1
                 key = (group["name"], kind)
                 spare = arena.get(key)
-                if spare is None or spare.shape[0] < n_out or spare.data_ptr() == src.data_ptr():
+                if spare is None or spare.shape[0] < n_out or spare.data_ptr() == src.data_ptr() or spare.shape[1:] != src.shape[1:]:
                     cap = max(int(1.5 * n_out) + 1024, 1)
                     spare = torch.empty((cap,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
                 dst = spare[:n_out]
@@ -400,13 +403,15 @@ class GaussianModel:
             mine = {kind: (src, spare, dst, key) for g, kind, src, spare, dst, key in swaps if g is group}
             src, spare, dst, key = mine["p"]
             new = nn.Parameter(dst.requires_grad_(old.requires_grad))
-            arena[key] = src._base if src._base is not None else src          # the old storage becomes the spare half
+            arena[key] = backing.get(key, src)          # the old storage (its full buffer) becomes the spare half
+            backing[key] = spare
             if state is not None:
                 for kind, field in (("m", "exp_avg"), ("v", "exp_avg_sq")):
                     if kind in mine:
                         s_, _, d_, k_ = mine[kind]
                         state[field] = d_
-                        arena[k_] = s_._base if s_._base is not None else s_
+                        arena[k_] = backing.get(k_, s_)
+                        backing[k_] = mine[kind][1]
                 self.optimizer.state[new] = state
             group["params"][0] = new
             setattr(self, _ATTR[group["name"]], new)

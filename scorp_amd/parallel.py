@@ -39,16 +39,37 @@ def broadcast_tensors(tensors, src=0):
     return tensors
 
 
-def gather_results(ids, values):
-    """All ranks receive every (id, value-row) pair, ordered by id.  `ids`: int64[m]; `values`: float32[m, c]."""
+def gather_results(ids, values, n_total=None):
+    """All ranks receive every (id, value-row) pair, ordered by id.  `ids`: int64[m]; `values`: float32[m, c].
+
+    With `n_total` (the units were dealt by `shard_indices(n_total)`, as every caller here does) the exchange is ONE
+    fixed-size all-gather and no host synchronisation: every rank's share is at most ceil(n_total / world) rows, so the
+    padded size is known without asking, ids ride in the same buffer as a float column (exact below 2^24) and the padding
+    is removed by construction (rank r holds ids r, r + world, ...).  Without it (ragged, unknown shares) the counts are
+    exchanged first."""
     _, w = world()
-    ids = torch.as_tensor(ids, dtype=torch.int64, device=values.device)
+    dev = values.device
+    ids = torch.as_tensor(ids, dtype=torch.int64, device=dev)
+    if w > 1 and n_total is not None and n_total < (1 << 24):
+        m, c = -(-int(n_total) // w), values.shape[1]
+        buf = torch.full((m, c + 1), -1.0, dtype=torch.float32, device=dev)
+        buf[: ids.numel(), 0] = ids.to(torch.float32)
+        buf[: ids.numel(), 1:] = values.to(torch.float32)
+        out = torch.empty((w * m, c + 1), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out, buf)
+        # rank r's row k is unit r + k * world: the valid rows and their order follow from n_total alone
+        unit = torch.arange(w * m, device=dev)
+        unit = (unit // m) + (unit % m) * w
+        keep = unit < n_total
+        order = torch.argsort(unit[keep])
+        rows = out[keep][order]
+        return rows[:, 0].to(torch.int64), rows[:, 1:].to(values.dtype)
     if w > 1:
-        counts = [torch.zeros(1, dtype=torch.int64, device=values.device) for _ in range(w)]
-        dist.all_gather(counts, torch.tensor([ids.numel()], dtype=torch.int64, device=values.device))
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(w)]
+        dist.all_gather(counts, torch.tensor([ids.numel()], dtype=torch.int64, device=dev))
         m = int(max(c.item() for c in counts))
-        pad_i = torch.full((m,), -1, dtype=torch.int64, device=values.device)
-        pad_v = torch.zeros((m, values.shape[1]), dtype=values.dtype, device=values.device)
+        pad_i = torch.full((m,), -1, dtype=torch.int64, device=dev)
+        pad_v = torch.zeros((m, values.shape[1]), dtype=values.dtype, device=dev)
         pad_i[: ids.numel()] = ids
         pad_v[: ids.numel()] = values
         gi = [torch.empty_like(pad_i) for _ in range(w)]
@@ -70,7 +91,7 @@ def sweep(n_units, score_fn, device="cpu"):
     vals = [score_fn(i).reshape(-1).float() for i in mine]
     c = vals[0].numel() if vals else 1
     v = torch.stack(vals) if vals else torch.zeros((0, c), dtype=torch.float32, device=device)
-    ids, scores = gather_results(mine, v.to(device))
+    ids, scores = gather_results(mine, v.to(device), n_total=n_units)
     best = int(ids[torch.argmax(scores[:, 0])]) if ids.numel() else -1
     return ids, scores, best
 

@@ -35,11 +35,12 @@ class GaussianRasterizationSettings(NamedTuple):
 
 class _Pending:
     """One forward issued without a host synchronisation: a copy of its 64-byte StateHeader (pair count, overflow flag),
-    the event recorded behind that copy on the stream that produced it, and the reservation context it belongs to."""
-    __slots__ = ("header", "event", "key")
+    the event recorded behind that copy on the stream that produced it, the reservation context it belongs to and the
+    number of Gaussians it rendered."""
+    __slots__ = ("header", "event", "key", "n")
 
-    def __init__(self, header, event, key):
-        self.header, self.event, self.key = header, event, key
+    def __init__(self, header, event, key, n=0):
+        self.header, self.event, self.key, self.n = header, event, key, int(n)
 
     def numel(self):
         return self.header.numel()
@@ -54,29 +55,39 @@ class PairPolicy:
               each forward is queued for `drain()`, which waits for the forward's own stream, raises if any view
               overflowed and grows that context's reservation.  For throughput loops that check once per N views.
 
-    A context is (number of Gaussians, image height, image width, stream): the align loop changes resolution per
-    render, densification changes N, `bench.py --streams` runs views on several streams — each gets its own
-    reservation instead of one process-wide number.  `reserve` is only a caller-set FLOOR for every context (0 = none);
-    `mode` / `slack` are configuration.  A context nobody has sized yet starts at max(4 N, 2^20) pairs.
+    A context is (image height, image width, stream): the align loop changes resolution per render, `bench.py
+    --streams` runs views on several streams — each gets its own reservation instead of one process-wide number.  What a
+    context remembers is pairs PER GAUSSIAN at the model size it was learned on: when the model grows or shrinks
+    (densify_and_prune, every 100 iterations) the reservation scales with it instead of starting again from a default
+    (a scene that needs more than 4 pairs per Gaussian used to overflow after every densification).  `reserve` is only
+    a caller-set FLOOR for every context (0 = none); `mode` / `slack` are configuration.  A context nobody has sized yet
+    starts at max(4 N, 2^20) pairs.
     """
     mode = "exact"
     slack = 1.25
     reserve = 0          # pairs: floor applied to every context (callers that know their workload set it)
-    _ctx = {}            # context key -> reserved pairs learned by drain()
+    _ctx = {}            # context key -> (reserved pairs, number of Gaussians they were learned on)
     _pending = []        # _Pending entries whose overflow flag has not been read yet
+    _MAX_CTX = 64        # contexts kept (least recently learned dropped first)
 
     @classmethod
     def key(cls, N, H, W):
-        return (int(N), int(H), int(W), int(torch.cuda.current_stream().cuda_stream))
+        return (int(H), int(W), int(torch.cuda.current_stream().cuda_stream))
 
     @classmethod
     def capacity(cls, N, H, W):
         """Pairs to reserve for a forward of this context."""
-        k = cls.key(N, H, W)
-        got = cls._ctx.get(k, 0)
+        got, n0 = cls._ctx.get(cls.key(N, H, W), (0, 0))
+        if got > 0 and n0 > 0 and int(N) != n0:
+            got = max(int(got * (int(N) / n0)) + 1024, 1 << 16)     # same pairs per Gaussian on the resized model
         if got <= 0 and cls.reserve <= 0:
             got = max(4 * int(N), 1 << 20)
         return max(got, int(cls.reserve))
+
+    @classmethod
+    def set_context(cls, N, H, W, pairs):
+        """Seed / override the reservation of the current stream's (H, W) context (tests, callers that know their scene)."""
+        cls._ctx[cls.key(N, H, W)] = (int(pairs), int(N))
 
     @classmethod
     def pend(cls, state, N, H, W):
@@ -90,7 +101,7 @@ class PairPolicy:
             hdr = state[:64].clone()     # not the state itself, or every pending view would pin ~100 MB until the drain
             ev = torch.cuda.Event()
             ev.record()
-        cls._pending.append(_Pending(hdr, ev, cls.key(N, H, W)))
+        cls._pending.append(_Pending(hdr, ev, cls.key(N, H, W), N))
         return hdr
 
     @classmethod
@@ -107,7 +118,13 @@ class PairPolicy:
             code = L.scorp_gs3d_check_overflow(p.header.data_ptr(), _stream(), ctypes.byref(n))
             worst = max(worst, n.value)
             if p.key is not None:
-                cls._ctx[p.key] = max(cls._ctx.get(p.key, 0), int(n.value * cls.slack) + 1024)
+                need = int(n.value * cls.slack) + 1024
+                got, n0 = cls._ctx.pop(p.key, (0, 0))
+                if n0 > 0 and p.n > 0 and n0 != p.n:
+                    got = int(got * (p.n / n0))                       # what was learned, at this view's model size
+                cls._ctx[p.key] = (max(got, need), p.n if p.n > 0 else n0)   # (re-inserted last: most recently learned)
+                while len(cls._ctx) > cls._MAX_CTX:
+                    cls._ctx.pop(next(iter(cls._ctx)))
             if code != 0 and err is None:
                 err = L.scorp_last_error().decode()
         if err:

@@ -46,6 +46,16 @@ def _sync_densification_stats(gaussians):
         dist.all_reduce(gaussians.max_radii2D, op=dist.ReduceOp.MAX)
 
 
+def _shared_overflow(pkg, data_parallel):
+    """Data-parallel replicas must discard an iteration TOGETHER: the overflow word of a fused view is per rank, and a rank
+    that skipped its Adam step alone would stop being bit-identical to the others (next densification: different N,
+    mismatched all-reduce shapes).  One 4-byte all-reduce(MAX) on the device word, no host synchronisation; the reduced
+    word then guards the optimizer step and masks the statistics on every rank."""
+    if data_parallel and world()[1] > 1:
+        dist.all_reduce(pkg["overflow"], op=dist.ReduceOp.MAX)
+    return pkg["overflow"]
+
+
 def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteration, scene_extent=4.0, densify=True,
                        render_fn=render, loss_fn=fused_l1_ssim_loss, data_parallel=False, gt_depth=None, gt_depth_est=None,
                        surfels=False, fused_view=False, white_background=False, sparse_gradients=False):
@@ -66,9 +76,10 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
         lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
         pkg = train_view2d(cam, gaussians, pipe, bg, gt_image, opt.lambda_dssim, lambda_normal, lambda_dist)
         loss = pkg["loss"]
+        ovf = _shared_overflow(pkg, data_parallel)
         if hasattr(gaussians.optimizer, "skip_flag"):
-            gaussians.optimizer.skip_flag = pkg["overflow"]
-        pkg["visibility_filter"] = pkg["visibility_filter"] & (pkg["overflow"] == 0)
+            gaussians.optimizer.skip_flag = ovf
+        pkg["visibility_filter"] = pkg["visibility_filter"] & (ovf == 0)
     elif (fused_view and not surfels and not extra_terms and render_fn is render and loss_fn is fused_l1_ssim_loss
             and getattr(pipe, "fused_activations", False)):
         # plain photometric iteration: render + loss + backward enqueued by ONE library call (train_view.py); same
@@ -79,9 +90,10 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
         # The pair buffer was reserved, not sized from this view's count.  If the view overflowed it (device word
         # pkg["overflow"]), its gradients come from truncated tile lists: the optimizer step is skipped on the device and
         # the densification statistics below are masked - no host synchronisation, nothing wrong is ever applied.
+        ovf = _shared_overflow(pkg, data_parallel)      # BEFORE the gradients are averaged and the flag is used
         if hasattr(gaussians.optimizer, "skip_flag"):
-            gaussians.optimizer.skip_flag = pkg["overflow"]
-        pkg["visibility_filter"] = pkg["visibility_filter"] & (pkg["overflow"] == 0)
+            gaussians.optimizer.skip_flag = ovf
+        pkg["visibility_filter"] = pkg["visibility_filter"] & (ovf == 0)
     else:
         pkg = render_fn(cam, gaussians, pipe, bg)
         loss = loss_fn(pkg["render"], gt_image, opt.lambda_dssim)
@@ -103,8 +115,12 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
     with torch.no_grad():
         if data_parallel:
             ps = [g["params"][0] for g in gaussians.optimizer.param_groups]
-            if sparse_gradients:   # only the rows some rank rendered travel (parallel.average_gradients_sparse)
-                average_gradients_sparse(ps, pkg["visibility_filter"])
+            # Only the rows some rank rendered travel (parallel.average_gradients_sparse) - valid only while every loss term
+            # flows through the rasterizer: the isotropic regulariser gives EVERY Gaussian a scaling gradient, a
+            # caller-supplied render / loss function may do anything, and then the dense average is the right one.
+            rasterizer_only = not extra_terms and loss_fn is fused_l1_ssim_loss and (render_fn is render or surfels)
+            if sparse_gradients and rasterizer_only:
+                average_gradients_sparse(ps, pkg["radii"] > 0)    # (the view's own visibility: not masked by an overflow)
             else:
                 average_gradients(ps)
         if densify and iteration < opt.densify_until_iter:
@@ -117,8 +133,10 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
                     _sync_densification_stats(gaussians)
                     torch.manual_seed(1_000_003 * iteration)   # densify_and_split samples positions: same draw on every rank
                 gaussians.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, scene_extent, size_threshold)
-                # (a different number of Gaussians is a new PairPolicy context: the fused view starts again from the
-                # default reservation of max(4 N, 2^20) pairs and drain() sizes it from what the views needed)
+                if fused_view:
+                    # the reservation context keeps pairs PER GAUSSIAN, so the resized model starts from a scaled
+                    # reservation; drain now so that it is also the freshest figure (one event wait per 100 iterations)
+                    _drain_reservation()
             if iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter):
                 gaussians.reset_opacity()   # train_3dgs.py:187-188
         gaussians.optimizer.step()

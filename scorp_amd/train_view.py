@@ -19,7 +19,7 @@ import math
 import torch
 
 from . import _C
-from .rasterizer3d import GaussianRasterizationSettings, PairPolicy, _inputs_struct, _prep, _ptr, _stream
+from .rasterizer3d import GaussianRasterizationSettings, PairPolicy, _inputs_struct, _prep, _ptr, _stream, _tls
 
 
 def _accumulate(p, g):
@@ -80,6 +80,7 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     v.out_color, v.out_depth_raw, v.out_alpha = color.data_ptr(), depth_raw.data_ptr(), alpha.data_ptr()
     v.out_depth, v.out_visible = depth.data_ptr(), visible.data_ptr()
     v.gt, v.mask, v.lambda_dssim = gt.data_ptr(), (None if mask is None else mask.data_ptr()), float(lambda_dssim)
+    v.backward_flags = int(getattr(_tls, "backward_flags", 0))     # rasterizer3d.backward_precision("exact_fp32") reaches the one-call view too
     v.out_loss3, v.loss_workspace, v.loss_workspace_bytes = loss3.data_ptr(), ws.data_ptr(), ws_bytes
     v.grad_color, v.grads = grad_color.data_ptr(), ctypes.addressof(grads)
     v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes

@@ -1,0 +1,252 @@
+"""BASELINE.json's configurations at their FULL sizes on the GPU (round 2 ran #2, #3, #4 only in miniature, and compared
+full-size frames with the oracle only inside bench.py):
+
+  * S3 (1 M Gaussians), S2 (500 k) and S6 (1 M surfels) at 1600x1200, SH3: one view, forward AND backward, against the
+    CPU oracle (OpenMP; its backward with tiles in parallel) - radii bit-exact, images within 1e-4 mean L1, every
+    gradient tensor within 1e-4 relative L1 (north_star's tolerance) through tests.util.assert_grad_close;
+  * config #2: one train_3dgs iteration on S2 - the one-call view equals render + loss + backward, the fused Adam step
+    leaves finite parameters, one densify-and-prune at 500 k equals the sequential surgery;
+  * config #3: the 128-rotation sweep on S4 (100 k Gaussians x 128 hypotheses x 15 cameras at 800x800): the planted
+    rotation is recovered, the captured plan equals eager launches;
+  * config #4: post-refinement of 4 x 100 k SH0 objects as one model at 1600x1200: the colour-only replay's gradients
+    equal the full backward's, and only _features_dc moves.
+"""
+import copy
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need a GPU"
+    from scorp_amd import _C
+    _C.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def parallel_oracle():
+    from oracle import gs_oracle
+    os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0))))
+    gs_oracle.set_parallel_backward(True, np.float32)
+    gs_oracle.set_parallel_backward(True, np.float64)
+    yield
+    gs_oracle.set_parallel_backward(False, np.float32)
+    gs_oracle.set_parallel_backward(False, np.float64)
+
+
+def _scene_kw(name, cam_index=0):
+    from scorp_amd.synthetic import SCENES, activate, scene
+    raw, cams, deg = scene(name, n_cameras=None)
+    N, W, H = SCENES[name][:3]
+    act = activate(raw)
+    cam = cams[cam_index]
+    return dict(means3D=act["means3D"], opacities=act["opacities"], shs=act["shs"], sh_degree=deg, scales=act["scales"],
+                rotations=act["rotations"], W=W, H=H, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2),
+                view=cam.world_view_transform.numpy().astype(np.float32), proj=cam.full_proj_transform.numpy().astype(np.float32),
+                campos=cam.camera_center.numpy().astype(np.float32), bg=np.zeros(3, np.float32))
+
+
+@pytest.mark.parametrize("name", ["S3", "S2"])
+def test_full_size_parity_vs_oracle(name, dev, parallel_oracle):
+    """One full-size 3DGS view, forward + backward (upstream gradients on colour, depth and alpha), HIP against oracle."""
+    from tests.test_gs3d_gpu import compare_forward, compare_grads, hip_render, oracle, oracle64_grads
+    from tests.util import image_weights
+    kw = _scene_kw(name)
+    o = oracle(kw)
+    out, t = hip_render(kw, dev)
+    compare_forward(out, o)
+    wc, wd, wa = image_weights(kw["H"], kw["W"], 3)
+    color, _, depth, alpha = out
+    ((color * torch.tensor(wc, device=dev)).sum() + (depth * torch.tensor(wd, device=dev)).sum()
+     + (alpha * torch.tensor(wa, device=dev)).sum()).backward()
+    report = {}
+    compare_grads(t, o.backward(wc, wd, wa), report=report, g64_fn=oracle64_grads(kw, wc, wd, wa))
+    print(f"\n{name} full size: image L1 {np.abs(out[0].detach().cpu().numpy() - o.color).mean():.2e}; gradients (max-norm, rel L1): "
+          + ", ".join(f"{k} {v[0]:.1e}/{v[1]:.1e}" for k, v in report.items()))
+
+
+def test_full_size_parity_vs_oracle_photometric(dev, parallel_oracle):
+    """S3 with the upstream gradient the training step produces (colour only, 1 / (3 H W) per element): the default
+    (fp16-split) and the exact-fp32 backward, each against the oracle."""
+    from scorp_amd.rasterizer3d import backward_precision
+    from tests.test_gs3d_gpu import compare_grads, hip_render, oracle, oracle64_grads
+    kw = _scene_kw("S3")
+    o = oracle(kw)
+    w = np.full((3, kw["H"], kw["W"]), 1.0 / (3 * kw["H"] * kw["W"]), np.float32)
+    g = o.backward(w, None, None)
+    for precision in ("split", "exact_fp32"):
+        with backward_precision(precision):
+            out, t = hip_render(kw, dev)
+        (out[0] * torch.tensor(w, device=dev)).sum().backward()
+        compare_grads(t, g, g64_fn=oracle64_grads(kw, w, None, None))
+
+
+def test_full_size_parity_vs_oracle_2d(dev, parallel_oracle):
+    """S6: 1 M surfels at 1600x1200, SH3 - the 2-D oracle's first full-size frame."""
+    from tests.test_gs2d_gpu import _parity_2d
+    kw = _scene_kw("S6")
+    kw["scale_modifier"] = 1.0
+    report = {}
+    _parity_2d(dict(seed=6), dev, report=report, kw=kw)
+    print("\nS6 full size: gradients (max-norm, rel L1): " + ", ".join(f"{k} {v[0]:.1e}/{v[1]:.1e}" for k, v in report.items()))
+
+
+class _Pipe:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+    fused_activations = True
+
+
+def test_config2_full_size_training_iteration(dev):
+    """BASELINE config #2 at its size: S2 (500 k Gaussians, 1600x1200, SH3).  (a) scorp_gs3d_train_view == render() +
+    fused loss + backward (images bit for bit, gradients to atomics noise); (b) a full training_iteration with FusedAdam
+    leaves finite parameters and moves them; (c) ONE densify_and_prune at 500 k equals the sequential torch surgery."""
+    from scorp_amd.fused_loss import fused_l1_ssim_loss
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.renderer import render
+    from scorp_amd.synthetic import SCENES, make_gaussians, ring_cameras
+    from scorp_amd.train import training_iteration
+    from scorp_amd.train_view import train_view
+    N, W, H, deg, seed, _ = SCENES["S2"]
+    raw = make_gaussians(N, deg, seed)
+    cam = ring_cameras(280, W, H, seed, device=dev)[11]
+    bg, pipe = torch.zeros(3, device=dev), _Pipe()
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    a = GaussianModel.from_raw(raw, deg, device=dev); a.active_sh_degree = deg
+    b = GaussianModel.from_raw(raw, deg, device=dev); b.active_sh_degree = deg
+    with torch.no_grad():
+        gt = (render(cam, a, pipe, bg)["render"] + 0.05 * torch.randn(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(2))).clamp(0, 1)
+    PairPolicy.reset()
+    try:
+        pa = render(cam, a, pipe, bg)
+        la = fused_l1_ssim_loss(pa["render"], gt, 0.2)
+        la.backward()
+        pb = train_view(cam, b, pipe, bg, gt, 0.2)
+        PairPolicy.drain()
+        assert torch.equal(pa["render"], pb["render"]) and torch.equal(pa["radii"], pb["radii"])
+        assert torch.equal(pa["render_depth"], pb["render_depth"]) and torch.equal(pa["visibility_filter"], pb["visibility_filter"])
+        assert float(la) == float(pb["loss"])
+        for n in names:
+            ga, gb = getattr(a, n).grad, getattr(b, n).grad
+            l1 = float((ga - gb).abs().sum() / ga.abs().sum())
+            assert l1 < 2e-5 and float((ga - gb).abs().max()) <= 2e-3 * float(ga.abs().max()), (n, l1)
+        del a, pa, pb
+        # (b) the whole iteration: LR schedule, random background, one-call view, statistics, guarded FusedAdam
+        opt = OptimizationParams()
+        for n in names:
+            getattr(b, n).grad = None
+        b.training_setup(opt)
+        before = b._xyz.detach().clone()
+        loss, pkg = training_iteration(b, cam, gt, opt, pipe, bg, 1001, fused_view=True)
+        PairPolicy.drain()
+        assert math.isfinite(float(loss)) and int(pkg["overflow"]) == 0
+        for n in names:
+            assert bool(torch.isfinite(getattr(b, n)).all()), n
+        assert not torch.equal(before, b._xyz.detach())
+        assert float(b.denom.sum()) == float(pkg["visibility_filter"].sum())
+    finally:
+        PairPolicy.reset()
+    # (c) densify + prune at 500 k: fused row plan + one gather launch against the sequential surgery
+    models = []
+    for fused in (False, True):
+        m = GaussianModel.from_raw(raw, deg, device=dev)
+        m.training_setup(OptimizationParams())
+        m.fused_densify = fused
+        models.append(m)
+    g = torch.Generator(device=dev).manual_seed(3)
+    grads_acc = torch.rand(N, 1, device=dev, generator=g) * 4e-4
+    denom = torch.randint(0, 3, (N, 1), device=dev, generator=g).float()
+    for m in models:
+        m.xyz_gradient_accum, m.denom, m.max_radii2D = grads_acc.clone(), denom.clone(), torch.zeros(N, device=dev)
+        torch.manual_seed(77)
+        m.densify_and_prune(2e-4, 0.3, 4.0, 20)
+    ma, mb = models
+    assert ma.get_xyz.shape[0] == mb.get_xyz.shape[0] != N
+    for n in names:
+        assert torch.equal(getattr(ma, n).detach(), getattr(mb, n).detach()), n
+
+
+def test_config3_full_size_rotation_sweep(dev):
+    """BASELINE config #3 at its size: S4 - a 100 k-Gaussian SH0 object, rotations_128.npz x 15 cameras at 800x800,
+    forward only: the planted rotation wins, the captured plan and eager launches give the same fitness."""
+    from scorp_amd.align import SweepPlan, render_views, rotation_sweep
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.transforms import gaussians_rotate
+    rots = np.load(os.path.join(os.path.dirname(__file__), "golden", "rotations_128.npz"))["rotations"]
+    raw = make_gaussians(100_000, 0, 4, extent=0.8, log_scale_mean=math.log(0.01))
+    raw["xyz"][:, 0] *= 1.6
+    obj = GaussianModel.from_raw(raw, 0, device=dev)
+    cams = ring_cameras(15, 800, 800, 4, radius=3.0, device=dev)
+    bg = torch.zeros(3, device=dev)
+    planted = 77
+    tgt = copy.copy(obj)
+    tgt._xyz, tgt._rotation, tgt._features_rest = obj._xyz.detach().clone(), obj._rotation.detach().clone(), obj._features_rest.detach().clone()
+    gaussians_rotate(tgt, torch.tensor(rots[planted], dtype=torch.float32, device=dev), fix_center=True)
+    PairPolicy.reset()
+    try:
+        targets = render_views(tgt, cams, bg)
+        plan = SweepPlan(obj, cams, targets, bg)
+        assert plan.graph is not None, "the sweep's plan was not captured"
+        ids, fit, best = rotation_sweep(obj, rots, cams, targets, bg, plan=plan)
+        assert plan.graph is not None, "the captured plan fell back to eager launches during the sweep"
+        assert ids.numel() == 128 and best == planted
+        assert float(fit[planted, 0]) > -1e-6 and float(fit[:, 0].sort().values[-2]) < float(fit[planted, 0]) - 1e-4
+        ids_e, fit_e, best_e = rotation_sweep(obj, rots, cams, targets, bg, use_graph=False)
+        assert best_e == planted and torch.equal(ids, ids_e)
+        assert float((fit - fit_e).abs().max()) < 1e-6
+    finally:
+        PairPolicy.reset()
+
+
+def test_config4_full_size_post_refine(dev):
+    """BASELINE config #4 at its size: 4 x 100 k SH0 objects refined as ONE model at 1600x1200 (post_refine_gs.py:40-56):
+    the colour-only replay gives the full backward's colour gradients, and post_refine() moves _features_dc only."""
+    from scorp_amd.fused_loss import fused_l1_ssim_loss
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.renderer import render
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import post_refine
+    raws = [make_gaussians(100_000, 0, 50 + k, extent=0.5, log_scale_mean=math.log(0.01)) for k in range(4)]
+    for k, r in enumerate(raws):
+        r["xyz"] += np.array([(k % 2) * 1.2 - 0.6, (k // 2) * 1.2 - 0.6, 0], np.float32)
+    merged = {kk: np.concatenate([r[kk] for r in raws]) for kk in raws[0]}
+    cams = ring_cameras(4, 1600, 1200, 9, device=dev)
+    bg, pipe = torch.zeros(3, device=dev), _Pipe()
+    full = GaussianModel.from_raw(merged, 0, device=dev)
+    with torch.no_grad():
+        pk = [render(c, full, pipe, bg) for c in cams]
+        gen = torch.Generator(device=dev).manual_seed(4)
+        gts = [(p["render"] + 0.1 * torch.randn(p["render"].shape, device=dev, generator=gen)).clamp(0, 1) for p in pk]
+        masks = [(p["render_alpha"] > 0.5).float() for p in pk]
+    PairPolicy.reset()
+    fused_l1_ssim_loss(render(cams[0], full, pipe, bg)["render"], gts[0], 0.2, mask=masks[0]).backward()
+    m = GaussianModel.from_raw(merged, 0, device=dev)
+    for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
+        getattr(m, n).requires_grad_(False)
+    pkg = render(cams[0], m, pipe, bg)
+    fused_l1_ssim_loss(pkg["render"], gts[0], 0.2, mask=masks[0]).backward()
+    assert pkg["viewspace_points"].grad is None
+    ga, gb = full._features_dc.grad, m._features_dc.grad
+    assert float((ga - gb).abs().sum() / ga.abs().sum()) < 5e-5 and float((ga - gb).abs().max()) <= 2e-4 * float(ga.abs().max())
+    del full, m
+    merged2 = dict(merged)
+    merged2["features_dc"] = merged["features_dc"] + np.random.default_rng(5).normal(0, 0.4, merged["features_dc"].shape).astype(np.float32)
+    student = GaussianModel.from_raw(merged2, 0, device=dev)
+    before = {n: getattr(student, n).detach().clone() for n in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc")}
+    losses = post_refine(student, cams, gts, masks, OptimizationParams(), iterations=16)
+    assert all(math.isfinite(v) for v in losses) and sum(losses[-4:]) < sum(losses[:4])      # (every camera once per four iterations)
+    for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
+        assert torch.equal(getattr(student, n).detach(), before[n]), n
+    assert not torch.equal(student._features_dc.detach(), before["_features_dc"])

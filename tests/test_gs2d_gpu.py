@@ -68,9 +68,11 @@ def test_forward_backward_parity_2d(name, dev):
     _parity_2d(CASES[name], dev)
 
 
-def _parity_2d(case, dev, report=None, outlier_gaussians=0):
+def _parity_2d(case, dev, report=None, outlier_gaussians=0, kw=None):
+    """`case`: arguments of make_case2d - or, with `kw` given (a full-size scene), only its "seed" is used."""
     from oracle.gs_oracle import OracleRender2D
-    kw, _ = make_case2d(**case)
+    if kw is None:
+        kw, _ = make_case2d(**case)
     o = OracleRender2D(np.float32, **kw)
     assert o.num_pairs > 0
     out, t = hip_render2d(kw, dev)

@@ -211,7 +211,7 @@ def test_overflowed_fused_view_is_discarded_on_the_device(dev):
     gt = torch.rand(3, 96, 128, device=dev)
     bg = torch.zeros(3, device=dev)
     try:
-        PairPolicy._ctx[PairPolicy.key(3000, 96, 128)] = 64          # far too few pairs for this view
+        PairPolicy.set_context(3000, 96, 128, 64)          # far too few pairs for this view
         before = [p.detach().clone() for p in (m._xyz, m._features_dc, m._opacity, m._scaling, m._rotation)]
         loss, pkg = training_iteration(m, cam, gt, opt, PipelineParams(), bg, 1, fused_view=True)
         assert int(pkg["overflow"]) != 0

@@ -78,6 +78,13 @@ def grad_errors(got, ref):
             float(np.abs(got - ref).sum() / max(np.abs(ref).sum(), 1e-300)))
 
 
+# How often a gradient tensor needed the oracle's own band (below) instead of passing against the fp32 oracle as it
+# stands.  tests/conftest.py prints the tally at the end of the session and FAILS the session if more than
+# SCORP_BAND_CAP tensors (default 24 of the ~1 700 checked by the -m gpu suite) needed it: the fallback must stay the
+# exception it was introduced as, and a kernel change that makes it the norm shows up here.
+BAND_TALLY = {"checked": 0, "fallback": 0, "names": []}
+
+
 def assert_grad_close(name, got, ref32, band_fn, max_tol, l1_tol, k=3.0):
     """A gradient tensor of the HIP path against the oracle.
 
@@ -93,8 +100,12 @@ def assert_grad_close(name, got, ref32, band_fn, max_tol, l1_tol, k=3.0):
     three gradient arrays).  It passes if, after allowing k x band per element, the remaining error meets the two
     tolerances, and if the elements that needed the allowance are few (< 0.5 %)."""
     e32 = grad_errors(got, ref32)
+    BAND_TALLY["checked"] += 1
     if e32[0] < max_tol and e32[1] < l1_tol:
         return e32
+    BAND_TALLY["fallback"] += 1
+    import os
+    BAND_TALLY["names"].append(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}:{name} max {e32[0]:.2e} L1 {e32[1]:.2e}")
     ref = np.asarray(ref32, np.float64)
     g = np.asarray(got, np.float64).reshape(ref.shape)
     band = np.zeros_like(ref)
