@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "exp_mfma.hpp"
 
 namespace scorp {
 namespace {
@@ -583,6 +584,193 @@ sort_tiles_long_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__rest
 // dead key region of the pair buffer) and per pixel the final T and the 1-based position IN THAT LIST of the last splat
 // that contributed: the backward replays the hit list and never looks at the tile's list again.
 // ---------------------------------------------------------------------------------------------------------
+#if SCORP_EXP_MFMA
+// The exponent log2(opacity * G) of a group of 16 hits at the block's 64 pixels comes from the matrix cores (exp_mfma.hpp:
+// three v_mfma_f32_32x32x16_bf16 against the lane's own monomials; register i of a lane = splat i at that lane's pixel):
+// the lane that stages a hit turns its record into the six block-frame coefficients, cut into three bf16 terms each, and a
+// ring slot holds those 48 bytes plus (r, g, b, depth).  The sequential blend then costs, per hit and pixel: v_exp, the
+// two threshold selects, the T update and four accumulations - the seven VALU instructions of the Horner form (35 % of the
+// old loop's issue time together with its LDS reads of the conic) are gone.  A hit's 1-based position in the block's hit
+// list is arithmetic (hits are blended in ring order): no position array.
+#ifndef SCORP_FWD_DB
+#define SCORP_FWD_DB 0
+#endif
+#ifndef SCORP_FWD_FMA
+#define SCORP_FWD_FMA 1
+#endif
+constexpr int kFRing = 96, kFChunk = 64, kFGroup = 16;   // ring: at most 15 left-over hits + 64 new ones
+
+// (__launch_bounds__(64, 2): at least two waves per SIMD, i.e. at most 256 registers - which is what lets the compiler keep
+// the MFMA results in VGPRs; with the accumulators in AGPRs every exponent costs a v_accvgpr_read before its v_exp)
+#ifndef SCORP_FWD_WAVES
+#define SCORP_FWD_WAVES 2
+#endif
+template <bool kForBackward>
+__global__ void __launch_bounds__(64, SCORP_FWD_WAVES)
+blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
+                          const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
+                          const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
+                          float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                          uint32_t *__restrict__ hits, uint32_t *__restrict__ block_hits, float *__restrict__ out_depth_norm,
+                          float4 *__restrict__ zero_buf, uint32_t zero_per_wave, uint32_t zero_total) {
+  __shared__ uint4 q_k[3][kFRing + 1];   // the three bf16 terms of a hit's six coefficients; slot kFRing stays zero
+  __shared__ float4 q_col[kFRing];       // r, g, b, depth
+  const int lane = threadIdx.x;
+  if (zero_buf) {   // this wave's share of the buffer the launch was asked to clear (every workgroup of the grid takes part)
+    const uint32_t z0 = blockIdx.x * zero_per_wave, z1 = min(z0 + zero_per_wave, zero_total);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v zero = {0.0f, 0.0f, 0.0f, 0.0f};   // streaming stores: the rows are not read before the backward, keep them out of L2
+    for (uint32_t z = z0 + lane; z < z1; z += 64) __builtin_nontemporal_store(zero, reinterpret_cast<f4v *>(zero_buf) + z);
+  }
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
+  if (tile >= tiles) return;
+  const int bx = (tile % tiles_x) * kTile + (quad & 1) * 8, by = (tile / tiles_x) * kTile + (quad >> 1) * 8;
+  const int px = bx + (lane & 7), py = by + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
+  const float cx = (float)bx + 3.5f, cy = (float)by + 3.5f;
+  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t n = end - beg;
+  uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
+  if (lane < 3) q_k[lane][kFRing] = make_uint4(0u, 0u, 0u, 0u);
+  const uint4 basis = pixel_basis_frag(lane);
+  const bool a_on = a_operand_active(lane);
+  const int a_slot = a_operand_slot(lane);
+  float T = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f;   // T < 0: pixel finished (see below)
+  uint32_t last = 0;
+  int head = 0, count = 0;   // head stays a multiple of kFGroup (only a wave's final group is partial), so the
+                             // slots of a group are head + i without wrap-around: one LDS base, immediate offsets
+  uint32_t nh = 0;           // hits found so far (wave-uniform)
+  uint32_t consumed = 0;     // hits blended so far: slot i of the next group is hit number consumed + i + 1 of the list
+  // The chunk's gathers (list entry -> record) are dependent loads of ~1 us each; they are software-pipelined: while
+  // chunk c is blended the records of chunk c+1 and the list entries of chunk c+2 are already in flight.
+  auto fetch_id = [&](uint32_t bs) { return (bs + lane < n) ? point_list[beg + bs + lane] : 0xFFFFFFFFu; };
+  auto fetch_rec = [&](uint32_t id_, float4 &a_, float4 &b_, float4 &c_) {
+    if (id_ != 0xFFFFFFFFu) {
+      const float4 *src = reinterpret_cast<const float4 *>(rec + id_);
+      a_ = src[0]; b_ = src[1]; c_ = src[2];
+    }
+  };
+  float4 a, b, c;
+  uint32_t id0 = fetch_id(0);
+  fetch_rec(id0, a, b, c);
+  uint32_t id1 = fetch_id(kFChunk);
+  for (uint32_t base = 0; base < n; base += kFChunk) {
+    if (__ballot(T > 0.0f) == 0) break;
+    float4 a1, b1, c1;
+    fetch_rec(id1, a1, b1, c1);
+    const uint32_t id2 = fetch_id(base + 2 * kFChunk);
+    bool hit = false;
+    if (id0 != 0xFFFFFFFFu)   // the record holds -k * conic and k * cutoff (k > 0): the test is scale-invariant
+      hit = conic_min_over_box(a.x, a.y, -a.z, -0.5f * a.w, -b.x, bx0, bx1, by0, by1) <= c.z;
+    const uint64_t m = __ballot(hit);
+    if (hit) {
+      const uint32_t rank = nh + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      int qi = head + count + (int)(rank - nh);
+      qi = qi >= kFRing ? qi - kFRing : qi;
+      uint4 k0, k1, k2;
+      splat_block_coefs(a.x, a.y, a.z, a.w, b.x, b.y, cx, cy, k0, k1, k2);
+      q_k[0][qi] = k0; q_k[1][qi] = k1; q_k[2][qi] = k2;
+      q_col[qi] = make_float4(b.z, b.w, c.x, c.y);
+      if constexpr (kForBackward) my_hits[rank] = id0;   // (rank < n: inside this tile's slice of the region)
+    }
+    count += __builtin_popcountll(m);
+    nh += (uint32_t)__builtin_popcountll(m);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool last_chunk = base + kFChunk >= n;
+    // full groups run straight-line (nslots is the compile-time kFGroup); only a wave's final group is partial
+    // log2(opacity * G) of the 16 hits in ring slots h .. h + 15 at this lane's pixel (three MFMAs)
+    auto exponents = [&](int h) -> f32x16 {
+      int hv = h;
+      asm volatile("" : "+v"(hv));
+      const int sl = a_on ? hv + a_slot : kFRing;      // the other half of the lanes feeds zeros (exp_mfma.hpp)
+      return block_exponents(q_k[0][sl], q_k[1][sl], q_k[2][sl], basis);
+    };
+    auto blend_group = [&](auto full, int nslots, const f32x16 &e) -> bool {
+      constexpr bool kFull = decltype(full)::value;
+      int hv = head;
+      asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
+      const float4 *gc = q_col + hv;
+      bool all_done = false;
+      uint32_t lastg = 0;   // 1-based slot of the group's last contributor to this pixel (inline constants, no SGPR moves)
+#pragma unroll
+      for (int i = 0; i < kFGroup; i++) {
+        if (kFull || i < nslots) {  // wave-uniform
+          if (kFull && i == kFGroup / 2) {   // every pixel saturated already: the second half is not needed
+            if (__ballot(T > 0.0f) == 0) { all_done = true; break; }
+          }
+          const float4 col = gc[i];
+          const float alpha = fminf(kAlphaMax, __builtin_amdgcn_exp2f(e[i]));
+          const bool live = alpha >= kAlphaMin;
+          const float al = live ? alpha : 0.0f;
+          // A saturated pixel is latched by the SIGN of T: the splat that would take T below 1e-4 is not blended and
+          // flips T negative, after which every test_T is negative too (a live pixel always has T >= 1e-4, and
+          // alpha = 0 leaves test_T = T exactly).
+#if SCORP_FWD_FMA
+          const float test_T = __builtin_fmaf(-al, T, T);
+#else
+          const float test_T = T * (1.0f - al);
+#endif
+          const bool ok = test_T >= kTMin;
+          const float ae = ok ? al : 0.0f;
+          const float w = ae * T;
+          C0 += col.x * w; C1 += col.y * w; C2 += col.z * w;
+          Dp += col.w * w;
+          T = ok ? test_T : -fabsf(T);
+          if constexpr (kForBackward) lastg = (ok & live) ? (uint32_t)(i + 1) : lastg;
+        }
+      }
+      if constexpr (kForBackward) last = lastg ? consumed + lastg : last;
+      head = head + kFGroup == kFRing ? 0 : head + kFGroup;
+      count -= nslots;
+      consumed += (uint32_t)nslots;
+      return all_done;
+    };
+    bool all_done = false;   // every pixel saturated: checked twice per group, not only once per 64 list entries
+#if SCORP_FWD_DB
+    // The exponents of the NEXT group are issued to the matrix cores before the current group is blended: the three
+    // dependent MFMAs (~100 cycles before the first result can be read) then run under the blend instead of in front of it.
+    if (count >= kFGroup) {
+      f32x16 e = exponents(head);
+      for (;;) {
+        const bool more = count >= 2 * kFGroup;
+        f32x16 e2 = e;
+        if (more) e2 = exponents(head + kFGroup == kFRing ? 0 : head + kFGroup);
+        if (blend_group(std::true_type{}, kFGroup, e) || __ballot(T > 0.0f) == 0) { all_done = true; break; }
+        if (!more) break;
+        e = e2;
+      }
+    }
+#else
+    while (count >= kFGroup) {
+      if (blend_group(std::true_type{}, kFGroup, exponents(head)) || __ballot(T > 0.0f) == 0) { all_done = true; break; }
+    }
+#endif
+    if (all_done) break;
+    if (last_chunk && count > 0) blend_group(std::false_type{}, count, exponents(head));
+    id0 = id1; a = a1; b = b1; c = c1; id1 = id2;
+  }
+  if constexpr (kForBackward) {
+    if (lane == 0) block_hits[tile * 4 + quad] = consumed;   // (block, splat) iterations this wave ran: the P statistic
+  }
+  if (inside) {
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    T = fabsf(T);
+    if constexpr (kForBackward) {
+      final_T[pix] = T;
+      n_contrib[pix] = last;
+    }
+    out_color[pix] = C0 + T * bg[0];
+    out_color[HW + pix] = C1 + T * bg[1];
+    out_color[2 * HW + pix] = C2 + T * bg[2];
+    out_depth[pix] = Dp;
+    out_alpha[pix] = 1.0f - T;   // = sum of the blend weights (sum_i alpha_i T_i telescopes to 1 - T)
+    if (out_depth_norm) out_depth_norm[pix] = nan_to_num00(Dp / (1.0f - T));   // render()'s depth, as render_tail_kernel forms it
+  }
+}
+#else   // !SCORP_EXP_MFMA: the exponent as a Horner form on the vector pipe (round 2; kept for same-box A/B builds)
 #ifndef SCORP_FWD_GROUP
 #define SCORP_FWD_GROUP 8
 #endif
@@ -740,6 +928,8 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     if (out_depth_norm) out_depth_norm[pix] = nan_to_num00(Dp / (1.0f - T));   // render()'s depth, as render_tail_kernel forms it
   }
 }
+
+#endif   // SCORP_EXP_MFMA
 
 int validate(const ScorpGs3dInputs *in) {
   if (!in) { set_error("inputs is NULL"); return SCORP_ERR_INVALID; }

@@ -3,12 +3,15 @@
     python scripts/isa_mix.py          (needs hipcc; no GPU)
 
 Compiles gs3d_forward.hip / gs3d_backward.hip with -save-temps, takes each blend kernel's largest basic block (the
-straight-line full group: 8 hits in the forward, 16 in the backward), counts its wave64 VALU instructions by class and
+straight-line full group: 16 hits in both), counts its wave64 VALU instructions by class and
 prices them with the per-class issue costs MEASURED on MI355X by scripts/mb_valu_peak.hip
 (profiles/r02_mb_valu_peak.txt, 8 waves per SIMD, every SIMD busy, cycles at 2.4 GHz per wave-instruction per SIMD):
-VOP2 2.8, VOP3 (three-source fma / mix) 3.3, v_cmp and v_cndmask 4.15, transcendental 8.5; a v_mfma_f32_16x16x32_f16
-occupies the matrix pipe for 16.  bench.py multiplies the per-hit cost by the hits of the view: the time the kernel
-would take if the VALU issued back to back ("instruction-mix VALU roofline"), and reports measured / that.
+VOP2 2.8, VOP3 (three-source fma / mix) 3.3, v_cmp and v_cndmask 4.15, transcendental 8.5.  An MFMA holds the SIMD's
+vector issue for 8 cycles (MI355X_MICROARCH.md, "vector-instruction ISSUE cost") and occupies the matrix pipe - which
+runs beside the other waves' VALU work - for 16 (16x16x32) or 32 (32x32x16) cycles: `mfma_cycles_per_hit` is the issue
+hold, `matrix_pipe_cycles_per_hit` the pipe occupancy (far below the VALU figure: not the limiter).  bench.py multiplies
+the per-hit issue cost by the hits of the view: the time the kernel would take if the VALU issued back to back
+("instruction-mix VALU roofline"), and reports measured / that.
 """
 import collections
 import json
@@ -66,6 +69,10 @@ def kernel_blocks(asm, symbol_re):
     return blocks
 
 
+def mfma_pipe_cycles(op):
+    return 32.0 if "32x32" in op else 16.0
+
+
 def hot_block(src, symbol_re, hits):
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call([HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-c",
@@ -77,12 +84,13 @@ def hot_block(src, symbol_re, hits):
     valu = sum(COST[k] * c[k] for k in COST)
     return {"block": name, "hits_per_block": hits, "instructions": dict(sorted(c.items())),
             "valu_insts_per_hit": round(sum(c[k] for k in COST) / hits, 2),
-            "valu_cycles_per_hit": round(valu / hits, 2), "mfma_cycles_per_hit": round(16.0 * c["mfma"] / hits, 2)}
+            "valu_cycles_per_hit": round(valu / hits, 2), "mfma_cycles_per_hit": round(8.0 * c["mfma"] / hits, 2),
+            "matrix_pipe_cycles_per_hit": round(sum(mfma_pipe_cycles(o) for o in ops if o.startswith("v_mfma")) / hits, 2)}
 
 
 out = {"_source": "scripts/isa_mix.py; issue costs from profiles/r02_mb_valu_peak.txt (cycles at 2.4 GHz per wave-instruction per SIMD)",
        "source_sha": source_sha(), "costs": COST,
-       "blend_forward": hot_block("gs3d_forward.hip", r"^_ZN5scorp12_GLOBAL__N_125blend_forward_wave_kernelILb1E.*:", 8),
+       "blend_forward": hot_block("gs3d_forward.hip", r"^_ZN5scorp12_GLOBAL__N_125blend_forward_wave_kernelILb1E.*:", 16),
        "blend_backward": hot_block("gs3d_backward.hip", r"^_ZN5scorp12_GLOBAL__N_126blend_backward_wave_kernelILb0ELb0E.*:", 16)}
 json.dump(out, open(os.path.join(ROOT, "profiles", "valu_mix.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -204,7 +204,7 @@ def test_config3_full_size_rotation_sweep(dev):
         assert float(fit[planted, 0]) > -1e-6 and float(fit[:, 0].sort().values[-2]) < float(fit[planted, 0]) - 1e-4
         ids_e, fit_e, best_e = rotation_sweep(obj, rots, cams, targets, bg, use_graph=False)
         assert best_e == planted and torch.equal(ids, ids_e)
-        assert float((fit - fit_e).abs().max()) < 1e-6
+        assert float((fit - fit_e).abs().max()) < 5e-6      # (the score is a float-atomic sum over 15 x 640 000 pixels)
     finally:
         PairPolicy.reset()
 
