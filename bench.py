@@ -226,9 +226,9 @@ def secondary_s6(dev, steps=40, warmup=8, cams=4, parity=False):
 def secondary_sweep(dev, cdev, rank, world):
     """Secondary record, every N: BASELINE config #3 as north_star scores it - the 128-rotation alignment sweep on S4 (a
     100k-Gaussian SH0 object, rotations_128.npz x 15 cameras at 800x800, forward-only renders).  Hypothesis j -> rank
-    j mod N, the object is broadcast once (one flat buffer), one all-gather of (id, fitness) at the end: STRONG scaling
-    (128 hypotheses whatever N).  The per-rank HIP graph (rotate + 15 renders + comparison) is captured outside the timed
-    region, like the model load; the timed region is score-all-my-hypotheses + gather, max over ranks."""
+    j mod N, the object is broadcast once (one flat buffer), ONE fixed-size all-gather of (id, fitness) at the end: STRONG
+    scaling (128 hypotheses whatever N).  The plan (targets in the stacked layout, pair-buffer sizing pass) is built
+    outside the timed region, like the model load; the timed region is score-all-my-hypotheses + gather, max over ranks."""
     import copy
     from scorp_amd.align import SweepPlan, render_views, rotation_sweep
     from scorp_amd.gaussian_model import GaussianModel
@@ -275,6 +275,8 @@ def secondary_sweep(dev, cdev, rank, world):
     return {"metric": "pose hypotheses/s, 128-rotation alignment sweep (S4)", "value": round(len(rots) / dt, 2), "unit": "hypotheses/s",
             "renders_per_s": round(len(rots) * len(cams) / dt, 1), "seconds_per_sweep": round(dt, 4), "n_gpus": world, "scaling": "strong",
             "hypotheses": len(rots), "cameras": len(cams), "graph_replay": plan.graph is not None,
+            "form": ("cameras moved instead of the SH-0 object; the 15 views rendered as ONE stacked image (ScorpGs3dInputs.num_views) "
+                     "+ one score launch per hypothesis" if plan.stacked is not None else "object rotated; one render per camera"),
             "best_id": best, "planted_id": planted,
             "roofline": (lambda b: {"bound": "latency", "achieved": round(len(rots) * len(cams) / dt * b / 1e9 / world, 1), "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": round(len(rots) * len(cams) / dt * b / 1e9 / world / HBM_PEAK_GBS, 5),

@@ -75,6 +75,16 @@ typedef struct ScorpGs3dInputs {
   const float *shs_rest;    /* non-NULL: `shs` is [N,1,3] (degree 0) and shs_rest is [N,sh_coeffs-1,3] */
   int32_t raw_params;       /* bit 0: opacities are logits (sigmoid); bit 1: scales are logs (exp); bit 2: rotations
                                are un-normalised (x / max(|x|, 1e-12)) */
+  /* ---- optional: V views of the SAME Gaussians in one launch set (0 or 1 = one view, the reference's call) ----
+   * The align loop renders one object from ~15 cameras per pose hypothesis, forward only
+   * (align_3dgs_clpe_9dof.py:157-169,336-368); 100 k Gaussians at 800x800 cannot fill the chip, so a single view is a
+   * chain of launch-latency-bound kernels.  With num_views = V > 1: viewmatrix / projmatrix / campos are arrays of V
+   * entries ([V,16], [V,16], [V,3]), image_height is the height of ONE view (a multiple of 16) and every per-view size
+   * is multiplied by V: the V images are rendered as one image of V * image_height rows (view v = rows
+   * [v * image_height, (v + 1) * image_height)), Gaussian i of view v is "virtual Gaussian" v * N + i.  So
+   * out_radii is [V * N], color [3, V * H, W], depth / alpha [V * H, W]; state / pairs are sized with
+   * scorp_gs3d_state_bytes(V * N, W, V * H).  Forward only: scorp_gs3d_backward* refuse such inputs. */
+  int32_t num_views;
 } ScorpGs3dInputs;
 
 /* Gradients w.r.t. the 8 call arguments; any pointer may be NULL (not wanted). Each is fully overwritten. */

@@ -21,7 +21,7 @@ class ScorpGs3dInputs(ctypes.Structure):
         ("bg", c_float_p), ("viewmatrix", c_float_p), ("projmatrix", c_float_p), ("campos", c_float_p),
         ("means3D", c_float_p), ("shs", c_float_p), ("colors_precomp", c_float_p), ("opacities", c_float_p),
         ("scales", c_float_p), ("rotations", c_float_p), ("cov3D_precomp", c_float_p),
-        ("shs_rest", c_float_p), ("raw_params", ctypes.c_int32),
+        ("shs_rest", c_float_p), ("raw_params", ctypes.c_int32), ("num_views", ctypes.c_int32),
     ]
 
 

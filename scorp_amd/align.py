@@ -69,6 +69,82 @@ def hypothesis_fitness(model, R, cameras, targets, bg, render_fn=render):
 log = logging.getLogger("scorp_amd.align")
 
 
+def _stacked_ok(model, cameras, render_fn):
+    """The camera-side form applies to SH-0 objects (view-independent colour: what align loads as `gaussian_generated`,
+    align_3dgs_clpe_9dof.py:307-308) rendered by the HIP rasterizer from cameras of one resolution."""
+    if render_fn is not render or not model._xyz.is_cuda or getattr(model, "max_sh_degree", 1) != 0:
+        return False
+    c0 = cameras[0]
+    return all(tuple(c.resolution) == tuple(c0.resolution) and c.FoVx == c0.FoVx and c.FoVy == c0.FoVy for c in cameras) \
+        and int(c0.resolution[1]) % 16 == 0
+
+
+class StackedSweep:
+    """The rotation sweep for an SH-0 object WITHOUT touching the object: a hypothesis x -> R (x - c) + c is scored by
+    moving the V cameras the other way (multiview.ViewStack.moved; tests/test_aux_gpu.py proves that rotating object and
+    camera together is invisible) and rendering all V views as ONE stacked image (ScorpGs3dInputs.num_views): per
+    hypothesis one preprocess -> bin -> sort -> blend launch set of training-frame size plus ONE score launch, instead
+    of a model clone + ~20 torch kernels + V x 7 latency-bound launches.  The camera matrices of every hypothesis are
+    formed by three batched matmuls up front."""
+
+    def __init__(self, model, cameras, targets, bg):
+        from .multiview import ViewStack
+        self.model, self.bg = model, bg
+        self.dev = model._xyz.device
+        self.stack = ViewStack(cameras, self.dev)
+        # targets in the stacked layout (normalised depth, alpha), 16-byte aligned rows of the score kernel
+        self.t_depth = torch.cat([t["render_depth"].reshape(self.stack.H, self.stack.W) for t in targets]).contiguous()
+        self.t_alpha = torch.cat([t["render_alpha"].reshape(self.stack.H, self.stack.W) for t in targets]).contiguous()
+        self.centre = model._xyz.detach().mean(0)
+        # sizing pass (setup): the exact pair count of the unrotated object; the sweep reserves twice that
+        from .multiview import render_stacked
+        prev = PairPolicy.mode
+        PairPolicy.mode = "exact"
+        try:
+            self.reserve = 2 * render_stacked(model, self.stack, bg)["num_pairs"] + 4096
+        finally:
+            PairPolicy.mode = prev
+
+    def score(self, rotations, ids):
+        import ctypes
+        import numpy as np
+        from . import _C
+        from .multiview import render_stacked
+        from .rasterizer3d import _stream
+        if len(ids) == 0:
+            return []
+        L = _C.lib()
+        R = torch.as_tensor(np.asarray([rotations[i] for i in ids]), dtype=torch.float32).to(self.dev)     # [n,3,3]
+        d = self.centre - self.centre @ R.transpose(-1, -2)                                                     # c - R c
+        view, proj, campos = self.stack.moved(R, d)
+        acc = torch.zeros(len(ids), dtype=torch.float32, device=self.dev)
+        n = self.t_alpha.numel()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        prev, prev_reserve = PairPolicy.mode, PairPolicy.reserve
+        PairPolicy.mode, PairPolicy.reserve = "reserve", max(prev_reserve, self.reserve)
+        try:
+            for k in range(len(ids)):
+                out = render_stacked(self.model, self.stack, self.bg, view[k], proj[k], campos[k])
+                _C.check(L.scorp_gs3d_pose_score_accumulate(p(out["render_depth_raw"]), p(out["render_alpha"]), p(self.t_depth),
+                                                            p(self.t_alpha), n, 1.0 / n, ctypes.c_void_p(acc[k:k + 1].data_ptr()),
+                                                            _stream()), "scorp_gs3d_pose_score_accumulate")
+            try:
+                PairPolicy.drain()       # the sweep's one synchronisation: every view's overflow word
+            except RuntimeError:
+                # the reservation was too small for some hypothesis (drain has grown it): score again
+                log.warning("StackedSweep: pair reservation grown during the sweep; scoring the hypotheses again")
+                acc.zero_()
+                for k in range(len(ids)):
+                    out = render_stacked(self.model, self.stack, self.bg, view[k], proj[k], campos[k])
+                    _C.check(L.scorp_gs3d_pose_score_accumulate(p(out["render_depth_raw"]), p(out["render_alpha"]), p(self.t_depth),
+                                                                p(self.t_alpha), n, 1.0 / n, ctypes.c_void_p(acc[k:k + 1].data_ptr()),
+                                                                _stream()), "scorp_gs3d_pose_score_accumulate")
+                self.reserve = max(self.reserve, PairPolicy.drain() * 2)
+        finally:
+            PairPolicy.mode, PairPolicy.reserve = prev, prev_reserve
+        return [(-acc[k]).reshape(1) for k in range(len(ids))]
+
+
 class SweepPlan:
     """Everything of a rotation sweep that does not depend on the hypothesis, built once: on a GPU one hypothesis (rotate
     + len(cameras) renders + comparison) is captured as a HIP graph and `score()` replays it per rotation - the sweep's
@@ -77,10 +153,20 @@ class SweepPlan:
     into a device-side maximum and checked once per `score()`.  With `use_graph=False` (CPU stand-in renderers, capture
     failures) hypotheses are scored with eager launches, each verified by PairPolicy.drain()."""
 
-    def __init__(self, model, cameras, targets, bg, use_graph=None, render_fn=render):
+    def __init__(self, model, cameras, targets, bg, use_graph=None, render_fn=render, stacked=None):
         self.model, self.cameras, self.targets, self.bg, self.render_fn = model, cameras, targets, bg, render_fn
         self.dev = model._xyz.device
         self.graph = None
+        # SH-0 object on the GPU: cameras are moved, not the object, and the views render as one stacked image
+        self.stacked = None
+        if stacked is None:
+            stacked = use_graph is None and _stacked_ok(model, cameras, render_fn)
+        if stacked:
+            if not _stacked_ok(model, cameras, render_fn):
+                raise ValueError("the stacked sweep needs an SH-0 GPU model and cameras of one resolution (height % 16 == 0)")
+            self.stacked = StackedSweep(model, cameras, targets, bg)
+            self.reserve, self.fallback_reason = 0, None
+            return
         self.reserve = 0        # this plan's pair-reservation floor: applied only inside its own calls (_reserved)
         self.fallback_reason = None
         if use_graph is None:
@@ -135,6 +221,8 @@ class SweepPlan:
 
     def score(self, rotations, ids):
         """Fitness (1-element float tensors) of the hypotheses `ids` of `rotations`."""
+        if self.stacked is not None:
+            return self.stacked.score(rotations, ids)
         if self.graph is not None:
             try:
                 worst_flags = torch.zeros(2, dtype=torch.int32, device=self.dev)

@@ -59,7 +59,8 @@ struct StateHeader {
   uint32_t num_pairs;  // D of the last preprocess
   uint32_t overflow;   // 1 if the last render needed more than `capacity`
   uint32_t capacity;   // capacity the last render ran with
-  uint32_t _pad[13];
+  uint32_t long_tiles; // tiles whose list has more than 1024 entries (their ids: the dead tile_count array), see sort_tiles_*
+  uint32_t _pad[12];
 };
 static_assert(sizeof(StateHeader) == 64, "StateHeader must be 64 bytes");
 
@@ -143,10 +144,11 @@ __device__ __forceinline__ void for_each_tile(int x0, int y0, int x1, int y1, ui
 #endif
 
 // Forward state layout (one caller-owned blob, 256-byte aligned sub-buffers).
-constexpr int kMaxLdsTiles = 36864;   // tiles per pass of the LDS-histogram binning (144 KiB of the CU's 160 KiB): up to
-                                      // 3072 x 3072 pixels in ONE pass; larger images (the align loop renders at up to
-                                      // 1.5^3 x the base resolution, cameras.py:139-148) take ceil(tiles / this) passes
-                                      // over the Gaussians, each pass owning a contiguous range of tiles
+constexpr int kMaxLdsTiles = 40000;   // tiles per pass of the LDS-histogram binning (156.25 KiB of the CU's 160 KiB): up to
+                                      // 3200 x 3200 pixels - or the align sweep's 15 stacked 800x800 views, 37 500
+                                      // tiles - in ONE pass; larger images (the align loop renders at up to 1.5^3 x
+                                      // the base resolution, cameras.py:139-148) take ceil(tiles / this) passes over
+                                      // the Gaussians, each pass owning a contiguous range of tiles
 constexpr int kBinBlocksMax = 256;    // blocks of the LDS-histogram binning (each owns a contiguous Gaussian range)
 
 // As many blocks as the cap allows, down to 256 Gaussians each, while the histogram matrix hist[block][tile] stays
@@ -163,13 +165,22 @@ inline int bin_blocks(int N, int tiles) {
 struct StateLayout {
   size_t header, rec, bin, tile_mask, tile_count, tile_start, final_T, n_contrib, block_hits, block_hist, total;
   int tiles_x, tiles_y, tiles, nb;
+  int views, view_n;   // stacked views (ScorpGs3dInputs.num_views): binning pass v owns view v's Gaussians AND tiles
   bool lds_binning;
-  int bin_passes() const { return (tiles + kMaxLdsTiles - 1) / kMaxLdsTiles; }
-  int tiles_per_pass() const { return tiles < kMaxLdsTiles ? tiles : kMaxLdsTiles; }
+  int bin_passes() const { return views > 1 ? views : (tiles + kMaxLdsTiles - 1) / kMaxLdsTiles; }
+  int tiles_per_pass() const { return views > 1 ? tiles / views : (tiles < kMaxLdsTiles ? tiles : kMaxLdsTiles); }
+  int bin_n() const { return views > 1 ? view_n : -1; }   // Gaussians a pass looks at (-1: all of them)
   // up to 8192 tiles (one pass, 8 counts per thread) every scatter workgroup scans the tile totals itself while it sets
   // up its LDS cursors, and the one-workgroup scan launch between the count and the scatter is dropped
-  bool scan_in_scatter() const { return lds_binning && tiles <= 8192; }
-  StateLayout(int N, int W, int H, bool mode2d = false) {
+  bool scan_in_scatter() const { return lds_binning && tiles <= 8192 && views <= 1; }
+  // views_ > 1: N and H are the TOTALS of views_ stacked views (N / views_ Gaussians, H / views_ rows each).  View v's
+  // Gaussians only reach the tiles of band v, so the binning runs as views_ passes, pass v over view v's Gaussians with a
+  // histogram of view v's tiles only: nb blocks PER VIEW and a block-histogram matrix of nb x tiles counters instead of
+  // 256 x tiles (38 MB at the align sweep's 15 x 800x800).  Only nb - and with it the size of the last region - depends
+  // on views_, so a state buffer sized by the one-view formula on the totals (scorp_gs3d_state_bytes) always suffices.
+  StateLayout(int N, int W, int H, bool mode2d = false, int views_ = 1) {
+    views = views_ > 1 ? views_ : 1;
+    view_n = N / views;
     tiles_x = (W + kTile - 1) / kTile;
     tiles_y = (H + kTile - 1) / kTile;
     tiles = tiles_x * tiles_y;
@@ -185,6 +196,12 @@ struct StateLayout {
     n_contrib = off; off = align_up(off + hw * 4 * (mode2d ? 2 : 1), 256);   // ... and the median contributor
     block_hits = off; off = align_up(off + (size_t)tiles * 4 * 4, 256);      // per 8x8 block: hits the blend forward replayed
     nb = bin_blocks(N, tiles);
+    if (views > 1) {
+      // (a view's blocks write only the view's segment of their histogram row, so nb is the number of blocks PER VIEW; more
+      // than ~16 bought nothing at 15 views: the scatter is bound by its 8-byte pair stores, 64 blocks measured 69 vs 68 us)
+      const int per_view = bin_blocks(view_n, tiles / views), cap = kBinBlocksMax / views > 16 ? kBinBlocksMax / views : 16;
+      nb = per_view < cap ? per_view : cap;
+    }
     lds_binning = tiles <= 64 * kMaxLdsTiles;   // (beyond: the global-atomic fallback; 150 M pixels)
     block_hist = off; off = align_up(off + (lds_binning ? (size_t)nb * tiles * 4 : 0), 256);
     total = off;

@@ -821,6 +821,7 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
                                       scorp_stream_t stream_) {
   if (!in || !state || !pairs || !grads || !scratch) { set_error("NULL argument to scorp_gs3d_backward"); return SCORP_ERR_INVALID; }
   if (!dL_dcolor) { set_error("dL_dcolor is NULL"); return SCORP_ERR_INVALID; }
+  if (in->num_views > 1) { set_error("num_views > 1 is forward only"); return SCORP_ERR_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
   if (N <= 0) return SCORP_OK;

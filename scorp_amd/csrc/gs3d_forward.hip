@@ -81,6 +81,55 @@ scan_tiles_kernel(const uint32_t *__restrict__ tile_count, uint32_t *__restrict_
   }
 }
 
+// The same scan for up to kMaxLdsTiles tiles with the counts staged in LDS: coalesced, independent loads and stores (the
+// kernel above walks `per` consecutive counts per thread with dependent, uncoalesced global loads - 56 us for the 37 500
+// tiles of the align sweep's 15 stacked views, all of it latency).
+__global__ void __launch_bounds__(1024)
+scan_tiles_lds_kernel(const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_start, int tiles,
+                      StateHeader *__restrict__ header) {
+  extern __shared__ uint32_t s_all[];
+  __shared__ uint32_t s_wave[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int k = t; k < tiles; k += 1024) s_all[k] = tile_count[k];
+  __syncthreads();
+  const int per = (tiles + 1023) / 1024;
+  const int lo = min(tiles, t * per), hi = min(tiles, lo + per);
+  uint32_t sum = 0;
+  for (int k = lo; k < hi; k++) sum += s_all[k];
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < 16 ? s_wave[lane] : 0u;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)w, off, 64);
+      if (lane >= off) w += v;
+    }
+    if (lane < 16) s_wave[lane] = w;
+  }
+  __syncthreads();
+  uint32_t run = incl - sum + (wave > 0 ? s_wave[wave - 1] : 0u);
+  const uint32_t total = s_wave[15];
+  for (int k = lo; k < hi; k++) {
+    const uint32_t v = s_all[k];
+    s_all[k] = run;
+    run += v;
+  }
+  __syncthreads();
+  for (int k = t; k < tiles; k += 1024) tile_start[k] = s_all[k];
+  if (t == 0) {
+    tile_start[tiles] = total;
+    header->num_pairs = total;
+    header->overflow = 0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K3: bucket (tile,splat) pairs by tile. The per-tile counter doubles as the cursor (counted back down to zero,
 // so it is clean for the next view). Slot order inside a tile is arbitrary; the sort below fixes it.
@@ -93,6 +142,7 @@ scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__re
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) {
     header->capacity = capacity;
+    header->long_tiles = 0;   // (the sort's list of long tiles starts empty)
     if (header->num_pairs > capacity) header->overflow = 1;
   }
   if (i >= N) return;
@@ -121,7 +171,7 @@ constexpr int kBinThreads = 1024;   // few Gaussians per thread: the count / sca
 // Images with more tiles than one LDS histogram holds are binned in passes: workgroup (pass, block) owns the tile range
 // [pass * tpp, (pass + 1) * tpp) of bin block `block` (blockIdx.x = pass * nb + block).
 __global__ void __launch_bounds__(kBinThreads)
-count_tiles_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__restrict__ bin,
+count_tiles_lds_kernel(int N, int per_block, int nb, int tpp, int view_n, const BinRec *__restrict__ bin,
                        const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x, uint32_t *__restrict__ block_hist,
                        StateHeader *__restrict__ header) {
   extern __shared__ uint32_t s_hist[];
@@ -130,7 +180,9 @@ count_tiles_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__re
   const int t_lo = pass * tpp, nt = min(tiles - t_lo, tpp);
   for (int t = threadIdx.x; t < nt; t += kBinThreads) s_hist[t] = 0;
   __syncthreads();
-  const int lo = blk * per_block, hi = min(N, lo + per_block);
+  // (stacked views: pass v looks at view v's Gaussians only, [v * view_n, (v + 1) * view_n))
+  const int g0 = view_n >= 0 ? pass * view_n : 0, g1 = view_n >= 0 ? g0 + view_n : N;
+  const int lo = g0 + blk * per_block, hi = min(g1, lo + per_block);
   for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
     const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
     const uint64_t mask = tile_mask[i];   // issued with the record, not after the visibility test
@@ -193,7 +245,7 @@ scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uin
 }
 
 __global__ void __launch_bounds__(kBinThreads)
-scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__restrict__ bin,
+scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, int view_n, const BinRec *__restrict__ bin,
                          const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x,
                          const uint32_t *__restrict__ block_hist, uint32_t *__restrict__ tile_start,
                          const uint32_t *__restrict__ tile_count, uint64_t *__restrict__ keys, uint32_t capacity,
@@ -201,6 +253,7 @@ scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__
   extern __shared__ uint32_t s_cur[];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     header->capacity = capacity;
+    header->long_tiles = 0;   // (the sort's list of long tiles starts empty)
     if (header->num_pairs > capacity) header->overflow = 1;
   }
   const int pass = blockIdx.x / nb, blk = blockIdx.x - pass * nb;
@@ -252,7 +305,8 @@ scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, const BinRec *__
     for (int t = threadIdx.x; t < nt; t += kBinThreads) s_cur[t] = tile_start[t_lo + t] + row[t];
   }
   __syncthreads();
-  const int lo = blk * per_block, hi = min(N, lo + per_block);
+  const int g0 = view_n >= 0 ? pass * view_n : 0, g1 = view_n >= 0 ? g0 + view_n : N;
+  const int lo = g0 + blk * per_block, hi = min(g1, lo + per_block);
   for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
     const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
     const uint64_t mask = tile_mask[i];
@@ -439,12 +493,17 @@ __device__ __forceinline__ void sort_level(uint64_t (&k)[4], uint64_t *s_x, uint
 
 __global__ void __launch_bounds__(256)
 sort_tiles_reg_kernel(const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
-                      uint32_t *__restrict__ point_list, uint32_t capacity) {
+                      uint32_t *__restrict__ point_list, uint32_t capacity, uint32_t *__restrict__ long_list,
+                      StateHeader *__restrict__ header) {
   __shared__ __attribute__((aligned(16))) uint64_t s_x[1024];
   const int tile = blockIdx.x;
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t n = end - beg;
-  if (n == 0 || n > 1024) return;
+  if (n > 1024) {   // sort_tiles_long_kernel's: it walks the list of such tiles (usually empty) instead of every tile
+    if (threadIdx.x == 0) long_list[atomicAdd(&header->long_tiles, 1u)] = (uint32_t)tile;
+    return;
+  }
+  if (n == 0) return;
   const uint32_t base = 4 * threadIdx.x;
   uint32_t P = 4;
   while (P < n) P <<= 1;
@@ -492,13 +551,9 @@ __device__ __forceinline__ void clean_chunk_1024(uint64_t (&k)[4], uint64_t *s_x
   thread_tail(k);
 }
 
-__global__ void __launch_bounds__(256)
-sort_tiles_long_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict__ keys,
-                       uint32_t *__restrict__ point_list, uint32_t capacity) {
+__device__ __forceinline__ void sort_long_tile(int tile, const uint32_t *__restrict__ tile_start, uint64_t *__restrict__ keys,
+                                               uint32_t *__restrict__ point_list, uint32_t capacity, uint64_t *s_keys, uint64_t *s_x) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  __shared__ __attribute__((aligned(16))) uint64_t s_keys[kSortLds];
-  __shared__ __attribute__((aligned(16))) uint64_t s_x[1024];
-  const int tile = blockIdx.x;
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t n = end - beg;
   if (n <= 1024) return;   // sort_tiles_reg_kernel's
@@ -573,6 +628,20 @@ sort_tiles_long_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__rest
   }
 }
 
+// A fixed, small grid walks the list of long tiles the register kernel left (header->long_tiles ids in long_list): with
+// no long tile - the usual case - its workgroups read one word and leave, instead of one workgroup per tile doing so.
+__global__ void __launch_bounds__(256)
+sort_tiles_long_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
+                       uint32_t capacity, const uint32_t *__restrict__ long_list, const StateHeader *__restrict__ header) {
+  __shared__ __attribute__((aligned(16))) uint64_t s_keys[kSortLds];
+  __shared__ __attribute__((aligned(16))) uint64_t s_x[1024];
+  const uint32_t count = header->long_tiles;
+  for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+    sort_long_tile((int)long_list[k], tile_start, keys, point_list, capacity, s_keys, s_x);
+    __syncthreads();   // the next tile reuses the staging arrays
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K5: front-to-back blend with ONE WAVE PER 8x8 BLOCK as the unit (64-thread workgroups, no workgroup barriers), the
 // forward twin of blend_backward_wave_kernel: the wave walks the tile's list front to back 64 entries at a time, each
@@ -612,7 +681,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
                           float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                           uint32_t *__restrict__ hits, uint32_t *__restrict__ block_hits, float *__restrict__ out_depth_norm,
-                          float4 *__restrict__ zero_buf, uint32_t zero_per_wave, uint32_t zero_total) {
+                          float4 *__restrict__ zero_buf, uint32_t zero_per_wave, uint32_t zero_total, int band_h) {
   __shared__ uint4 q_k[3][kFRing + 1];   // the three bf16 terms of a hit's six coefficients; slot kFRing stays zero
   __shared__ float4 q_col[kFRing];       // r, g, b, depth
   const int lane = threadIdx.x;
@@ -628,8 +697,11 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   const int bx = (tile % tiles_x) * kTile + (quad & 1) * 8, by = (tile / tiles_x) * kTile + (quad >> 1) * 8;
   const int px = bx + (lane & 7), py = by + (lane >> 3);
   const bool inside = px < W && py < H;
-  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
-  const float cx = (float)bx + 3.5f, cy = (float)by + 3.5f;
+  // stacked views (ScorpGs3dInputs.num_views): the records hold each view's OWN pixel coordinates, so the block's frame
+  // is taken relative to the first row of its band (band_h = rows per view, 0 = one view)
+  const int byl = band_h > 0 ? by % band_h : by;
+  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)byl, by1 = (float)(byl + 7);
+  const float cx = (float)bx + 3.5f, cy = (float)byl + 3.5f;
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
   const uint32_t n = end - beg;
   uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
@@ -960,6 +1032,12 @@ int validate(const ScorpGs3dInputs *in) {
   if (!in->bg || !in->viewmatrix || !in->projmatrix || !in->campos) {
     set_error("bg / viewmatrix / projmatrix / campos is NULL"); return SCORP_ERR_INVALID;
   }
+  if (in->num_views < 0) { set_error("num_views %d is negative", in->num_views); return SCORP_ERR_INVALID; }
+  if (in->num_views > 1) {
+    const long long nt = (long long)in->num_views * in->num_gaussians, ht = (long long)in->num_views * in->image_height;
+    if (in->image_height % kTile != 0) { set_error("num_views > 1 needs image_height to be a multiple of %d", kTile); return SCORP_ERR_INVALID; }
+    if (nt > 0x7FFFFFFFll || ht > 16 * 65535ll) { set_error("num_views x N or num_views x H too large"); return SCORP_ERR_INVALID; }
+  }
   // SH rows and quaternions are fetched as 16-byte words (and SH rows by direct global -> LDS loads)
   if ((((uintptr_t)in->shs | (uintptr_t)in->shs_rest | (uintptr_t)in->rotations) & 15) != 0) {
     set_error("shs / shs_rest / rotations must be 16-byte aligned"); return SCORP_ERR_INVALID;
@@ -974,7 +1052,7 @@ namespace scorp {
 int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipStream_t stream) {
   uint32_t *tile_count = (uint32_t *)(base + L.tile_count);
   if (L.lds_binning) {
-    const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
+    const int per_block = (max(L.bin_n() >= 0 ? L.bin_n() : N, 1) + L.nb - 1) / L.nb;
     uint32_t *block_hist = (uint32_t *)(base + L.block_hist);
     {
       ProfScope prof(kKCountTiles, stream);
@@ -987,7 +1065,7 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
         SCORP_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_pairs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4));
       }
       count_tiles_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
-          N, per_block, L.nb, tpp, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
+          N, per_block, L.nb, tpp, L.bin_n(), (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
           block_hist, L.scan_in_scatter() ? (StateHeader *)(base + L.header) : nullptr);
       scan_block_hist_kernel<<<(L.tiles + kScanTiles - 1) / kScanTiles, kScanTiles * kScanSegs, 0, stream>>>(
           L.nb, L.tiles, block_hist, tile_count, L.scan_in_scatter() ? (StateHeader *)(base + L.header) : nullptr);
@@ -996,8 +1074,15 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
   }
   if (!L.scan_in_scatter()) {
     ProfScope prof(kKScanTiles, stream);
-    scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, (uint32_t *)(base + L.tile_start), L.tiles,
-                                              (StateHeader *)(base + L.header));
+    if (L.tiles > 8192 && L.tiles <= kMaxLdsTiles) {
+      if ((size_t)L.tiles * 4 > 64 * 1024)
+        SCORP_HIP_CHECK(hipFuncSetAttribute((const void *)scan_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4));
+      scan_tiles_lds_kernel<<<1, 1024, (size_t)L.tiles * 4, stream>>>(tile_count, (uint32_t *)(base + L.tile_start), L.tiles,
+                                                                      (StateHeader *)(base + L.header));
+    } else {
+      scan_tiles_kernel<<<1, 1024, 0, stream>>>(tile_count, (uint32_t *)(base + L.tile_start), L.tiles,
+                                                (StateHeader *)(base + L.header));
+    }
   }
   SCORP_KERNEL_CHECK("scan_tiles", debug, stream);
   return SCORP_OK;
@@ -1012,10 +1097,10 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
   {
     ProfScope prof(kKScatterPairs, stream);
     if (L.lds_binning) {
-      const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
+      const int per_block = (max(L.bin_n() >= 0 ? L.bin_n() : N, 1) + L.nb - 1) / L.nb;
       const int tpp = L.tiles_per_pass();
       scatter_pairs_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
-          N, per_block, L.nb, tpp, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
+          N, per_block, L.nb, tpp, L.bin_n(), (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
           (const uint32_t *)(base + L.block_hist), tile_start, L.scan_in_scatter() ? tile_count : nullptr, keys, capacity,
           header);
     } else {
@@ -1027,8 +1112,9 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
   SCORP_KERNEL_CHECK("scatter_pairs", debug, stream);
   {
     ProfScope prof(kKSortTiles, stream);
-    sort_tiles_reg_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity);
-    sort_tiles_long_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity);
+    // (tile_count is dead once the pairs are scattered - the next preprocess rewrites it - and holds the long tiles' ids)
+    sort_tiles_reg_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity, tile_count, header);
+    sort_tiles_long_kernel<<<L.tiles < 1024 ? L.tiles : 1024, 256, 0, stream>>>(tile_start, keys, point_list, capacity, tile_count, header);
   }
   SCORP_KERNEL_CHECK("sort_tiles", debug, stream);
   return SCORP_OK;
@@ -1049,8 +1135,10 @@ int scorp::preprocess3d_impl(const ScorpGs3dInputs *in, int32_t *out_radii, uint
                              size_t state_bytes, scorp_stream_t stream_) {
   if (int e = validate(in)) return e;
   hipStream_t stream = (hipStream_t)stream_;
-  const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
-  const StateLayout L(N, W, H);
+  const int V = in->num_views > 1 ? in->num_views : 1;          // V views stacked vertically: V * N virtual Gaussians
+  const int N = V * in->num_gaussians, W = in->image_width, H = V * in->image_height;
+  const StateLayout L(N, W, H, false, V);
+  if (V > 1 && !L.lds_binning) { set_error("num_views > 1: the stacked image has too many tiles"); return SCORP_ERR_INVALID; }
   if (!state || state_bytes < L.total || ((uintptr_t)state & 255)) {
     set_error("state buffer NULL, misaligned or too small (%zu < %zu)", state_bytes, L.total);
     return SCORP_ERR_INVALID;
@@ -1098,9 +1186,11 @@ int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, ui
                          scorp_stream_t stream_, bool for_backward) {
   if (int e = validate(in)) return e;
   hipStream_t stream = (hipStream_t)stream_;
-  const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
-  const StateLayout L(N, W, H);
+  const int V = in->num_views > 1 ? in->num_views : 1;
+  const int N = V * in->num_gaussians, W = in->image_width, H = V * in->image_height;
+  const StateLayout L(N, W, H, false, V);
   const PairLayout P(capacity);
+  if (V > 1 && for_backward) { set_error("num_views > 1 is forward only: use scorp_gs3d_render_image"); return SCORP_ERR_INVALID; }
   if (!state || ((uintptr_t)state & 255) || !pairs || ((uintptr_t)pairs & 255)) {
     set_error("state / pairs buffer NULL or not 256-byte aligned"); return SCORP_ERR_INVALID;
   }
@@ -1122,7 +1212,11 @@ int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, ui
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
         out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib),
         (uint32_t *)(pb + P.hits), (uint32_t *)(base + L.block_hits), out_depth_norm, (float4 *)zero_buf,
-        (uint32_t)zero_per_wave, (uint32_t)zero_total);
+        (uint32_t)zero_per_wave, (uint32_t)zero_total
+#if SCORP_EXP_MFMA
+        , V > 1 ? in->image_height : 0
+#endif
+        );
   }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;

@@ -28,6 +28,7 @@ struct PgArgs {
   const float *view, *proj, *campos;
   const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
   uint8_t *visible;   // optional: radii > 0 as bytes (render()'s visibility_filter)
+  int views;          // > 1: blockIdx.y = view; N, H, tiles_y are those of ONE view, the outputs those of the stacked image
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -204,15 +205,21 @@ __device__ __forceinline__ void preprocess_body(const PgArgs &a, float *s_sh, Sp
     }
     op_raw = a.opacities[i];
   }
+  const int view = a.views > 1 ? (int)blockIdx.y : 0;   // workgroup-uniform: the matrices stay scalar loads
   float vm[16], pm[16];
   {  // camera matrices through the scalar cache (constant address space): no VMEM slots, no vmcnt dependence
-    const CFloat *cv = (const CFloat *)a.view, *cp = (const CFloat *)a.proj;
+    const CFloat *cv = (const CFloat *)a.view + 16 * view, *cp = (const CFloat *)a.proj + 16 * view;
 #pragma unroll
     for (int q = 0; q < 16; q++) { vm[q] = cv[q]; pm[q] = cp[q]; }
   }
   SplatGeom g;
   g.vis = false; g.mask = 0; g.radius = 0;
   if (active) g = splat_geometry(a, vm, pm, i, px_, py_, pz_, q_raw, sc_raw, op_raw, a.cov3D_precomp);
+  if (view > 0) {   // into the view's band of the stacked image: only the TILE rectangle moves (integers; the tile mask
+                    // is relative to it).  The record keeps the view's own pixel coordinates - adding view * H to sy
+                    // would round its low bits away - and the blend kernel subtracts the band's first row instead.
+    g.y0 += view * a.tiles_y; g.y1 += view * a.tiles_y;
+  }
   const bool vis = active && g.vis;
   float rgb[3] = {0.0f, 0.0f, 0.0f};
   int clamp_bits = 0;
@@ -224,7 +231,8 @@ __device__ __forceinline__ void preprocess_body(const PgArgs &a, float *s_sh, Sp
         __syncthreads();
       }
       if (vis) {
-        const float dx = px_ - ((const CFloat *)a.campos)[0], dy = py_ - ((const CFloat *)a.campos)[1], dz = pz_ - ((const CFloat *)a.campos)[2];
+        const CFloat *cc = (const CFloat *)a.campos + 3 * view;
+        const float dx = px_ - cc[0], dy = py_ - cc[1], dz = pz_ - cc[2];
         const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         sh_row_to_rgb<DEG>(sh_row(s_sh, threadIdx.x, lin), dx * inv, dy * inv, dz * inv, rgb);
 #pragma unroll
@@ -239,7 +247,7 @@ __device__ __forceinline__ void preprocess_body(const PgArgs &a, float *s_sh, Sp
     for (int q = 0; q < 3; q++) rgb[q] = a.colors_precomp[3 * (size_t)i + q];
   }
   if (!active) return;
-  emit_splat(a, i, g, rgb, clamp_bits, rec, bin, tile_mask, radii, tile_count);
+  emit_splat(a, view * a.N + i, g, rgb, clamp_bits, rec, bin, tile_mask, radii, tile_count);
 }
 
 template <int DEG, bool SPLIT>
@@ -535,6 +543,8 @@ PgArgs make_args(const ScorpGs3dInputs *in, const StateLayout &L) {
   a.means3D = in->means3D; a.shs = in->shs; a.shs_rest = in->shs_rest; a.colors_precomp = in->colors_precomp;
   a.opacities = in->opacities; a.scales = in->scales; a.rotations = in->rotations; a.cov3D_precomp = in->cov3D_precomp;
   a.visible = nullptr;
+  a.views = in->num_views > 1 ? in->num_views : 1;
+  if (a.views > 1) a.tiles_y = L.tiles_y / a.views;   // (L describes the stacked image)
   return a;
 }
 
@@ -544,7 +554,7 @@ void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec
                        int32_t *radii, uint32_t *tile_count, uint8_t *out_visible, hipStream_t stream) {
   PgArgs a = make_args(in, L);
   a.visible = out_visible;
-  const dim3 grid((a.N + 255) / 256), block(256);
+  const dim3 grid((a.N + 255) / 256, a.views), block(256);
   const int deg = in->shs ? in->sh_degree : 0;
   const bool split = in->shs_rest != nullptr;
 #define SCORP_LAUNCH_PRE(D, S) preprocess_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, tile_mask, radii, tile_count)

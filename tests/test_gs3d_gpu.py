@@ -125,7 +125,7 @@ CASES = {
     "huge_splats": dict(N=6000, W=64, H=64, deg=0, seed=6, log_scale=math.log(0.6)),  # >4096 per tile: global sort path
     "long_lists": dict(N=2500, W=64, H=64, deg=1, seed=11, log_scale=math.log(0.6)),     # 1024 < n <= 4096: second sort launch, in LDS
     "many_tiles": dict(N=3000, W=2320, H=1800, deg=1, seed=10, log_scale=math.log(0.03)),  # 16385 tiles: a 64 KiB+ LDS histogram
-    "two_pass_tiles": dict(N=2000, W=3104, H=3072, deg=0, seed=12, log_scale=math.log(0.03)),  # 37248 tiles > kMaxLdsTiles: binned in two tile-range passes
+    "two_pass_tiles": dict(N=2000, W=3104, H=3328, deg=0, seed=12, log_scale=math.log(0.03)),  # 40352 tiles > kMaxLdsTiles: binned in two tile-range passes
 }
 
 
