@@ -287,6 +287,62 @@ def secondary_sweep(dev, cdev, rank, world):
                        "parallelism": f"hypothesis j -> rank j mod {world}; one flat broadcast, one all-gather"}}
 
 
+def secondary_post_refine_objects(dev, cdev, rank, world, iters=24, warm=4):
+    """Secondary record, every N: BASELINE config #4, "post_refine_gs.py, 4 objects in parallel on 4 GPUs" - four 100 k
+    SH-0 objects at 1600x1200, colours only, masked L1 + SSIM, FusedAdam; object j -> rank j mod N (train.
+    post_refine_objects), one all-gather of the refined colours at the end (inside the timed region).  A timed slice
+    of `iters` iterations per object stands for the reference's 800 (README.md:153); STRONG scaling: 4 objects
+    whatever N.  Equal to the reference's joint refinement only where the objects' screen footprints are disjoint
+    (DESIGN.md, section 6); the joint model on one GPU is scripts/measure_configs.py's config #4 line."""
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.renderer import render as render3d
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import post_refine_objects
+    n_obj, n_pts = 4, 100_000
+    raws = [make_gaussians(n_pts, 0, 50 + k, extent=0.5, log_scale_mean=math.log(0.01)) for k in range(n_obj)]
+    for k, r in enumerate(raws):
+        r["xyz"] += np.array([(k % 2) * 1.2 - 0.6, (k // 2) * 1.2 - 0.6, 0], np.float32)
+    cams = ring_cameras(8, 1600, 1200, 9, device=dev)
+    bg, pipe = torch.zeros(3, device=dev), Pipe()
+    objs = [GaussianModel.from_raw(r, 0, device=dev) for r in raws]
+    mine = list(range(rank, n_obj, world))
+    masks, gts = {}, None
+    with torch.no_grad():
+        merged = GaussianModel.from_raw({kk: np.concatenate([r[kk] for r in raws]) for kk in raws[0]}, 0, device=dev)
+        gts = [render3d(c, merged, pipe, bg)["render"].clamp(0, 1) for c in cams]
+        del merged
+        for j in mine:
+            masks[j] = [(render3d(c, objs[j], pipe, bg)["render_alpha"] > 0.5).float() for c in cams]
+        g = torch.Generator(device=dev).manual_seed(7)
+        for o in objs:      # the student: perturbed colours (every rank draws the same perturbation)
+            o._features_dc.data.add_(0.3 * torch.randn(o._features_dc.shape, device=dev, generator=g))
+    alphas = [masks.get(j) for j in range(n_obj)]
+    opt = OptimizationParams()
+    post_refine_objects(objs, cams, gts, alphas, opt, iterations=warm)          # warm-up (allocations, reservation contexts)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    losses = post_refine_objects(objs, cams, gts, alphas, opt, iterations=iters)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    PairPolicy.reset()
+    ok = all(math.isfinite(v) for ls in losses.values() for v in ls)
+    return {"metric": "post-refinement object-iterations/s (config #4: 4 x 100k SH0 objects, 1600x1200, colours only)",
+            "value": round(n_obj * iters / dt, 1), "unit": "object-iterations/s", "n_gpus": world, "scaling": "strong",
+            "objects": n_obj, "iterations_timed_per_object": iters, "seconds_for_800_iterations_of_all_objects": round(800 * dt / iters, 2),
+            "losses_finite": ok,
+            "config": {"workload": "4 objects x 100k Gaussians SH0, 8 ring cameras 1600x1200, masked 0.8 L1 + 0.2 (1 - SSIM), FusedAdam",
+                       "parallelism": f"object j -> rank j mod {world}; one all-gather of the refined _features_dc"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -543,6 +599,9 @@ def main():
     sweep_rec = None
     if args.scene == "S3" and not args.no_secondary and not args.exact_backward and args.streams == 1:
         sweep_rec = secondary_sweep(dev, cdev, rank, world)
+    refine_rec = None
+    if args.scene == "S3" and not args.no_secondary and not args.exact_backward and args.streams == 1:
+        refine_rec = secondary_post_refine_objects(dev, cdev, rank, world)
     if rank == 0:
         views = args.steps * world
         value = views / dt
@@ -667,6 +726,8 @@ def main():
                 line["parity"]["full_size"]["grad_rel_l1"] = rel_l1     # north_star's norm; asserted < 1e-4 in tests/test_fullsize_gpu.py
         if sweep_rec is not None:
             line.setdefault("secondary", {})["sweep_128"] = sweep_rec
+        if refine_rec is not None:
+            line.setdefault("secondary", {})["post_refine_4obj"] = refine_rec
         if world == 1 and args.scene == "S3" and not args.no_secondary and not args.exact_backward:
             line.setdefault("secondary", {})["S6"] = secondary_s6(dev, parity=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)

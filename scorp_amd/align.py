@@ -267,12 +267,35 @@ class SweepPlan:
         return out
 
 
-def rotation_sweep(model, rotations, cameras, targets, bg, use_graph=None, plan=None, render_fn=render):
+def align_objects(models, rotations, cameras, targets_per_object, bg, render_fn=render):
+    """The rotation sweep with the OBJECT as the unit of sharding (align_3dgs_clpe_9dof.py:489-499 loops over objects
+    serially; they share no mutable state): object j -> rank j mod G, every rank sweeps all hypotheses of its objects
+    locally, and ONE fixed-size all-gather of (object, best id, best fitness) tells every rank every result.
+    Returns [(best id, best fitness)] per object, identical on every rank."""
+    from .parallel import gather_results, shard_indices
+    dev = models[0]._xyz.device
+    mine = shard_indices(len(models))
+    rows = []
+    for j in mine:
+        _, fit, best = rotation_sweep(models[j], rotations, cameras, targets_per_object[j], bg, render_fn=render_fn, shard=False)
+        rows.append(torch.stack([torch.tensor(float(best), device=fit.device), fit[best, 0].float()]))
+    v = torch.stack(rows) if rows else torch.zeros((0, 2), dtype=torch.float32, device=dev)
+    _, vals = gather_results(mine, v.to(dev), n_total=len(models))
+    return [(int(vals[j, 0]), float(vals[j, 1])) for j in range(len(models))]
+
+
+def rotation_sweep(model, rotations, cameras, targets, bg, use_graph=None, plan=None, render_fn=render, shard=True):
     """Score every rotation hypothesis (hypothesis j -> rank j mod world, one all-gather of (id, fitness) at the end);
     returns (ids, fitness[n,1], best id) on every rank.  `plan`: a SweepPlan built earlier (its graph capture is then
-    outside the caller's timed region)."""
+    outside the caller's timed region).  `shard=False`: this rank scores every hypothesis itself (align_objects)."""
     from .parallel import gather_results, shard_indices
     dev = model._xyz.device
+    if not shard:
+        if plan is None:
+            plan = SweepPlan(model, cameras, targets, bg, use_graph=use_graph, render_fn=render_fn)
+        ids = list(range(len(rotations)))
+        scores = torch.stack(plan.score(rotations, ids)) if ids else torch.zeros((0, 1), dtype=torch.float32, device=dev)
+        return torch.arange(len(ids), device=scores.device), scores, (int(torch.argmax(scores[:, 0])) if ids else -1)
     mine = shard_indices(len(rotations))
     if plan is None:
         plan = SweepPlan(model, cameras, targets, bg, use_graph=use_graph, render_fn=render_fn)

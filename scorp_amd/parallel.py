@@ -185,3 +185,32 @@ def average_gradients_sparse(params, visible, bucket_bytes=64 << 20):
         p.grad = g.view_as(p)
         off += wd
     return n
+
+
+def gather_rows(rows_by_unit, n_units, widths, c=None, device=None):
+    """Every rank ends up with the per-unit row blocks of ALL units in ONE fixed-size all-gather.  `rows_by_unit`:
+    {unit id: float32 tensor [widths[unit], c]} for the units of this rank (dealt by `shard_indices(n_units)`);
+    `widths`: the row count of every unit, known to every rank (object sizes); `c` / `device`: row width and device,
+    needed from a rank that holds no unit (more ranks than objects).  Returns a list of n_units tensors."""
+    r, w = world()
+    if c is None:
+        c = next(iter(rows_by_unit.values())).shape[1]
+    dev = device if device is not None else next(iter(rows_by_unit.values())).device
+    if w == 1:
+        return [rows_by_unit[j] for j in range(n_units)]
+    shares = [sum(widths[j] for j in range(k, n_units, w)) for k in range(w)]    # rows every rank contributes
+    m = max(shares) if shares else 0
+    buf = torch.zeros((m, c), dtype=torch.float32, device=dev)
+    off = 0
+    for j in range(r, n_units, w):
+        buf[off:off + widths[j]] = rows_by_unit[j].to(torch.float32)
+        off += widths[j]
+    out = torch.empty((w * m, c), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, buf)
+    res = [None] * n_units
+    for k in range(w):
+        off = k * m
+        for j in range(k, n_units, w):
+            res[j] = out[off:off + widths[j]]
+            off += widths[j]
+    return res

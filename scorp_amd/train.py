@@ -215,6 +215,41 @@ def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, p
     return [float(l) for l in losses]
 
 
+def post_refine_objects(objects, cameras, gt_images, object_alphas, opt, iterations=800, pipe=None, background=None, seed=0,
+                        refine_fn=None):
+    """BASELINE config #4, "4 objects in parallel on 4 GPUs": the 800-iteration appearance refinement with the OBJECT as
+    the unit of sharding - object j -> rank j mod G, every rank refines its objects against the per-object
+    masks (`masked_image_rgba/<prompt>/`, segmentation_2d.py:79), and ONE fixed-size all-gather hands every rank the
+    refined `_features_dc` of every object (what post_refine_gs.py:197-202 writes out per object).
+
+    This is NOT the reference's computation wherever objects overlap on screen: post_refine_gs.py:40-50,103-111 trains the
+    concatenation of all objects against the UNION mask, so an object seen through or in front of another one receives
+    gradient from the blend of both; refined separately, each object only explains its own mask.  The two agree exactly
+    where the screen footprints are disjoint (tests/test_parallel_cpu.py); use `post_refine` on the merged model - one
+    GPU - when they are not.
+
+    `objects`: list of SH-0 GaussianModels (identical on every rank); `object_alphas[j][k]`: mask of object j in view k.
+    Returns the per-iteration losses of this rank's objects ({j: [...]}); every object's `_features_dc` is updated in
+    place on every rank."""
+    from .parallel import gather_rows, shard_indices
+    refine_fn = refine_fn or post_refine
+    n = len(objects)
+    mine = shard_indices(n)
+    losses = {}
+    for j in mine:
+        losses[j] = refine_fn(objects[j], cameras, gt_images, object_alphas[j], opt, iterations=iterations, pipe=pipe,
+                              background=background, seed=seed + j)
+    widths = [int(o._features_dc.shape[0]) for o in objects]
+    rows = {j: objects[j]._features_dc.detach().reshape(widths[j], -1) for j in mine}
+    # (a rank without an object - more ranks than objects - still takes part in the collective)
+    gathered = gather_rows(rows, n, widths, c=objects[0]._features_dc[0].numel(), device=objects[0]._features_dc.device)
+    with torch.no_grad():
+        for j in range(n):
+            if j not in losses:
+                objects[j]._features_dc.data.copy_(gathered[j].to(objects[j]._features_dc).view_as(objects[j]._features_dc))
+    return losses
+
+
 @torch.no_grad()
 def evaluate_psnr(gaussians, cameras, gt_images, pipe=None, background=None):
     pipe = pipe or PipelineParams()

@@ -94,7 +94,8 @@ def test_full_size_parity_vs_oracle_2d(dev, parallel_oracle):
     kw = _scene_kw("S6")
     kw["scale_modifier"] = 1.0
     report = {}
-    _parity_2d(dict(seed=6), dev, report=report, kw=kw)
+    # tie_outliers: at 1 M surfels a few dozen have a pixel ON the low-pass switch (tests.util.assert_grad_close)
+    _parity_2d(dict(seed=6), dev, report=report, kw=kw, tie_outliers=64)
     print("\nS6 full size: gradients (max-norm, rel L1): " + ", ".join(f"{k} {v[0]:.1e}/{v[1]:.1e}" for k, v in report.items()))
 
 

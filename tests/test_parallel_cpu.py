@@ -360,3 +360,86 @@ def test_sparse_gradient_average_equals_dense_on_two_gloo_ranks():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+# ---- object-level sharding (SURVEY §8e rows "align: objects" and "post_refine: 4 objects on 4 GPUs"), two gloo ranks ----
+def _objects_setup():
+    import copy
+    from scorp_amd.align import render_views
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.synthetic import make_gaussians
+    from scorp_amd.transforms import gaussians_rotate
+    rots = np.load(os.path.join(os.path.dirname(__file__), "golden", "rotations_128.npz"))["rotations"][:12]
+    cams = [_SweepCam(k) for k in range(3)]
+    objs, targets, planted = [], [], [7, 3, 10]
+    for j, pl in enumerate(planted):
+        raw = make_gaussians(300 + 40 * j, 0, 20 + j, extent=0.8)
+        raw["xyz"][:, 0] *= 1.8
+        obj = GaussianModel.from_raw(raw, 0, device="cpu")
+        tgt = copy.copy(obj)
+        tgt._xyz, tgt._rotation, tgt._features_rest = obj._xyz.detach().clone(), obj._rotation.detach().clone(), obj._features_rest.detach().clone()
+        gaussians_rotate(tgt, torch.tensor(rots[pl], dtype=torch.float32), fix_center=True)
+        objs.append(obj)
+        targets.append(render_views(tgt, cams, torch.zeros(3), render_fn=_standin_render))
+    return objs, rots, cams, targets, planted
+
+
+def _standin_refine(obj, cams, gts, alphas, opt, iterations=5, pipe=None, background=None, seed=0):
+    """A stand-in for post_refine (the HIP renderer needs a GPU): a few Adam steps on _features_dc only."""
+    g = torch.Generator().manual_seed(seed)
+    target = torch.rand(obj._features_dc.shape, generator=g)
+    o = torch.optim.Adam([obj._features_dc], lr=0.05)
+    losses = []
+    for _ in range(iterations):
+        loss = ((obj._features_dc - target) ** 2).mean()
+        o.zero_grad()
+        loss.backward()
+        o.step()
+        losses.append(float(loss))
+    return losses
+
+
+def _objects_worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from scorp_amd.align import align_objects
+        from scorp_amd.gaussian_model import OptimizationParams
+        from scorp_amd.train import post_refine_objects
+        objs, rots, cams, targets, planted = _objects_setup()
+        res = align_objects(objs, rots, cams, targets, torch.zeros(3), render_fn=_standin_render)
+        losses = post_refine_objects(objs, cams, None, [None] * len(objs), OptimizationParams(), iterations=5, refine_fn=_standin_refine)
+        q.put((rank, "ok", res, sorted(losses), [o._features_dc.detach().numpy().tolist() for o in objs]))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_object_sharding_on_two_gloo_ranks():
+    """align_objects / post_refine_objects: object j -> rank j mod 2, ONE all-gather each.  Both ranks end with every
+    object's best hypothesis and every object's refined colours, equal to the single-process run; a rank only refines
+    its own objects."""
+    from scorp_amd.align import align_objects
+    from scorp_amd.gaussian_model import OptimizationParams
+    from scorp_amd.train import post_refine_objects
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_objects_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    objs, rots, cams, targets, planted = _objects_setup()
+    single = align_objects(objs, rots, cams, targets, torch.zeros(3), render_fn=_standin_render)
+    assert [b for b, _ in single] == planted
+    post_refine_objects(objs, cams, None, [None] * len(objs), OptimizationParams(), iterations=5, refine_fn=_standin_refine)
+    for rank, _, got, mine, fdc in sorted(res, key=lambda r: r[0]):
+        assert [b for b, _ in got] == planted and [f for _, f in got] == pytest.approx([f for _, f in single], abs=1e-6)
+        assert mine == list(range(rank, 3, 2))                       # this rank refined objects rank, rank + 2, ...
+        for a, b in zip(fdc, objs):
+            assert torch.allclose(torch.tensor(a), b._features_dc.detach(), atol=1e-7)

@@ -335,3 +335,52 @@ def test_train_view2d_equals_render_loss_regularizers_backward(dev):
         va, vb = pa["viewspace_points"].grad, pb["viewspace_points"].grad
         assert float((va - vb).abs().max()) <= 2e-3 * float(va.abs().max()) + 1e-12
     PairPolicy.reset()
+
+
+def test_post_refine_objects_equals_the_joint_model_where_footprints_are_disjoint(dev):
+    """BASELINE config #4 sharded by object (train.post_refine_objects) against the reference's joint refinement of the
+    concatenated model under the union mask (post_refine_gs.py:40-50,103-111): with screen footprints that never meet
+    (two objects one above the other, cameras on a ring around the vertical axis) the loss decomposes and the refined
+    colours agree; the objects' frozen leaves do not move either way."""
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.renderer import render
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams, post_refine, post_refine_objects
+    raws = []
+    for k, z in enumerate((-0.9, 0.9)):
+        r = make_gaussians(2500, 0, 60 + k, extent=0.35, log_scale_mean=math.log(0.03))
+        r["xyz"][:, 2] += z
+        r["opacity"] += 1.0
+        raws.append(r)
+    cams = ring_cameras(4, 208, 160, 5, radius=4.0, device=dev)
+    bg, pipe = torch.zeros(3, device=dev), PipelineParams()
+    teachers = [GaussianModel.from_raw(r, 0, device=dev) for r in raws]
+    with torch.no_grad():
+        pk = [[render(c, t, pipe, bg) for c in cams] for t in teachers]
+    masks = [[(p["render_alpha"] > 0.02).float() for p in row] for row in pk]
+    for k in range(len(cams)):      # the footprints (grown by the SSIM window) never meet
+        grow = lambda m: torch.nn.functional.max_pool2d(m[None], 13, 1, 6)[0]
+        assert float((grow(masks[0][k]) * grow(masks[1][k])).sum()) == 0.0
+    gts = [(pk[0][k]["render"] + pk[1][k]["render"]).clamp(0, 1) for k in range(len(cams))]
+    rng = np.random.default_rng(3)
+    pert = [dict(r, features_dc=r["features_dc"] + rng.normal(0, 0.5, r["features_dc"].shape).astype(np.float32)) for r in raws]
+    merged = {kk: np.concatenate([p[kk] for p in pert]) for kk in pert[0]}
+    joint = GaussianModel.from_raw(merged, 0, device=dev)
+    union = [torch.maximum(masks[0][k], masks[1][k]) for k in range(len(cams))]
+    post_refine(joint, cams, gts, union, OptimizationParams(), iterations=24, seed=5)
+    objs = [GaussianModel.from_raw(p, 0, device=dev) for p in pert]
+    # (same camera order for every object: post_refine_objects seeds object j with seed + j, so give it the joint's draw)
+    for j, o in enumerate(objs):
+        post_refine(o, cams, gts, masks[j], OptimizationParams(), iterations=24, seed=5)
+    got = torch.cat([o._features_dc.detach() for o in objs])
+    ref = joint._features_dc.detach()
+    moved = (ref - torch.tensor(merged["features_dc"], device=dev)).abs().mean()
+    assert float(moved) > 1e-3
+    assert float((got - ref).abs().max()) < 2e-3 * float(moved) + 2e-5, (float((got - ref).abs().max()), float(moved))
+    # and the driver itself (one process: both objects are this rank's), colours gathered in place
+    objs2 = [GaussianModel.from_raw(p, 0, device=dev) for p in pert]
+    losses = post_refine_objects(objs2, cams, gts, masks, OptimizationParams(), iterations=6)
+    assert sorted(losses) == [0, 1] and all(len(v) == 6 for v in losses.values())
+    for o, p in zip(objs2, pert):
+        assert torch.equal(o._xyz.detach(), torch.tensor(p["xyz"], device=dev))
+        assert not torch.equal(o._features_dc.detach(), torch.tensor(p["features_dc"], device=dev))

@@ -85,7 +85,7 @@ def grad_errors(got, ref):
 BAND_TALLY = {"checked": 0, "fallback": 0, "names": []}
 
 
-def assert_grad_close(name, got, ref32, band_fn, max_tol, l1_tol, k=3.0):
+def assert_grad_close(name, got, ref32, band_fn, max_tol, l1_tol, k=3.0, outliers=0, outlier_tol=0.0):
     """A gradient tensor of the HIP path against the oracle.
 
     First against the fp32 oracle as it stands: max-norm error < max_tol and relative L1 error < l1_tol (north_star's
@@ -98,7 +98,14 @@ def assert_grad_close(name, got, ref32, band_fn, max_tol, l1_tol, k=3.0):
     ELEMENT BY ELEMENT with what the oracle itself cannot decide: band = max |difference| between the fp32 oracle and
     (a) its float64 build, (b), (c) the fp32 oracle on inputs perturbed by 4e-6 relative (band_fn(name) returns those
     three gradient arrays).  It passes if, after allowing k x band per element, the remaining error meets the two
-    tolerances, and if the elements that needed the allowance are few (< 0.5 %)."""
+    tolerances, and if the elements that needed the allowance are few (< 0.5 %).
+
+    `outliers` / `outlier_tol` (full-size 2DGS only): up to `outliers` ELEMENTS may miss the max-norm tolerance beyond the
+    band, by at most `outlier_tol` of the tensor's maximum; the L1 tolerance still holds with them in.  They are surfels
+    with a pixel on which rho3d == rho2d to ~1e-5 relative (the low-pass switch): the intersection k = x Tw - Tu cancels
+    to 1e-4 of its terms (Tu.z ~ x Tw.z ~ 5e3 px), so that tie is decided by the last bit of T itself - the fp32 and fp64
+    oracles may agree on it by luck while a third correct fp32 implementation does not (scripts/dev/diag_s6.py lists
+    them: ~20 of 1 M surfels; the HIP form's rho3d is within 1e-6 of fp64 there, the fp32 oracle's within 4e-4)."""
     e32 = grad_errors(got, ref32)
     BAND_TALLY["checked"] += 1
     if e32[0] < max_tol and e32[1] < l1_tol:
@@ -114,7 +121,10 @@ def assert_grad_close(name, got, ref32, band_fn, max_tol, l1_tol, k=3.0):
     excess = np.maximum(np.abs(g - ref) - k * band, 0.0)
     scale, total = max(np.abs(ref).max(), 1e-300), max(np.abs(ref).sum(), 1e-300)
     needed = float(((np.abs(g - ref) > max_tol * scale) & (excess <= max_tol * scale)).mean())
-    ok = excess.max() / scale < max_tol and excess.sum() / total < l1_tol and needed < 5e-3
+    over = excess > max_tol * scale
+    max_ok = excess.max() / scale < max_tol or (int(over.sum()) <= outliers and excess.max() / scale < outlier_tol)
+    ok = max_ok and excess.sum() / total < l1_tol and needed < 5e-3
     assert ok, (f"grad {name}: vs fp32 oracle max {e32[0]:.3e} L1 {e32[1]:.3e}; beyond {k} x the oracle's own band: max "
-                f"{excess.max() / scale:.3e} L1 {excess.sum() / total:.3e}, elements that needed the band {needed:.2e}")
+                f"{excess.max() / scale:.3e} L1 {excess.sum() / total:.3e}, elements that needed the band {needed:.2e}, "
+                f"elements beyond the max-norm tolerance {int(over.sum())} (allowed {outliers})")
     return e32
