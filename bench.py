@@ -526,12 +526,15 @@ def main():
     _C.prof_enable(False)
     # the same step with the blend backward's pixel->splat reduction on fp32 MFMAs throughout (SCORP_BACKWARD_EXACT_FP32),
     # same protocol: the headline next to its all-fp32 twin
-    dt_exact = None
+    dt_exact = dt_det = None
     if fused_view and side_streams is None and not args.exact_backward:
         prev_flags = getattr(R._tls, "backward_flags", 0)
         R._tls.backward_flags = _C.BACKWARD_EXACT_FP32
         try:
             dt_exact = timed_run(min(args.warmup, 10), args.steps)[0]
+            # ... and with SCORP_BACKWARD_DETERMINISTIC: no float atomics, plain partial rows + an ordered per-Gaussian sum
+            R._tls.backward_flags = _C.BACKWARD_DETERMINISTIC
+            dt_det = timed_run(min(args.warmup, 5), args.steps)[0]
         finally:
             R._tls.backward_flags = prev_flags
     # extra (not part of `value`): forward-only render rate, the unit of the alignment sweep / test-view rendering
@@ -587,10 +590,11 @@ def main():
         R.LAST_FORWARD = None
         work = {"forward_block_splat_iterations": int(o3[0]), "backward_block_splat_iterations": int(o3[1]), "blocks_8x8": int(o3[2])}
     if world > 1:
-        tt = torch.tensor([dt, dt_host, dt_exact or 0.0], device=cdev, dtype=torch.float64)
+        tt = torch.tensor([dt, dt_host, dt_exact or 0.0, dt_det or 0.0], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, dt_host = float(tt[0]), float(tt[1])
         dt_exact = float(tt[2]) if dt_exact is not None else None
+        dt_det = float(tt[3]) if dt_det is not None else None
         ll = torch.tensor([float(loss.detach())], device=cdev)
         gathered = [torch.zeros_like(ll) for _ in range(world)]
         dist.all_gather(gathered, ll)     # gather of per-rank results (scalars)
@@ -668,6 +672,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "value_exact_fp32": None if dt_exact is None else round(views / dt_exact, 3),
             "ms_per_step_exact_fp32": None if dt_exact is None else round(dt_exact / args.steps * 1e3, 4),
+            "value_deterministic_backward": None if dt_det is None else round(views / dt_det, 3),
+            "ms_per_step_deterministic_backward": None if dt_det is None else round(dt_det / args.steps * 1e3, 4),
             "timing": {"clock": "hipEvents on the launch stream, recorded directly behind the warm-up views and behind the last timed view "
                                 "(max over ranks); barrier + synchronize before the warm-up and after the region",
                        "host_clock_ms_per_step": round(dt_host / args.steps * 1e3, 4),

@@ -65,7 +65,7 @@ class ScorpAdamTensor(ctypes.Structure):
 
 EXPORTS = [
     "scorp_version", "scorp_source_sha", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
-    "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
+    "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_backward_scratch_bytes_ex", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
     "scorp_gs3d_render_image",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_backward_ex", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles", "scorp_gs3d_debug_work",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
@@ -81,6 +81,7 @@ EXPORTS = [
 
 BACKWARD_EXACT_FP32 = 1   # scorp_gs3d_backward_ex flag (include/scorp_gs.h)
 BACKWARD_SCRATCH_ZEROED = 2   # scorp_gs3d_backward_ex flag: the caller cleared the accumulator rows already
+BACKWARD_DETERMINISTIC = 4    # scorp_gs3d_backward_ex flag: no float atomics (plain partial rows + an ordered per-Gaussian sum)
 
 _lib = None
 
@@ -107,6 +108,8 @@ def lib():
     L.scorp_gs3d_pairs_bytes.argtypes = [u64]
     L.scorp_gs3d_backward_scratch_bytes.restype = sz
     L.scorp_gs3d_backward_scratch_bytes.argtypes = [i32]
+    L.scorp_gs3d_backward_scratch_bytes_ex.restype = sz
+    L.scorp_gs3d_backward_scratch_bytes_ex.argtypes = [i32, i32, i32, u64, ctypes.c_uint32]
     L.scorp_gs3d_preprocess.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, sz, vp]
     L.scorp_gs3d_num_pairs.argtypes = [vp, vp, ctypes.POINTER(u64)]
     L.scorp_gs3d_render.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp, vp]

@@ -109,14 +109,15 @@ constexpr BasisTable make_basis_table() {
 __device__ const BasisTable kBasisV = make_basis_table();
 
 #if SCORP_EXP_MFMA
-template <bool kHasDA, bool kExact, bool kColorOnly = false>
+// kDet: SCORP_BACKWARD_DETERMINISTIC - the sums leave as plain rows partial[quad][hit-list position] instead of float atomics
+template <bool kHasDA, bool kExact, bool kColorOnly = false, bool kDet = false>
 __global__ void __launch_bounds__(64, SCORP_BWD_WAVES)
 blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ hits,
                            const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                            const float *__restrict__ bg, const float *__restrict__ final_T,
                            const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
                            const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dalpha,
-                           float *__restrict__ acc) {
+                           float *__restrict__ acc, float *__restrict__ partial, uint32_t *__restrict__ block_todo) {
   // staged hits: the three bf16 terms of the six block-frame coefficients of log2(opacity * G) (exp_mfma.hpp), the
   // blended values (r, g, b, depth) for the recurrence, and what the moment step needs: (x - cx, y - cy, A, B), (C, opacity), id
   __shared__ uint4 q_k[3][kChunk];
@@ -147,7 +148,10 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   const int a_slot = a_operand_slot(lane);
   if (lane < 3) *reinterpret_cast<uint4 *>(&xm[(13 + lane) * kXStride + 64]) = make_uint4(0u, 0u, 0u, 0u);
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  if (end == beg) return;
+  // deterministic mode (partial != NULL): the sums leave as plain rows partial[quad][hit-list position], and the
+  // per-Gaussian reduction needs to know how many of a block's hits were replayed
+  constexpr bool det = kDet;
+  if (end == beg) { if (det && lane == 0) block_todo[tile * 4 + quad] = 0u; return; }
   const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
   // all of the pixel's loads are issued together (no load waits on `last`); pixels nothing was blended into drop
   // their upstream gradient afterwards by a select (it may be NaN: depth / alpha at empty pixels)
@@ -162,6 +166,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   }
   if (last == 0) { dpix0 = dpix1 = dpix2 = ddep = dalp = 0.0f; }
   const uint32_t todo = wave_max_u32(last);   // wave-uniform (SGPR): the chunk loop and the slot indices live in SGPRs
+  if (det && lane == 0) block_todo[tile * 4 + quad] = todo;
   if (todo == 0) return;
   // split form: one power-of-two scale per wave from the block's largest upstream gradient
   float sv = 1.0f, inv_sv = 1.0f;
@@ -231,8 +236,19 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   float T = kExact ? T_final : kWScale * T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
   const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
   float park_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // a group's sums, parked until flush_sums
-  uint32_t park_o[4] = {0u, 0u, 0u, 0u};        // ... and their float offsets in acc (N * 16 < 2^32, checked at the entry point)
+  uint32_t park_o[4] = {det ? 0xFFFFFFFFu : 0u, det ? 0xFFFFFFFFu : 0u, det ? 0xFFFFFFFFu : 0u, det ? 0xFFFFFFFFu : 0u};
+                                                // ... and their float offsets in acc (N * 16 < 2^32, checked at the entry
+                                                // point); det: offsets in `partial`, 0xFFFFFFFF = nothing parked
+  const uint32_t prow0 = (uint32_t)quad * capacity + beg;   // det: first row of this block's slice of `partial`
   auto flush_sums = [&]() {
+    if (det) {   // rows are written whole (zeros included): nothing was cleared beforehand
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (park_o[k] != 0xFFFFFFFFu) partial[park_o[k]] = park_v[k];
+        park_o[k] = 0xFFFFFFFFu;
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (park_v[k] != 0.0f) atomicAdd(acc + park_o[k], park_v[k]);
@@ -403,7 +419,14 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     for (int k = 0; k < 4; k++) {
       const int sl = 4 * k + (lane >> 4), col = lane & 15;
       park_v[k] = 0.0f;
-      if (sl < nslots && (kColorOnly ? (col >= 6 && col < 9) : col < 10)) {
+      if (det) {
+        park_o[k] = 0xFFFFFFFFu;
+        if (sl < nslots && col < 10) {   // slot sl of this group is hit number top - sl (1-based) of the block's list
+          const bool used = kColorOnly ? (col >= 6 && col < 9) : true;
+          park_v[k] = used ? dbuf[sl * kDStride + col] : 0.0f;
+          park_o[k] = (prow0 + (uint32_t)(top - sl) - 1u) * (uint32_t)kAccStride + col;
+        }
+      } else if (sl < nslots && (kColorOnly ? (col >= 6 && col < 9) : col < 10)) {
         park_v[k] = dbuf[sl * kDStride + col];
         park_o[k] = q_id[head + sl] * (uint32_t)kAccStride + col;
       }
@@ -798,10 +821,68 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
 
 #endif   // SCORP_EXP_MFMA
 
+// ---------------------------------------------------------------------------------------------------------
+// Deterministic mode, second half: one thread per Gaussian sums the partial rows of the (8x8 block, hit) pairs it
+// belongs to, in a fixed order: tiles of its rectangle (those its exact tile mask keeps) in row-major order, the four
+// blocks of a tile in order.  A block's hit list is depth-sorted - by (depth bits, index), the key of the tile sort - so
+// the Gaussian's position in it is found by binary search; it may be absent (the block's exact footprint test dropped
+// it) or beyond the part of the list the backward replayed (block_todo): then it has no row there.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
+                       const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ hits, uint32_t capacity,
+                       int tiles_x, const uint32_t *__restrict__ block_todo, const float *__restrict__ partial,
+                       float *__restrict__ acc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float sum[10];
+#pragma unroll
+  for (int c = 0; c < 10; c++) sum[c] = 0.0f;
+  const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
+  const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
+  if ((br.radius & kRadiusMask) != 0) {
+    const uint64_t my_key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
+    for_each_tile(br.x0, br.y0, br.x1, br.y1, tile_mask[i], tiles_x, [&](int t) {
+      const uint32_t beg = min(tile_start[t], capacity);
+      for (int q = 0; q < 4; q++) {
+        const uint32_t n = block_todo[t * 4 + q];
+        const uint32_t *list = hits + (size_t)q * capacity + beg;
+        uint32_t lo = 0, hi = n;   // first position whose key is >= mine
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          const uint32_t id = list[mid];
+          const uint64_t key = ((uint64_t)bin[id].depth_bits << 32) | id;
+          if (key < my_key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < n && list[lo] == (uint32_t)i) {
+          const float4 *row = reinterpret_cast<const float4 *>(partial + ((size_t)q * capacity + beg + lo) * kAccStride);
+          const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+          sum[0] += r0.x; sum[1] += r0.y; sum[2] += r0.z; sum[3] += r0.w; sum[4] += r1.x; sum[5] += r1.y;
+          sum[6] += r1.z; sum[7] += r1.w; sum[8] += r2.x; sum[9] += r2.y;
+        }
+      }
+    });
+  }
+  float4 *dst = reinterpret_cast<float4 *>(acc + (size_t)i * kAccStride);
+  dst[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
+  dst[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
+  dst[2] = make_float4(sum[8], sum[9], 0.0f, 0.0f);
+}
+
 }  // namespace
 }  // namespace scorp
 
 using namespace scorp;
+
+extern "C" size_t scorp_gs3d_backward_scratch_bytes_ex(int32_t N, int32_t W, int32_t H, uint64_t capacity, uint32_t flags) {
+  size_t bytes = align_up((size_t)(N > 0 ? N : 1) * kAccStride * sizeof(float), 256);
+  if (flags & SCORP_BACKWARD_DETERMINISTIC) {
+    const StateLayout L(N, W, H);
+    bytes += align_up((size_t)L.tiles * 4 * sizeof(uint32_t), 256);
+    bytes += align_up((size_t)(capacity > 0 ? capacity : 1) * 4 * kAccStride * sizeof(float), 256);
+  }
+  return bytes;
+}
 
 extern "C" size_t scorp_gs3d_backward_scratch_bytes(int32_t N) {
   return align_up((size_t)(N > 0 ? N : 1) * kAccStride * sizeof(float), 256);
@@ -831,14 +912,24 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
   }
   const StateLayout L(N, W, H);
   const PairLayout P(capacity);
-  const size_t need = scorp_gs3d_backward_scratch_bytes(N);
+  const bool det = (flags & SCORP_BACKWARD_DETERMINISTIC) != 0;
+  const size_t need = scorp_gs3d_backward_scratch_bytes_ex(N, W, H, capacity, flags);
+  if (det && capacity * 4 * kAccStride > 0xFFFFFFFFull) { set_error("capacity too large for the deterministic backward"); return SCORP_ERR_INVALID; }
   if (scratch_bytes < need || ((uintptr_t)scratch & 15)) {
     set_error("backward scratch too small or misaligned (%zu < %zu)", scratch_bytes, need);
     return SCORP_ERR_INVALID;
   }
   const char *base = (const char *)state, *pb = (const char *)pairs;
   float *acc = (float *)scratch;
-  if (!(flags & SCORP_BACKWARD_SCRATCH_ZEROED)) SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAccStride * sizeof(float), stream));
+  uint32_t *block_todo = nullptr;
+  float *partial = nullptr;
+  if (det) {   // [accumulator rows][one word per block][4 x capacity partial rows]
+    char *p = (char *)scratch + align_up((size_t)N * kAccStride * sizeof(float), 256);
+    block_todo = (uint32_t *)p;
+    partial = (float *)(p + align_up((size_t)L.tiles * 4 * sizeof(uint32_t), 256));
+  } else if (!(flags & SCORP_BACKWARD_SCRATCH_ZEROED)) {
+    SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAccStride * sizeof(float), stream));
+  }
   {
     ProfScope prof(kKBlendBackward, stream);
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
@@ -846,15 +937,38 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
     // nothing but colour gradients wanted (every geometry / opacity output NULL): the colour-only replay
     const bool color_only = !exact && !grads->means3D && !grads->means2D && !grads->opacities && !grads->scales &&
                             !grads->rotations && !grads->cov3D_precomp;
+#if SCORP_EXP_MFMA
+    auto wk = det ? (color_only ? blend_backward_wave_kernel<false, false, true, true>
+                     : exact ? (da ? blend_backward_wave_kernel<true, true, false, true> : blend_backward_wave_kernel<false, true, false, true>)
+                             : (da ? blend_backward_wave_kernel<true, false, false, true> : blend_backward_wave_kernel<false, false, false, true>))
+              : color_only ? blend_backward_wave_kernel<false, false, true>
+              : exact ? (da ? blend_backward_wave_kernel<true, true> : blend_backward_wave_kernel<false, true>)
+                      : (da ? blend_backward_wave_kernel<true, false> : blend_backward_wave_kernel<false, false>);
+#else
     auto wk = color_only ? blend_backward_wave_kernel<false, false, true>
               : exact ? (da ? blend_backward_wave_kernel<true, true> : blend_backward_wave_kernel<false, true>)
                       : (da ? blend_backward_wave_kernel<true, false> : blend_backward_wave_kernel<false, false>);
+#endif
     wk<<<blocks, 64, 0, stream>>>(
         (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.hits), (const SplatRec *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),
-        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc);
+        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc
+#if SCORP_EXP_MFMA
+        , partial, block_todo
+#endif
+        );
   }
   SCORP_KERNEL_CHECK("blend_backward", in->debug, stream);
+  if (det) {
+#if SCORP_EXP_MFMA
+    reduce_partials_kernel<<<(N + 255) / 256, 256, 0, stream>>>(
+        N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), (const uint32_t *)(base + L.tile_start),
+        (const uint32_t *)(pb + P.hits), (uint32_t)capacity, L.tiles_x, block_todo, partial, acc);
+    SCORP_KERNEL_CHECK("reduce_partials", in->debug, stream);
+#else
+    set_error("SCORP_BACKWARD_DETERMINISTIC needs the SCORP_EXP_MFMA build"); return SCORP_ERR_INVALID;
+#endif
+  }
   {
     ProfScope prof(kKPreprocessBackward, stream);
     launch_preprocess_backward(in, L, (const BinRec *)(base + L.bin), acc, grads, stream);

@@ -137,6 +137,12 @@ class PairPolicy:
 
 
 _tls = threading.local()
+# SCORP_BACKWARD_DETERMINISTIC=1: every backward of this process runs the atomic-free form (include/scorp_gs.h)
+_ENV_FLAGS = _C.BACKWARD_DETERMINISTIC if __import__("os").environ.get("SCORP_BACKWARD_DETERMINISTIC", "0") not in ("", "0") else 0
+
+
+def _backward_flags():
+    return int(getattr(_tls, "backward_flags", 0)) | _ENV_FLAGS
 
 
 @contextlib.contextmanager
@@ -144,10 +150,14 @@ def backward_precision(mode):
     """Forwards issued inside `with backward_precision("exact_fp32"):` run their backward with fp32 MFMAs throughout
     (scorp_gs3d_backward_ex, SCORP_BACKWARD_EXACT_FP32) instead of the default two-term fp16 split of the pixel->splat
     reduction.  The choice is recorded per forward (thread-local while the block is active), so a backward that runs
-    after the block still honours it.  Used by the parity tests to compare the two forms."""
-    assert mode in ("split", "exact_fp32")
+    after the block still honours it.  Used by the parity tests to compare the two forms.
+    "deterministic" / "exact_fp32_deterministic": the same reductions with the sums leaving as plain per-(block, hit) rows
+    that a second kernel adds per Gaussian in a fixed order (SCORP_BACKWARD_DETERMINISTIC): no float atomics, two runs
+    give the same bits - what a caller that votes on gradient SIGNS wants (utils/mask.py:52,65,89,124)."""
+    assert mode in ("split", "exact_fp32", "deterministic", "exact_fp32_deterministic")
     prev = getattr(_tls, "backward_flags", 0)
-    _tls.backward_flags = _C.BACKWARD_EXACT_FP32 if mode == "exact_fp32" else 0
+    _tls.backward_flags = (_C.BACKWARD_EXACT_FP32 if mode.startswith("exact_fp32") else 0) | \
+                          (_C.BACKWARD_DETERMINISTIC if mode.endswith("deterministic") else 0)
     try:
         yield
     finally:
@@ -254,7 +264,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         gc = _prep(grad_color, "grad_color")
         gd = _prep(grad_depth, "grad_depth") if grad_depth is not None else None
         ga = _prep(grad_alpha, "grad_alpha") if grad_alpha is not None else None
-        scratch_bytes = L.scorp_gs3d_backward_scratch_bytes(N)
+        scratch_bytes = L.scorp_gs3d_backward_scratch_bytes_ex(N, int(s.image_width), int(s.image_height), ctx.capacity, ctx.backward_flags)
         scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
         _C.check(L.scorp_gs3d_backward_ex(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(gd),
                                           _ptr(ga), ctypes.byref(grads), _ptr(scratch), scratch_bytes, ctx.backward_flags,
@@ -298,7 +308,7 @@ def _forward_common(ctx, settings, means3D, sh, sh_rest, colors_precomp, opaciti
         global LAST_FORWARD
         LAST_FORWARD = (state, N, W, H)
     ctx.settings, ctx.capacity = settings, capacity
-    ctx.backward_flags = getattr(_tls, "backward_flags", 0)
+    ctx.backward_flags = _backward_flags()
     ctx.set_materialize_grads(False)   # unused outputs arrive as None in backward: the kernels skip those terms
     return color, radii, depth, alpha, state, pairs, keep
 
@@ -344,7 +354,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         gc = _prep(grad_color, "grad_color")
         gd = _prep(grad_depth, "grad_depth") if grad_depth is not None else None
         ga = _prep(grad_alpha, "grad_alpha") if grad_alpha is not None else None
-        scratch_bytes = L.scorp_gs3d_backward_scratch_bytes(N)
+        scratch_bytes = L.scorp_gs3d_backward_scratch_bytes_ex(N, int(s.image_width), int(s.image_height), ctx.capacity, ctx.backward_flags)
         scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
         _C.check(L.scorp_gs3d_backward_ex(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(gd),
                                           _ptr(ga), ctypes.byref(grads), _ptr(scratch), scratch_bytes, ctx.backward_flags,

@@ -19,7 +19,7 @@ import math
 import torch
 
 from . import _C
-from .rasterizer3d import GaussianRasterizationSettings, PairPolicy, _inputs_struct, _prep, _ptr, _stream, _tls
+from .rasterizer3d import GaussianRasterizationSettings, PairPolicy, _backward_flags, _inputs_struct, _prep, _ptr, _stream
 
 
 def _accumulate(p, g):
@@ -63,7 +63,8 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     pairs = new((L.scorp_gs3d_pairs_bytes(capacity),), torch.uint8)
     ws_bytes = L.scorp_loss_workspace_bytes(3, H, W)
     ws = new((ws_bytes,), torch.uint8)
-    scratch_bytes = L.scorp_gs3d_backward_scratch_bytes(N)
+    flags = _backward_flags()     # rasterizer3d.backward_precision(...) / SCORP_BACKWARD_DETERMINISTIC reach the one-call view too
+    scratch_bytes = L.scorp_gs3d_backward_scratch_bytes_ex(N, W, H, capacity, flags)
     scratch = new((scratch_bytes,), torch.uint8)
     need = [p.requires_grad for p in leaves]          # frozen leaves (post-refine) get no gradient buffer: NULL = not wanted
     need[1] = need[2] = need[1] or need[2]            # the SH gradient is written as a whole
@@ -80,7 +81,7 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     v.out_color, v.out_depth_raw, v.out_alpha = color.data_ptr(), depth_raw.data_ptr(), alpha.data_ptr()
     v.out_depth, v.out_visible = depth.data_ptr(), visible.data_ptr()
     v.gt, v.mask, v.lambda_dssim = gt.data_ptr(), (None if mask is None else mask.data_ptr()), float(lambda_dssim)
-    v.backward_flags = int(getattr(_tls, "backward_flags", 0))     # rasterizer3d.backward_precision("exact_fp32") reaches the one-call view too
+    v.backward_flags = flags
     v.out_loss3, v.loss_workspace, v.loss_workspace_bytes = loss3.data_ptr(), ws.data_ptr(), ws_bytes
     v.grad_color, v.grads = grad_color.data_ptr(), ctypes.addressof(grads)
     v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes

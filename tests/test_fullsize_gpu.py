@@ -88,6 +88,39 @@ def test_full_size_parity_vs_oracle_photometric(dev, parallel_oracle):
         compare_grads(t, g, g64_fn=oracle64_grads(kw, w, None, None))
 
 
+def test_full_size_deterministic_backward(dev):
+    """S3 through the one-call view with SCORP_BACKWARD_DETERMINISTIC: two views of the same camera give bit-identical
+    gradients on all six leaves, equal to the default (float-atomic) backward within 2e-5 relative L1."""
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.rasterizer3d import PairPolicy, backward_precision
+    from scorp_amd.synthetic import SCENES, make_gaussians, ring_cameras
+    from scorp_amd.train_view import train_view
+    N, W, H, deg, seed, _ = SCENES["S3"]
+    raw = make_gaussians(N, deg, seed)
+    cam = ring_cameras(280, W, H, seed, device=dev)[5]
+    bg, pipe = torch.zeros(3, device=dev), _Pipe()
+    gt = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    PairPolicy.reset()
+
+    def run(mode):
+        m = GaussianModel.from_raw(raw, deg, device=dev)
+        m.active_sh_degree = deg
+        with backward_precision(mode):
+            out = train_view(cam, m, pipe, bg, gt, 0.2)
+        PairPolicy.drain()
+        return {n: getattr(m, n).grad.detach().clone() for n in names}, out["viewspace_points"].grad.detach().clone()
+    try:
+        (g1, v1), (g2, v2), (ga, va) = run("deterministic"), run("deterministic"), run("split")
+        assert torch.equal(v1, v2)
+        for n in names:
+            assert torch.equal(g1[n], g2[n]), n
+            l1 = float((g1[n].double() - ga[n].double()).abs().sum() / ga[n].double().abs().sum())
+            assert l1 < 2e-5, (n, l1)
+    finally:
+        PairPolicy.reset()
+
+
 def test_full_size_parity_vs_oracle_2d(dev, parallel_oracle):
     """S6: 1 M surfels at 1600x1200, SH3 - the 2-D oracle's first full-size frame."""
     from tests.test_gs2d_gpu import _parity_2d
