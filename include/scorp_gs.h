@@ -348,6 +348,14 @@ typedef struct ScorpGs2dTrainView {
 } ScorpGs2dTrainView;
 int scorp_gs2d_train_view(const ScorpGs2dTrainView *view, scorp_stream_t stream);
 
+/* ---- rigid / scale transform of a whole model incl. its SH coefficients (utils/gaussians.py:12-108) ----
+ * In place, one launch:  xyz <- ((xyz - c) R^T) * s + c + t;  rotation <- q (x) normalize(rotation) (w,x,y,z; q = the
+ * quaternion of R);  scaling <- scaling + log(s) (log-space, `scale_dims` = 3, or 2 for surfels);  features_rest
+ * [N, rest_coeffs, 3]: band l = 1..3 (coefficients l^2-1 .. (l+1)^2-2 of it) multiplied by the real Wigner-D block D_l.
+ * params: 113 device floats, 16-byte aligned: R[9] (row-major) c[3] t[3] s[3] q[4] D1[9] D2[25] D3[49]. */
+int scorp_gaussians_transform(float *xyz, float *rotation, float *scaling, float *features_rest, int32_t num_gaussians,
+                              int32_t rest_coeffs, int32_t scale_dims, const float *params, scorp_stream_t stream);
+
 /* ---- simple_knn replacement ----
  * out[i] = mean of the squared distances from point i to its 3 nearest other points, as
  * `simple_knn._C.distCUDA2(points)` (gs3dgs/scene/gaussian_model.py:177).  xyz[N,3], out[N]. */

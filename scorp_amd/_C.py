@@ -69,7 +69,7 @@ EXPORTS = [
     "scorp_gs3d_render_image",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_backward_ex", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles", "scorp_gs3d_debug_work",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
-    "scorp_knn_dist2", "scorp_adam_step", "scorp_adam_step_guarded", "scorp_gather_rows", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
+    "scorp_knn_dist2", "scorp_gaussians_transform", "scorp_adam_step", "scorp_adam_step_guarded", "scorp_gather_rows", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
     "scorp_gs3d_pose_score_accumulate",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
     "scorp_gs2d_render_image",
@@ -148,6 +148,7 @@ def lib():
     L.scorp_gs3d_train_view.argtypes = [ctypes.POINTER(ScorpGs3dTrainView), vp]
     L.scorp_gs2d_train_view.argtypes = [ctypes.POINTER(ScorpGs2dTrainView), vp]
     L.scorp_knn_dist2.argtypes = [vp, i32, vp, vp]
+    L.scorp_gaussians_transform.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.scorp_adam_step.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i32, vp]
     L.scorp_adam_step_guarded.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                           i32, vp, vp]

@@ -134,6 +134,96 @@ gather_rows_kernel(RowPack pk, const int32_t *__restrict__ src_index, uint64_t n
 }  // namespace
 }  // namespace scorp
 
+namespace scorp {
+namespace {
+// One pass over a GaussianModel for the align loop's rigid / scale updates (utils/gaussians.py:12-108: translate, scale,
+// rotate incl. the SH coefficients): thread i owns Gaussian i,
+//   xyz      <- ((xyz - c) R^T) * s + c + t
+//   rotation <- q (x) normalize(rotation)            (Hamilton product, q = the quaternion of R)
+//   scaling  <- scaling + log(s)                     (log-space scales; `dims` of them: 3, or 2 for surfels)
+//   rest[l]  <- D_l rest[l]  for the SH bands l = 1..3 present (real Wigner-D blocks, row-major 3x3, 5x5, 7x7), per channel
+// instead of ~20 elementwise / einsum torch launches over the model.  params (device, 113 floats):
+//   R[9] c[3] t[3] s[3] q[4] D1[9] D2[25] D3[49] | flags[8] (floats: 1 = rotate SH).
+struct TransformParams { float R[9], c[3], t[3], s[3], q[4], D1[9], D2[25], D3[49]; };
+__global__ void __launch_bounds__(256)
+transform_gaussians_kernel(int N, int k_rest, int dims, float *__restrict__ xyz, float *__restrict__ rot, float *__restrict__ scaling,
+                           float *__restrict__ rest, const TransformParams *__restrict__ pp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const TransformParams &P = *pp;   // uniform address: scalar loads
+  {
+    const float x = xyz[3 * (size_t)i] - P.c[0], y = xyz[3 * (size_t)i + 1] - P.c[1], z = xyz[3 * (size_t)i + 2] - P.c[2];
+    xyz[3 * (size_t)i]     = (P.R[0] * x + P.R[1] * y + P.R[2] * z) * P.s[0] + P.c[0] + P.t[0];
+    xyz[3 * (size_t)i + 1] = (P.R[3] * x + P.R[4] * y + P.R[5] * z) * P.s[1] + P.c[1] + P.t[1];
+    xyz[3 * (size_t)i + 2] = (P.R[6] * x + P.R[7] * y + P.R[8] * z) * P.s[2] + P.c[2] + P.t[2];
+  }
+  {
+    float4 b = reinterpret_cast<const float4 *>(rot)[i];
+    const float inv = 1.0f / sqrtf(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
+    b.x *= inv; b.y *= inv; b.z *= inv; b.w *= inv;
+    const float aw = P.q[0], ax = P.q[1], ay = P.q[2], az = P.q[3];
+    reinterpret_cast<float4 *>(rot)[i] = make_float4(aw * b.x - ax * b.y - ay * b.z - az * b.w, aw * b.y + ax * b.x + ay * b.w - az * b.z,
+                                                      aw * b.z - ax * b.w + ay * b.x + az * b.y, aw * b.w + ax * b.z - ay * b.y + az * b.x);
+  }
+  for (int d = 0; d < dims; d++) scaling[(size_t)dims * i + d] += logf(P.s[d]);
+  // SH bands: rest[i][j][ch], j = 0 .. k_rest-1 (coefficient 1 + j of the full set)
+  float *r = rest + (size_t)i * k_rest * 3;
+  if (k_rest >= 3) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      const float v0 = r[0 * 3 + ch], v1 = r[1 * 3 + ch], v2 = r[2 * 3 + ch];
+#pragma unroll
+      for (int a = 0; a < 3; a++) r[a * 3 + ch] = P.D1[a * 3] * v0 + P.D1[a * 3 + 1] * v1 + P.D1[a * 3 + 2] * v2;
+    }
+  }
+  if (k_rest >= 8) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      float v[5];
+#pragma unroll
+      for (int b = 0; b < 5; b++) v[b] = r[(3 + b) * 3 + ch];
+#pragma unroll
+      for (int a = 0; a < 5; a++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 5; b++) acc += P.D2[a * 5 + b] * v[b];
+        r[(3 + a) * 3 + ch] = acc;
+      }
+    }
+  }
+  if (k_rest >= 15) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      float v[7];
+#pragma unroll
+      for (int b = 0; b < 7; b++) v[b] = r[(8 + b) * 3 + ch];
+#pragma unroll
+      for (int a = 0; a < 7; a++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 7; b++) acc += P.D3[a * 7 + b] * v[b];
+        r[(8 + a) * 3 + ch] = acc;
+      }
+    }
+  }
+}
+}  // namespace
+}  // namespace scorp
+
+extern "C" int scorp_gaussians_transform(float *xyz, float *rotation, float *scaling, float *features_rest, int32_t N,
+                                         int32_t rest_coeffs, int32_t scale_dims, const float *params, scorp_stream_t stream_) {
+  if (N < 0 || (N > 0 && (!xyz || !rotation || !scaling || !params)) || rest_coeffs < 0 || (rest_coeffs > 0 && !features_rest) ||
+      scale_dims < 1 || scale_dims > 3 || (((uintptr_t)rotation | (uintptr_t)params) & 15)) {
+    set_error("bad arguments to scorp_gaussians_transform"); return SCORP_ERR_INVALID;
+  }
+  if (N == 0) return SCORP_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  transform_gaussians_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, rest_coeffs, scale_dims, xyz, rotation, scaling, features_rest,
+                                                                  reinterpret_cast<const scorp::TransformParams *>(params));
+  SCORP_KERNEL_CHECK("transform_gaussians", 0, stream);
+  return SCORP_OK;
+}
+
 extern "C" int scorp_gather_rows(const ScorpRowTensor *tensors, int32_t n, const int32_t *src_index, uint64_t num_out_rows,
                                  scorp_stream_t stream_) {
   if (n < 0 || n > SCORP_ROWS_MAX_TENSORS || (n > 0 && !tensors) || (num_out_rows > 0 && !src_index)) {

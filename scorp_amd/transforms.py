@@ -55,13 +55,62 @@ def sh_rotation_blocks(R, max_degree=3):
     return blocks
 
 
+def _use_kernel(g, *host_args):
+    """The one-launch HIP transform serves GPU models whose transform parameters live on the host (what the align loop
+    has: numpy rotations / RANSAC results); device-resident parameters (a captured sweep's rotation buffer) keep the
+    torch formulation, which needs no host round trip."""
+    return g._xyz.is_cuda and all(a is None or not (torch.is_tensor(a) and a.is_cuda) for a in host_args) \
+        and not torch.cuda.is_current_stream_capturing()
+
+
+@torch.no_grad()
+def gaussians_transform(g, R=None, T=None, scale=None, fix_center=False, blocks=None):
+    """x -> ((x - c) R^T) * scale + c + T on a GPU model in ONE launch (scorp_gaussians_transform): positions,
+    quaternions, log-scales and the SH bands 1..3 (`blocks`: [D_1, D_2, D_3], default sh_rotation_blocks(R)); c = the
+    model's centre if fix_center else 0.  Equal to gaussians_rotate -> gaussians_scale -> gaussians_translate."""
+    import ctypes
+    from . import _C
+    dev = g._xyz.device
+    Rh = torch.eye(3, dtype=torch.float64) if R is None else torch.as_tensor(R).detach().double().cpu()
+    Th = torch.zeros(3, dtype=torch.float64) if T is None else torch.as_tensor(T).detach().double().cpu().reshape(3)
+    Sh = torch.ones(3, dtype=torch.float64) if scale is None else torch.as_tensor(scale).detach().double().cpu().reshape(-1)
+    if Sh.numel() == 1:
+        Sh = Sh.repeat(3)
+    k_rest = int(g._features_rest.shape[1])
+    if blocks is None:
+        blocks = sh_rotation_blocks(Rh, g.max_sh_degree) if (R is not None and k_rest > 0) else []
+    D = [torch.eye(n, dtype=torch.float64) for n in (3, 5, 7)]
+    for l, B in enumerate(blocks[:3]):
+        D[l] = torch.as_tensor(B).double().cpu()
+    q = matrix_to_quat(Rh).double() if R is not None else torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64)
+    flat = torch.cat([Rh.reshape(-1), torch.zeros(3, dtype=torch.float64), Th, Sh[:3], q, D[0].reshape(-1), D[1].reshape(-1),
+                      D[2].reshape(-1), torch.zeros(3, dtype=torch.float64)]).float()     # 113 floats + padding to 116
+    params = flat.to(dev)
+    if fix_center:
+        params[9:12] = g._xyz.data.mean(0)
+    L = _C.lib()
+    for name in ("_xyz", "_rotation", "_scaling", "_features_rest"):
+        t = getattr(g, name).data
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise RuntimeError(f"gaussians_transform: {name} must be a contiguous float32 tensor")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _C.check(L.scorp_gaussians_transform(p(g._xyz.data), p(g._rotation.data), p(g._scaling.data),
+                                         p(g._features_rest.data) if k_rest else None, g._xyz.shape[0], k_rest,
+                                         int(g._scaling.shape[1]), p(params), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+             "scorp_gaussians_transform")
+
+
 @torch.no_grad()
 def gaussians_translate(g, T):
+    if _use_kernel(g, T):
+        return gaussians_transform(g, T=T)
     g._xyz.data = g._xyz.data + T[None].to(g._xyz)
 
 
 @torch.no_grad()
 def gaussians_scale(g, scale, fix_center=False):
+    if _use_kernel(g, scale) and torch.as_tensor(scale).numel() in (1, 3) and g._scaling.shape[1] == 3:
+        return gaussians_transform(g, scale=scale, fix_center=fix_center)
     scale = scale.to(g._xyz)
     if fix_center:
         c = g._xyz.data.mean(0)
@@ -73,6 +122,8 @@ def gaussians_scale(g, scale, fix_center=False):
 
 @torch.no_grad()
 def gaussians_rotate(g, R, fix_center=False):
+    if _use_kernel(g, R):
+        return gaussians_transform(g, R=R, fix_center=fix_center)
     R = R.to(g._xyz)
     c = g._xyz.data.mean(0) if fix_center else torch.zeros(3, device=g._xyz.device)
     g._xyz.data = (g._xyz.data - c) @ R.T + c

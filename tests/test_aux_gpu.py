@@ -321,3 +321,51 @@ def test_stacked_views_equal_single_views(dev):
     b = render_stacked(moved, stack, bg)
     assert (a["render"] - b["render"]).abs().mean() < 2e-5 and (a["render_alpha"] - b["render_alpha"]).abs().mean() < 2e-5
     assert (a["render_depth_raw"] - b["render_depth_raw"]).abs().mean() < 1e-4
+
+
+def test_hip_transform_kernel_matches_wigner_table_and_torch_formulation(dev):
+    """scorp_gaussians_transform (one launch: positions, quaternions, log-scales, SH bands 1-3) against (a) the independent
+    real Wigner-D table tests/golden/wigner_d.npz applied with numpy and (b) the torch formulation of
+    gaussians_rotate / gaussians_scale / gaussians_translate (utils/gaussians.py:12-108), SH-3 3DGS and surfel models."""
+    import copy
+    import math
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.renderer2d import GaussianModel2D
+    from scorp_amd.synthetic import make_gaussians
+    from scorp_amd import transforms as TR
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "wigner_d.npz"))
+    for k in (0, 3, 7):
+        R = torch.tensor(g["rotations"][k], dtype=torch.float32)          # host tensors: the kernel path
+        blocks = [torch.tensor(g[n][k]) for n in ("D1", "D2", "D3")]
+        for cls, dims in ((GaussianModel, 3), (GaussianModel2D, 2)):
+            raw = make_gaussians(3001, 3, 11 + k, scale_dims=dims)
+            m = cls.from_raw(raw, 3, device=dev)
+            T = torch.tensor([0.3, -0.2, 0.7]); S = torch.tensor([1.5, 1.5, 1.5]) if dims == 3 else None
+            TR.gaussians_transform(m, R=R, T=T, scale=S, fix_center=True, blocks=blocks)
+            # (a) SH bands by the golden table, in float64 numpy
+            rest = raw["features_rest"].astype(np.float64)
+            for l, name in ((1, "D1"), (2, "D2"), (3, "D3")):
+                sl = slice(l * l - 1, (l + 1) ** 2 - 1)
+                rest[:, sl] = np.einsum("ij,njc->nic", g[name][k], rest[:, sl])
+            assert np.abs(m._features_rest.detach().cpu().numpy() - rest).max() < 2e-6
+            # (b) geometry by the torch formulation on a CPU copy
+            ref = cls.from_raw(raw, 3, device="cpu")
+            c = ref._xyz.data.mean(0)
+            xyz = (ref._xyz.data - c) @ R.T
+            if S is not None:
+                xyz = xyz * S[None]
+            xyz = xyz + c + T
+            assert (m._xyz.detach().cpu() - xyz).abs().max() < 2e-6
+            q = TR.matrix_to_quat(R)
+            rot = TR.quat_multiply(q[None], ref._rotation.data / ref._rotation.data.norm(dim=1, keepdim=True))
+            assert (m._rotation.detach().cpu() - rot).abs().max() < 2e-6
+            sc = ref._scaling.data + (torch.log(S[:dims])[None] if S is not None else 0.0)
+            assert (m._scaling.detach().cpu() - sc).abs().max() < 2e-6
+    # the public functions take the kernel for host-side parameters and agree with the torch path (device-side parameters)
+    m1 = GaussianModel.from_raw(make_gaussians(2000, 2, 5), 2, device=dev)
+    m2 = GaussianModel.from_raw(make_gaussians(2000, 2, 5), 2, device=dev)
+    R = torch.tensor(g["rotations"][2], dtype=torch.float32)
+    TR.gaussians_rotate(m1, R, fix_center=True)            # kernel
+    TR.gaussians_rotate(m2, R.to(dev), fix_center=True)    # torch ops
+    for n in ("_xyz", "_rotation", "_features_rest"):
+        assert (getattr(m1, n) - getattr(m2, n)).abs().max() < 5e-6, n

@@ -253,6 +253,27 @@ def test_ply_round_trip_and_reference_layout(tmp_path):
     assert torch.equal(mm._xyz[10:].detach(), b._xyz.detach())
 
 
+def test_ply_header_matches_the_reference_writers_attribute_list(tmp_path):
+    """The vertex properties save_ply writes - names AND order - against what the reference's own
+    construct_list_of_attributes returns (gs3dgs/scene/gaussian_model.py:220-232; captured by
+    tests/golden/make_ply_golden.py into ply_attributes.json) for SH-3 / SH-0 3DGS models and an SH-3 surfel model."""
+    import json
+    import os
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.ply import read_ply_vertices
+    from scorp_amd.renderer2d import GaussianModel2D
+    from scorp_amd.synthetic import make_gaussians
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ply_attributes.json")))
+    for key, cls, deg, dims in (("sh3_3d", GaussianModel, 3, 3), ("sh0_3d", GaussianModel, 0, 3), ("sh3_2d", GaussianModel2D, 3, 2)):
+        m = cls.from_raw(make_gaussians(11, deg, 4, scale_dims=dims), deg, device="cpu")
+        p = str(tmp_path / f"{key}.ply")
+        m.save_ply(p)
+        header = open(p, "rb").read(4096).split(b"end_header")[0].decode("ascii").splitlines()
+        assert [l.split()[2] for l in header if l.startswith("property")] == gold[key]["attributes"], key
+        assert all(l.split()[1] == "float" for l in header if l.startswith("property"))       # 'f4' in the reference's dtype_full
+        assert list(read_ply_vertices(p).dtype.names) == gold[key]["attributes"]
+
+
 def test_point_set_fits_match_reference(golden):
     """G6: scorp_amd.solve.kabsch / umeyama against utils/solution.py's numpy solvers on seeded 50-point sets, single
     and batched; the fit actually maps source onto target."""
