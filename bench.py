@@ -606,6 +606,19 @@ def main():
     refine_rec = None
     if args.scene == "S3" and not args.no_secondary and not args.exact_backward and args.streams == 1:
         refine_rec = secondary_post_refine_objects(dev, cdev, rank, world)
+    # N > 1 only: data-parallel training of ONE scene - the code path with a real exchange step
+    # (visibility-sparse reduce-scatter + all-gather of the gradient rows over RCCL).  Guarded: a failure here is
+    # reported in the record and never costs the headline line.
+    dp_rec = None
+    if world > 1 and args.scene == "S3" and not args.no_secondary:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import dp_train_rehearsal as dpr
+            ns = argparse.Namespace(n=200_000, width=1600, height=1200, iters=16)
+            dp_rec = {"metric": "data-parallel training iterations/s, one scene, one view per rank per iteration", "ranks": world,
+                      "backend": args.backend, **dpr.run(ns, dev, cdev, rank, world)}
+        except Exception as e:   # noqa: BLE001
+            dp_rec = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         views = args.steps * world
         value = views / dt
@@ -734,6 +747,8 @@ def main():
             line.setdefault("secondary", {})["sweep_128"] = sweep_rec
         if refine_rec is not None:
             line.setdefault("secondary", {})["post_refine_4obj"] = refine_rec
+        if dp_rec is not None:
+            line.setdefault("secondary", {})["dp_train"] = dp_rec
         if world == 1 and args.scene == "S3" and not args.no_secondary and not args.exact_backward:
             line.setdefault("secondary", {})["S6"] = secondary_s6(dev, parity=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
