@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(64)
 blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                             const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                             const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ allmap,
-                            float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, uint8_t *__restrict__ hit_flags) {
+                            float *__restrict__ final_T, uint32_t *__restrict__ n_contrib, uint32_t *__restrict__ hits) {
   __shared__ float4 q0[k2FRing], q1[k2FRing], q2[k2FRing], q3[k2FRing], q4[k2FRing];   // SurfelLin + (normal, r)
   __shared__ float2 q5[k2FRing];                                                          // (g, b)
   __shared__ __attribute__((aligned(16))) uint32_t q_pos[k2FRing];
@@ -354,9 +354,12 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   float T = inside ? 1.0f : -1.0f, C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
   uint32_t last = 0, med_c = 0;
   int head = 0, count = 0;
+  uint32_t nh = 0;   // hits found so far (wave-uniform): a hit's 1-based position in the block's hit list is its `pos`
+  uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
   // The chunk's gathers (list entry -> 96-byte record) are dependent loads; software-pipelined: while chunk c is blended
-  // the records of chunk c+1 and the list entries of chunk c+2 are in flight.  The footprint verdict of every
-  // (block, entry) is left for the backward in the pair buffer's key region (dead after the sort).
+  // the records of chunk c+1 and the list entries of chunk c+2 are in flight.  The entries that pass the footprint test
+  // are left for the backward as the block's HIT LIST (ids, compacted, in blend order) in the pair buffer's key region
+  // (dead after the sort), as in the 3-D kernels: the backward replays it and never looks at the tile's list again.
   auto fetch_id = [&](uint32_t bs) { return (bs + lane < n) ? point_list[beg + bs + lane] : 0xFFFFFFFFu; };
   auto fetch_rec = [&](uint32_t id_, float4 &a0_, float4 &a1_, float4 &a2_, float4 &a3_, float4 &a4_, float4 &a5_) {
     if (id_ != 0xFFFFFFFFu) {
@@ -374,18 +377,18 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
     fetch_rec(id1, nx0, nx1, nx2, nx3, nx4, nx5);
     const uint32_t id2 = fetch_id(base + 2 * k2FChunk);
     bool hit = false;
-    if (id0 != 0xFFFFFFFFu) {
-      hit = surfel_reaches_box(r2.y, r2.z, r4, r5, bx0, bx1, by0, by1);
-      if constexpr (kForBackward) hit_flags[(size_t)quad * capacity + beg + base + lane] = hit ? 1 : 0;
-    }
+    if (id0 != 0xFFFFFFFFu) hit = surfel_reaches_box(r2.y, r2.z, r4, r5, bx0, bx1, by0, by1);
     const uint64_t m = __ballot(hit);
     if (hit) {
-      const int qi = (head + count + __builtin_popcountll(m & ((1ull << lane) - 1ull))) & (k2FRing - 1);
+      const uint32_t rank = nh + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      const int qi = (head + count + (int)(rank - nh)) & (k2FRing - 1);
       const SurfelLin L = surfel_lin(r0, r1, r2, bxc, byc);
       q0[qi] = L.e0; q1[qi] = L.e1; q2[qi] = L.e2; q3[qi] = L.e3; q4[qi] = r3; q5[qi] = make_float2(r4.x, r4.y);
-      q_pos[qi] = base + lane + 1u;
+      q_pos[qi] = rank + 1u;
+      if constexpr (kForBackward) my_hits[rank] = id0;   // (rank < n: inside this tile's slice of the region)
     }
     count += __builtin_popcountll(m);
+    nh += (uint32_t)__builtin_popcountll(m);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool last_chunk = base + k2FChunk >= n;
@@ -515,7 +518,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
                              const float *__restrict__ bg, const float *__restrict__ final_T,
                              const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
                              const float *__restrict__ dL_dallmap, float *__restrict__ acc,
-                             const uint8_t *__restrict__ hit_flags) {
+                             const uint32_t *__restrict__ hits) {
   __shared__ float4 q0[k2BChunk], q1[k2BChunk], q2[k2BChunk], q3[k2BChunk], q4[k2BChunk], q5[k2BChunk];
   __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];   // q0..q3: SurfelLin, q4: (normal, r), q5: (g, b, 1 / opacity, -)
   const int lane = threadIdx.x;
@@ -558,14 +561,12 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // wave-uniform: keeps the chunk loop's counters in SGPRs
   const int slot = reduce20_slot(lane);
   float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f, last_dL_dT = 0.0f;
-  // gathers software-pipelined two chunks deep; only entries the forward's footprint test let through are fetched
+  // gathers software-pipelined two chunks deep over the block's hit list (left by the forward), back to front: lane l of
+  // the chunk that starts dn hits from the end takes the hit at 0-based position todo - 1 - dn - l
+  const uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
   auto fetch_idx = [&](uint32_t dn, bool &hit_, uint32_t &id_) {
-    hit_ = false; id_ = 0;
-    if (dn + lane < todo) {
-      const uint32_t pos0 = todo - 1 - dn - lane;
-      hit_ = hit_flags[(size_t)quad * capacity + beg + pos0] != 0;
-      id_ = point_list[beg + pos0];
-    }
+    hit_ = dn + lane < todo;
+    id_ = hit_ ? my_hits[todo - 1 - dn - lane] : 0u;
   };
   auto fetch_rec = [&](bool hit_, uint32_t id_, float4 &a0_, float4 &a1_, float4 &a2_, float4 &a3_, float4 &a4_) {
     if (hit_) {
@@ -586,17 +587,16 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
     bool hit2;
     uint32_t id2;
     fetch_idx(done_n + 2 * k2BChunk, hit2, id2);
-    const uint64_t m = __ballot(hit);
     __builtin_amdgcn_wave_barrier();   // every lane is past the previous chunk's reads of the ring
-    if (hit) {
-      const int qi = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (hit) {   // (the chunk's hits are lanes 0 .. cnt-1: a hit list has no gaps)
+      const int qi = lane;
       const SurfelLin L = surfel_lin(r0, r1, r2, bxc, byc);
       q0[qi] = L.e0; q1[qi] = L.e1; q2[qi] = L.e2; q3[qi] = L.e3; q4[qi] = r3;
       // (ox, oy) = block centre - the surfel's accumulation point (its centre clamped into the image)
       q5[qi] = make_float4(r4.x, r4.y, bxc - fminf(fmaxf(r2.y, 0.0f), (float)(W - 1)), byc - fminf(fmaxf(r2.z, 0.0f), (float)(H - 1)));
       q_id[qi] = id; q_pos[qi] = top - (uint32_t)lane + 1u;
     }
-    const int cnt = __builtin_popcountll(m);
+    const int cnt = (int)min(todo - done_n, (uint32_t)k2BChunk);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int s_ = 0; s_ < cnt; s_++) {
@@ -984,7 +984,7 @@ static int render2d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, ui
     bk<<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(
         (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, out_color, out_allmap, (float *)(base + L.final_T),
-        (uint32_t *)(base + L.n_contrib), (uint8_t *)(pb + P.keys));
+        (uint32_t *)(base + L.n_contrib), (uint32_t *)(pb + P.hits));
   }
   SCORP_KERNEL_CHECK("blend_forward_2d", in->debug, stream);
   return SCORP_OK;
@@ -1019,7 +1019,7 @@ extern "C" int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state,
   blend2d_backward_wave_kernel<HASMAP><<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(                                \
       (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),    \
       (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),                     \
-      (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc, (const uint8_t *)(pb + P.keys))
+      (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc, (const uint32_t *)(pb + P.hits))
     if (dL_dallmap) SCORP_BW2(true);
     else SCORP_BW2(false);
 #undef SCORP_BW2
