@@ -8,12 +8,6 @@
 
 #include "scorp_gs.h"
 
-// 1 (default): the blend kernels take log2(opacity * G) of 16 hits x 64 pixels from the matrix cores (exp_mfma.hpp);
-// 0: the round-2 Horner form on the vector pipe (A/B builds only; forward and backward must be built alike).
-#ifndef SCORP_EXP_MFMA
-#define SCORP_EXP_MFMA 1
-#endif
-
 namespace scorp {
 
 // ---- constants of the published 3DGS algorithm (named as in oracle/gs3d_oracle.c) ----

@@ -53,7 +53,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int kXStride = 68;                 // dwords per slot row of the wave-private matrices: rows stay 16-byte
                                              // aligned for the A-operand's ds_read_b128; row writes are conflict-free
 constexpr int kGroup = 16;                   // splats per MFMA group
-constexpr int kDStride = 16;                 // floats per slot row of the 16 x 14 result tile
+#ifndef SCORP_BWD_DSTRIDE
+#define SCORP_BWD_DSTRIDE 20
+#endif
+constexpr int kDStride = SCORP_BWD_DSTRIDE;   // floats per slot row of the 16 x 14 result tile: 20 (80 bytes, 16-byte aligned rows) keeps the
+                                             // sixteen moment lanes' 16-byte row reads on distinct banks (stride 16: lanes 0, 4, 8, 12 collide)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kVTargetExp = 7;               // split form: the block's largest |dL/dpixel| is scaled into [2^7, 2^8)
 constexpr int kVTargetExpDA = 4;             // ... [2^4, 2^5) when depth / alpha gradients (depth values!) take part
@@ -108,7 +112,6 @@ constexpr BasisTable make_basis_table() {
 }
 __device__ const BasisTable kBasisV = make_basis_table();
 
-#if SCORP_EXP_MFMA
 // kDet: SCORP_BACKWARD_DETERMINISTIC - the sums leave as plain rows partial[quad][hit-list position] instead of float atomics
 template <bool kHasDA, bool kExact, bool kColorOnly = false, bool kDet = false>
 __global__ void __launch_bounds__(64, SCORP_BWD_WAVES)
@@ -414,7 +417,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     // issued after the next chunk's gathers have been picked up (flush_sums).  vmcnt counts loads and atomics alike
     // and the compiler waits with vmcnt(0) for the gathers, so atomics issued right here would be waited for, at
     // their full memory-side latency, at the top of the next chunk.
-    static_assert(kAccStride == kDStride && kDStride == 16, "a result row maps onto an accumulator row lane for lane");
+    static_assert(kAccStride == 16 && kDStride >= 16 && kDStride % 4 == 0, "a result row's first 16 floats map onto an accumulator row lane for lane");
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int sl = 4 * k + (lane >> 4), col = lane & 15;
@@ -482,344 +485,6 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   flush_sums();
 }
 
-#else   // !SCORP_EXP_MFMA: the round-2 kernel (exponent as a Horner form on the vector pipe), for same-box A/B builds
-template <bool kHasDA, bool kExact, bool kColorOnly = false>
-__global__ void __launch_bounds__(64, SCORP_BWD_WAVES)
-blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ hits,
-                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
-                           const float *__restrict__ bg, const float *__restrict__ final_T,
-                           const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
-                           const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dalpha,
-                           float *__restrict__ acc) {
-  // staged records as preprocess stored them: (x, y, A, B), (C, log2 opacity, r, g), (b, depth, -, opacity) with
-  // opacity * G = exp2(A dx^2 + C dy^2 + B dx dy + log2 opacity)
-  __shared__ float4 q_a[kChunk], q_b[kChunk], q_c[kChunk];
-  __shared__ __attribute__((aligned(16))) uint32_t q_id[kChunk];
-  // [row][pixel] matrix of one half-group (8 splats).  split form: rows 0..7 = first fp16 terms (v | w << 16) of the 8
-  // splats, rows 8..15 = second terms; exact form: rows 0..7 = v, rows 8..15 = w (fp32)
-  __shared__ __attribute__((aligned(16))) uint32_t xm[16 * kXStride];
-  float *dbuf = reinterpret_cast<float *>(xm);   // the 2 x 16 x 14 result tile reuses the matrix once the MFMAs have consumed it
-  float *xs = reinterpret_cast<float *>(xm);     // prologue scratch: 64 x 4 floats
-  static_assert(2 * kGroup * kDStride <= 16 * kXStride && 64 * 4 <= 16 * kXStride, "scratch fits");
-  const int lane = threadIdx.x;
-  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
-  const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
-  if (tile >= tiles) return;
-  const int tx0 = (tile % tiles_x) * kTile, ty0 = (tile / tiles_x) * kTile;
-  const int bx = tx0 + (quad & 1) * 8, by = ty0 + (quad >> 1) * 8;
-  const int px = bx + (lane & 7), py = by + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const float cx = (float)bx + 3.5f, cy = (float)by + 3.5f;  // block-frame origin of the moments
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  if (end == beg) return;
-  const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
-  // all of the pixel's loads are issued together (no load waits on `last`); pixels nothing was blended into drop
-  // their upstream gradient afterwards by a select (it may be NaN: depth / alpha at empty pixels)
-  float T_final = 0.0f, dpix0 = 0.0f, dpix1 = 0.0f, dpix2 = 0.0f, ddep = 0.0f, dalp = 0.0f;
-  uint32_t last = 0u;
-  if (inside) {
-    T_final = final_T[pix];
-    last = n_contrib[pix];
-    dpix0 = dL_dcolor[pix]; dpix1 = dL_dcolor[HW + pix]; dpix2 = dL_dcolor[2 * HW + pix];
-    if (kHasDA && dL_ddepth) ddep = dL_ddepth[pix];
-    if (kHasDA && dL_dalpha) dalp = dL_dalpha[pix];
-  }
-  if (last == 0) { dpix0 = dpix1 = dpix2 = ddep = dalp = 0.0f; }
-  const uint32_t todo = wave_max_u32(last);   // wave-uniform (SGPR): the chunk loop and the slot indices live in SGPRs
-  if (todo == 0) return;
-  // split form: one power-of-two scale per wave from the block's largest upstream gradient
-  float sv = 1.0f, inv_sv = 1.0f;
-  if constexpr (!kExact) {
-    float amax = fmaxf(fmaxf(fabsf(dpix0), fabsf(dpix1)), fabsf(dpix2));
-    if (kHasDA) amax = fmaxf(amax, fmaxf(fabsf(ddep), fabsf(dalp)));
-    const int eb = (int)((wave_max_u32(__float_as_uint(amax)) >> 23) & 0xFFu);   // biased exponent (|x| orders like its bits); 0: zero / denormal
-    int sb = eb == 0 ? 127 : 254 + (kHasDA ? kVTargetExpDA : kVTargetExp) - eb;   // biased exponent of the scale
-    sb = min(max(sb, 1), 253);
-    sv = __uint_as_float((uint32_t)sb << 23);
-    inv_sv = __uint_as_float((uint32_t)(254 - sb) << 23);
-  }
-  // In the split form the recurrence runs on T' = 2^10 T (so that w' = alpha T' is the scaled blend weight at no cost)
-  // and on upstream gradients scaled by sv / 2^10, which makes dL/dalpha come out scaled by sv:
-  //   sv dL/dalpha = (s'' - R'') T' - (sv T_final bg.dL/dcolor) / (1 - alpha).
-  const float tf_bg = sv * (T_final * (bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2));
-  const int bn = lane & 15, bk = lane >> 4;
-  // Every lane already holds its own pixel's four gradients, so the B operand's W columns are exchanged through LDS
-  // (the matrices are idle until the first group) instead of being gathered from global memory again.
-  xs[lane * 4 + 0] = sv * dpix0; xs[lane * 4 + 1] = sv * dpix1; xs[lane * 4 + 2] = sv * dpix2; xs[lane * 4 + 3] = sv * ddep;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  // B operand.  A lane supplies ONE column bn of the 16-column basis: columns 0..5 are the position basis of the V half
-  // (1, x, y, x^2, xy, y^2 in the block frame), the following ones the upstream gradients (dL/dr, dL/dg, dL/db,
-  // dL/ddepth) of the W half.
-  union Frag { f16x8 v; uint4 q; uint32_t d[4]; };
-  float bb[kExact ? 16 : 1];
-  Frag bh[kExact ? 1 : 4];
-  if constexpr (kExact) {
-#pragma unroll
-    for (int t = 0; t < 16; t++) {   // fp32 MFMA t covers pixels t, t + 16, t + 32, t + 48
-      const int q = t + 16 * bk;
-      const float xl = (float)(q & 7) - 3.5f, yl = (float)(q >> 3) - 3.5f;
-      float v = 0.0f;
-      v = bn == 0 ? 1.0f : v; v = bn == 1 ? xl : v; v = bn == 2 ? yl : v;
-      v = bn == 3 ? xl * xl : v; v = bn == 4 ? xl * yl : v; v = bn == 5 ? yl * yl : v;
-      v = (bn >= 6 && bn <= 9) ? xs[q * 4 + ((bn - 6) & 3)] : v;
-      bb[t] = v;
-    }
-  } else {
-    // fp16 MFMA m covers pixels 16 bk + 4 m + j, j = 0..3: element 2j = v slot, 2j + 1 = w slot.  V columns (bn < 6) come
-    // from the constant table (two 16-byte loads per lane), W columns from the exchanged gradients.
-    uint4 tv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    if (bn < 6) {
-      const uint4 *tp = reinterpret_cast<const uint4 *>(&kBasisV.v[bn][16 * bk]);
-      tv[0] = tp[0]; tv[1] = tp[1];
-    }
-    const uint32_t tw[8] = {tv[0].x, tv[0].y, tv[0].z, tv[0].w, tv[1].x, tv[1].y, tv[1].z, tv[1].w};
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int q = 16 * bk + 4 * m + j, e = 4 * m + j;
-        const uint32_t vbits = (e & 1) ? tw[e >> 1] >> 16 : tw[e >> 1] & 0xFFFFu;
-        const float g = (bn >= 6 && bn <= 13) ? xs[q * 4 + ((bn - 6) & 3)] : 0.0f;
-        const uint32_t g1 = pack_rtz16(g, 0.0f);
-        const float gw = bn <= 9 ? half_lo(g1) : g - half_lo(g1);     // columns 6..9: first term, 10..13: the remainder
-        bh[m].d[j] = vbits | (pack_rtz16(gw, 0.0f) << 16);
-      }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if constexpr (!kExact) {
-    const float sq = sv * (1.0f / kWScale);
-    dpix0 *= sq; dpix1 *= sq; dpix2 *= sq; ddep *= sq; dalp *= sq;
-  }
-  float T = kExact ? T_final : kWScale * T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
-  const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
-  float park_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // a group's sums, parked until flush_sums
-  uint32_t park_o[4] = {0u, 0u, 0u, 0u};        // ... and their float offsets in acc (N * 16 < 2^32, checked at the entry point)
-  auto flush_sums = [&]() {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (park_v[k] != 0.0f) atomicAdd(acc + park_o[k], park_v[k]);
-      park_v[k] = 0.0f;
-    }
-  };
-  // slots of a group: head + i, head a multiple of kGroup: one LDS base per array, immediate offsets.  `top` = 1-based
-  // position in the hit list of the group's first slot (positions fall by one per slot).
-  // A group is two halves of 8 splats.  Each half: 1a, 1b, then ONE pass over the matrix pipe whose 16 rows are
-  // (8 slots) x (first term | second term) [exact form: (8 slots) x (v | w)], so the [row][pixel] matrix in LDS is
-  // 16 x 64 dwords whatever the form; the two halves' results wait in registers and leave together.
-  auto process_group = [&](auto full, int nslots, int head, int top) {
-    flush_sums();   // (a later group of the same chunk: the previous one's sums leave now)
-    constexpr bool kFull = decltype(full)::value;   // full groups run straight-line; only a wave's last one is partial
-    int hv = head;
-    asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
-    const float4 *ga = q_a + hv, *gb = q_b + hv, *gc = q_c + hv;
-    const int first = top - (int)last;   // slot i takes part in this pixel's blend iff top - i <= last, i.e. i >= first
-    f32x4 dd[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      if (kFull || h * 8 < nslots) {   // wave-uniform
-        // One straight-line pass per splat (alpha, then the recurrence): with four waves per SIMD an in-order wave's own
-        // issue interval already covers the ALU latencies, so nothing is gained by separating a parallel alpha phase
-        // from the sequential part - and keeping eight (alpha, record) sets live costs the registers that let the
-        // staged records of the NEXT splats be fetched from LDS ahead of their use.
-        // The staged records are fetched kAhead splats ahead of their use (explicit rotation: left alone the scheduler
-        // issues each ds_read right in front of its use and the wave eats the LDS latency once per splat).
-#ifndef SCORP_BWD_AHEAD
-#define SCORP_BWD_AHEAD 3
-#endif
-        constexpr int kAhead = SCORP_BWD_AHEAD;
-        float4 ra[kAhead], rb[kAhead];
-        float2 rc[kAhead];
-#pragma unroll
-        for (int j = 0; j < kAhead - 1; j++) {
-          ra[j] = ga[h * 8 + j]; rb[j] = gb[h * 8 + j]; rc[j] = *reinterpret_cast<const float2 *>(&gc[h * 8 + j]);
-        }
-#pragma unroll
-        for (int i8 = 0; i8 < 8; i8++) {
-          const int i = h * 8 + i8;
-          if (i8 + kAhead - 1 < 8) {
-            const int j = (i8 + kAhead - 1) % kAhead, ij = i + kAhead - 1;
-            ra[j] = ga[ij]; rb[j] = gb[ij]; rc[j] = *reinterpret_cast<const float2 *>(&gc[ij]);
-          }
-          if (kFull || i < nslots) {  // wave-uniform: stale staging entries beyond the group must not enter the recurrence
-            const float4 a = ra[i8 % kAhead];
-            const float4 b = rb[i8 % kAhead];
-            const float2 bz = rc[i8 % kAhead];
-            const float e = splat_exponent(a.x - pxf, a.y - pyf, a.z, a.w, b.x, b.y);   // log2(opacity * G)
-            const float g_o = __builtin_amdgcn_exp2f(e);
-            // alpha = min(0.99, g_o) >= 1/255  <=>  g_o >= 1/255
-            const bool ok = (i >= first) & (e <= b.y) & (g_o >= kAlphaMin);
-            const float Go = ok ? g_o : 0.0f;
-            const float alpha = fminf(kAlphaMax, Go);
-            const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
-            T *= rinv;
-            const float w = alpha * T;
-            float v = 0.0f;
-            if constexpr (!kColorOnly) {
-              R = last_alpha * (s_last - R) + R;
-              const float sc = kHasDA ? b.z * dpix0 + b.w * dpix1 + bz.x * dpix2 + bz.y * ddep + dalp
-                                      : b.z * dpix0 + b.w * dpix1 + bz.x * dpix2;
-              const float dL_dal = (sc - R) * T - tf_bg * rinv;
-              s_last = sc;
-              last_alpha = alpha;
-              v = Go * dL_dal;
-            }
-            if constexpr (kExact) {
-              xm[i8 * kXStride + lane] = __float_as_uint(v);
-              xm[(8 + i8) * kXStride + lane] = __float_as_uint(w);
-            } else if constexpr (kColorOnly) {
-              const uint32_t p1 = pack_rtz16(0.0f, w);
-              xm[i8 * kXStride + lane] = p1;
-              xm[(8 + i8) * kXStride + lane] = pack_rtz16(0.0f, __builtin_fmaf(half_hi(p1), -1.0f, w));
-            } else {   // x = h1 + h2, two fp16 terms (round toward zero, saturating); v and w share the dwords
-              const uint32_t p1 = pack_rtz16(v, w);
-              const uint32_t p2 = pack_rtz16(__builtin_fmaf(half_lo(p1), -1.0f, v), __builtin_fmaf(half_hi(p1), -1.0f, w));
-              xm[i8 * kXStride + lane] = p1;
-              xm[(8 + i8) * kXStride + lane] = p2;
-            }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // A operands: the lane's 16 pixels are consecutive in its row, fetched as four 16-byte reads issued together
-        f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
-        if constexpr (kExact) {
-          float4 av[4];
-#pragma unroll
-          for (int t4 = 0; t4 < 4; t4++) av[t4] = *reinterpret_cast<const float4 *>(&xm[abase + 4 * t4]);
-#pragma unroll
-          for (int t4 = 0; t4 < 4; t4++) {
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bb[4 * t4], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].y, bb[4 * t4 + 1], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].z, bb[4 * t4 + 2], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].w, bb[4 * t4 + 3], d, 0, 0, 0);
-          }
-        } else {
-          Frag af[4];
-#pragma unroll
-          for (int m = 0; m < 4; m++) af[m].q = *reinterpret_cast<const uint4 *>(&xm[abase + 4 * m]);
-#pragma unroll
-          for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m].v, bh[m].v, d, 0, 0, 0);
-        }
-        dd[h] = d;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();   // the next half (and the result tile) overwrite the matrix
-      }
-    }
-    // result tile [term][slot][column] (it reuses the matrix): lane (bn, bk) holds rows 4 bk .. 4 bk + 3 of column bn
-    if (bn < 14) {
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          dbuf[((bk >> 1) * kGroup + h * 8 + ((4 * bk + r) & 7)) * kDStride + bn] = dd[h][r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < nslots) {  // block-frame moments -> the ten screen-space gradients of slot `lane`
-      float *m = dbuf + lane * kDStride;
-      const float *m2 = m + kGroup * kDStride;
-      const float4 a = ga[lane];
-      const float4 b = gb[lane];
-      const float opac = gc[lane].w;
-      const float cA = a.z * (-1.0f / kConicScale), cB = a.w * (-0.5f / kConicScale), cC = b.x * (-1.0f / kConicScale);
-      const float xl = a.x - cx, yl = a.y - cy;
-      float mm[10];
-      {
-        const float4 u0 = *reinterpret_cast<const float4 *>(m), u1 = *reinterpret_cast<const float4 *>(m + 4),
-                     u2 = *reinterpret_cast<const float4 *>(m + 8), u3 = *reinterpret_cast<const float4 *>(m + 12);
-        const float4 w0 = *reinterpret_cast<const float4 *>(m2), w1 = *reinterpret_cast<const float4 *>(m2 + 4),
-                     w2 = *reinterpret_cast<const float4 *>(m2 + 8), w3 = *reinterpret_cast<const float4 *>(m2 + 12);
-        if constexpr (kExact) {      // rows 0..7 carried v (columns 0..5), rows 8..15 w (columns 6..9)
-          mm[0] = u0.x; mm[1] = u0.y; mm[2] = u0.z; mm[3] = u0.w; mm[4] = u1.x; mm[5] = u1.y;
-          mm[6] = w1.z; mm[7] = w1.w; mm[8] = w2.x; mm[9] = w2.y;
-        } else {                     // first + second term; W sums = (first-term + remainder columns) of the upstream gradients
-          const float inv_w = inv_sv * (1.0f / kWScale);
-          mm[0] = (u0.x + w0.x) * inv_sv; mm[1] = (u0.y + w0.y) * inv_sv; mm[2] = (u0.z + w0.z) * inv_sv;
-          mm[3] = (u0.w + w0.w) * inv_sv; mm[4] = (u1.x + w1.x) * inv_sv; mm[5] = (u1.y + w1.y) * inv_sv;
-          mm[6] = ((u1.z + w1.z) + (u2.z + w2.z)) * inv_w; mm[7] = ((u1.w + w1.w) + (u2.w + w2.w)) * inv_w;
-          mm[8] = ((u2.x + w2.x) + (u3.x + w3.x)) * inv_w; mm[9] = ((u2.y + w2.y) + (u3.y + w3.y)) * inv_w;
-        }
-      }
-      if constexpr (kColorOnly) {
-        *reinterpret_cast<float4 *>(m) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        *reinterpret_cast<float4 *>(m + 4) = make_float4(0.0f, 0.0f, mm[6], mm[7]);
-        *reinterpret_cast<float2 *>(m + 8) = make_float2(mm[8], 0.0f);
-      } else {
-        const float m0 = mm[0], mx = mm[1], my = mm[2], mxx = mm[3], mxy = mm[4], myy = mm[5];
-        const float svdx = xl * m0 - mx, svdy = yl * m0 - my;
-        const float svdx2 = xl * xl * m0 - 2.0f * xl * mx + mxx;
-        const float svdxdy = xl * yl * m0 - xl * my - yl * mx + mxy;
-        const float svdy2 = yl * yl * m0 - 2.0f * yl * my + myy;
-        *reinterpret_cast<float4 *>(m) = make_float4(0.5f * W * (-cA * svdx - cB * svdy), 0.5f * H * (-cC * svdy - cB * svdx),
-                                                     -0.5f * svdx2, -svdxdy);
-        *reinterpret_cast<float4 *>(m + 4) = make_float4(-0.5f * svdy2, m0 / opac, mm[6], mm[7]);
-        *reinterpret_cast<float2 *>(m + 8) = make_float2(mm[8], mm[9]);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // The 160 sums go out as four wave-wide atomic instructions (lane = float of a 64-byte accumulator row, four rows
-    // per instruction, ten lanes of sixteen active: one memory-side request per splat) - but not yet: they are parked in registers and
-    // issued after the next chunk's gathers have been picked up (flush_sums).  vmcnt counts loads and atomics alike
-    // and the compiler waits with vmcnt(0) for the gathers, so atomics issued right here would be waited for, at
-    // their full memory-side latency, at the top of the next chunk.
-    static_assert(kAccStride == kDStride && kDStride == 16, "a result row maps onto an accumulator row lane for lane");
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int sl = 4 * k + (lane >> 4), col = lane & 15;
-      park_v[k] = 0.0f;
-      if (sl < nslots && (kColorOnly ? (col >= 6 && col < 9) : col < 10)) {
-        park_v[k] = dbuf[sl * kDStride + col];
-        park_o[k] = q_id[head + sl] * (uint32_t)kAccStride + col;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-
-  // The chunk's gathers are a chain of dependent loads (hit-list entry -> record) of ~1 us each way; with three waves
-  // per SIMD nothing hides them, so they are software-pipelined two chunks deep: while chunk c is replayed the records
-  // of chunk c+1 and the list entries of chunk c+2 are already in flight.  Chunk c holds the hits at 0-based positions
-  // todo - 64 c - 1 (slot 0) down to todo - 64 c - 64 (slot 63): slots ascend back to front.
-  const uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
-  auto fetch_id = [&](uint32_t c_) {
-    const int o = (int)todo - (int)(kChunk * c_) - 1 - lane;
-    return o >= 0 ? my_hits[o] : 0xFFFFFFFFu;
-  };
-  auto fetch_rec = [&](uint32_t id_, float4 &a_, float4 &b_, float4 &c_) {
-    if (id_ != 0xFFFFFFFFu) {
-      const float4 *src = reinterpret_cast<const float4 *>(rec + id_);
-      a_ = src[0]; b_ = src[1]; c_ = src[2];
-    }
-  };
-  float4 a, b, c;
-  uint32_t id = fetch_id(0);
-  fetch_rec(id, a, b, c);
-  uint32_t id1 = fetch_id(1);
-  const uint32_t nchunks = (todo + kChunk - 1) / kChunk;
-  for (uint32_t ch = 0; ch < nchunks; ch++) {
-    float4 a1, b1, c1;
-    fetch_rec(id1, a1, b1, c1);
-    const uint32_t id2 = fetch_id(ch + 2);
-    flush_sums();
-    if (id != 0xFFFFFFFFu) { q_a[lane] = a; q_b[lane] = b; q_c[lane] = c; q_id[lane] = id; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int top = (int)todo - (int)(kChunk * ch);          // 1-based position of slot 0
-    const int n = top < kChunk ? top : kChunk;               // hits in this chunk (only the last chunk is short)
-    for (int head = 0; head < n; head += kGroup) {
-      if (n - head >= kGroup) process_group(std::true_type{}, kGroup, head, top - head);
-      else process_group(std::false_type{}, n - head, head, top - head);
-    }
-    id = id1; a = a1; b = b1; c = c1; id1 = id2;
-  }
-  flush_sums();
-}
-
-#endif   // SCORP_EXP_MFMA
 
 // ---------------------------------------------------------------------------------------------------------
 // Deterministic mode, second half: one thread per Gaussian sums the partial rows of the (8x8 block, hit) pairs it
@@ -937,37 +602,23 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
     // nothing but colour gradients wanted (every geometry / opacity output NULL): the colour-only replay
     const bool color_only = !exact && !grads->means3D && !grads->means2D && !grads->opacities && !grads->scales &&
                             !grads->rotations && !grads->cov3D_precomp;
-#if SCORP_EXP_MFMA
     auto wk = det ? (color_only ? blend_backward_wave_kernel<false, false, true, true>
                      : exact ? (da ? blend_backward_wave_kernel<true, true, false, true> : blend_backward_wave_kernel<false, true, false, true>)
                              : (da ? blend_backward_wave_kernel<true, false, false, true> : blend_backward_wave_kernel<false, false, false, true>))
               : color_only ? blend_backward_wave_kernel<false, false, true>
               : exact ? (da ? blend_backward_wave_kernel<true, true> : blend_backward_wave_kernel<false, true>)
                       : (da ? blend_backward_wave_kernel<true, false> : blend_backward_wave_kernel<false, false>);
-#else
-    auto wk = color_only ? blend_backward_wave_kernel<false, false, true>
-              : exact ? (da ? blend_backward_wave_kernel<true, true> : blend_backward_wave_kernel<false, true>)
-                      : (da ? blend_backward_wave_kernel<true, false> : blend_backward_wave_kernel<false, false>);
-#endif
     wk<<<blocks, 64, 0, stream>>>(
         (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.hits), (const SplatRec *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),
-        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc
-#if SCORP_EXP_MFMA
-        , partial, block_todo
-#endif
-        );
+        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc, partial, block_todo);
   }
   SCORP_KERNEL_CHECK("blend_backward", in->debug, stream);
   if (det) {
-#if SCORP_EXP_MFMA
     reduce_partials_kernel<<<(N + 255) / 256, 256, 0, stream>>>(
         N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), (const uint32_t *)(base + L.tile_start),
         (const uint32_t *)(pb + P.hits), (uint32_t)capacity, L.tiles_x, block_todo, partial, acc);
     SCORP_KERNEL_CHECK("reduce_partials", in->debug, stream);
-#else
-    set_error("SCORP_BACKWARD_DETERMINISTIC needs the SCORP_EXP_MFMA build"); return SCORP_ERR_INVALID;
-#endif
   }
   {
     ProfScope prof(kKPreprocessBackward, stream);

@@ -653,7 +653,6 @@ sort_tiles_long_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__rest
 // dead key region of the pair buffer) and per pixel the final T and the 1-based position IN THAT LIST of the last splat
 // that contributed: the backward replays the hit list and never looks at the tile's list again.
 // ---------------------------------------------------------------------------------------------------------
-#if SCORP_EXP_MFMA
 // The exponent log2(opacity * G) of a group of 16 hits at the block's 64 pixels comes from the matrix cores (exp_mfma.hpp:
 // three v_mfma_f32_32x32x16_bf16 against the lane's own monomials; register i of a lane = splat i at that lane's pixel):
 // the lane that stages a hit turns its record into the six block-frame coefficients, cut into three bf16 terms each, and a
@@ -842,166 +841,6 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     if (out_depth_norm) out_depth_norm[pix] = nan_to_num00(Dp / (1.0f - T));   // render()'s depth, as render_tail_kernel forms it
   }
 }
-#else   // !SCORP_EXP_MFMA: the exponent as a Horner form on the vector pipe (round 2; kept for same-box A/B builds)
-#ifndef SCORP_FWD_GROUP
-#define SCORP_FWD_GROUP 8
-#endif
-#ifndef SCORP_FWD_WAVES
-#define SCORP_FWD_WAVES 1
-#endif
-constexpr int kFRing = 128, kFChunk = 64, kFGroup = SCORP_FWD_GROUP;
-
-// kForBackward = false (scorp_gs3d_render_image): nothing is left behind for a backward pass - no hit lists, no
-// per-pixel final T / last contributor, no bookkeeping of the last contributor in the blend loop.
-template <bool kForBackward>
-__global__ void __launch_bounds__(64, SCORP_FWD_WAVES)
-blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
-                          const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
-                          const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
-                          float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                          uint32_t *__restrict__ hits, uint32_t *__restrict__ block_hits, float *__restrict__ out_depth_norm,
-                          float4 *__restrict__ zero_buf, uint32_t zero_per_wave, uint32_t zero_total) {
-  // ring entries: the record's (x, y, A, B), (C, log2 opacity, r, g), (b, depth) as preprocess stored them:
-  // alpha = exp2(A dx^2 + C dy^2 + B dx dy + log2 opacity), one v_exp and no multiply
-  __shared__ float4 q_a[kFRing], q_b[kFRing];
-  __shared__ float2 q_c[kFRing];
-  __shared__ __attribute__((aligned(16))) uint32_t q_pos[kFRing];
-  const int lane = threadIdx.x;
-  if (zero_buf) {   // this wave's share of the buffer the launch was asked to clear (every workgroup of the grid takes part)
-    const uint32_t z0 = blockIdx.x * zero_per_wave, z1 = min(z0 + zero_per_wave, zero_total);
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const f4v zero = {0.0f, 0.0f, 0.0f, 0.0f};   // streaming stores: the rows are not read before the backward, keep them out of L2
-    for (uint32_t z = z0 + lane; z < z1; z += 64) __builtin_nontemporal_store(zero, reinterpret_cast<f4v *>(zero_buf) + z);
-  }
-  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
-  const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
-  if (tile >= tiles) return;
-  const int bx = (tile % tiles_x) * kTile + (quad & 1) * 8, by = (tile / tiles_x) * kTile + (quad >> 1) * 8;
-  const int px = bx + (lane & 7), py = by + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const float pxf = (float)px, pyf = (float)py;
-  const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  const uint32_t n = end - beg;
-  uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
-  float T = inside ? 1.0f : -1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, Dp = 0.0f;   // T < 0: pixel finished (see below)
-  uint32_t last = 0;
-  int head = 0, count = 0;   // head stays a multiple of kFGroup (only a wave's final group is partial), so the
-                             // slots of a group are head + i without wrap-around: one LDS base, immediate offsets
-  uint32_t nh = 0;           // hits so far (wave-uniform): a hit's 1-based position in the block's hit list is its `pos`
-  // The chunk's gathers (list entry -> record) are dependent loads of ~1 us each; they are software-pipelined: while
-  // chunk c is blended the records of chunk c+1 and the list entries of chunk c+2 are already in flight.
-  auto fetch_id = [&](uint32_t bs) { return (bs + lane < n) ? point_list[beg + bs + lane] : 0xFFFFFFFFu; };
-  auto fetch_rec = [&](uint32_t id_, float4 &a_, float4 &b_, float4 &c_) {
-    if (id_ != 0xFFFFFFFFu) {
-      const float4 *src = reinterpret_cast<const float4 *>(rec + id_);
-      a_ = src[0]; b_ = src[1]; c_ = src[2];
-    }
-  };
-  float4 a, b, c;
-  uint32_t id0 = fetch_id(0);
-  fetch_rec(id0, a, b, c);
-  uint32_t id1 = fetch_id(kFChunk);
-  for (uint32_t base = 0; base < n; base += kFChunk) {
-    if (__ballot(T > 0.0f) == 0) break;
-    float4 a1, b1, c1;
-    fetch_rec(id1, a1, b1, c1);
-    const uint32_t id2 = fetch_id(base + 2 * kFChunk);
-    bool hit = false;
-    if (id0 != 0xFFFFFFFFu)   // the record holds -k * conic and k * cutoff (k > 0): the test is scale-invariant
-      hit = conic_min_over_box(a.x, a.y, -a.z, -0.5f * a.w, -b.x, bx0, bx1, by0, by1) <= c.z;
-    const uint64_t m = __ballot(hit);
-    if (hit) {
-      const uint32_t rank = nh + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-      const int qi = (head + count + (int)(rank - nh)) & (kFRing - 1);
-      q_a[qi] = a;
-      q_b[qi] = b;
-      q_c[qi] = make_float2(c.x, c.y);
-      q_pos[qi] = rank + 1u;
-      if constexpr (kForBackward) my_hits[rank] = id0;   // (rank < n: inside this tile's slice of the region)
-    }
-    count += __builtin_popcountll(m);
-    nh += (uint32_t)__builtin_popcountll(m);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const bool last_chunk = base + kFChunk >= n;
-    // full groups run straight-line (nslots is the compile-time kFGroup); only a wave's final group is partial
-    auto blend_group = [&](auto full, int nslots) {
-      constexpr bool kFull = decltype(full)::value;
-      int hv = head;
-      asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
-      const float4 *ga = q_a + hv, *gb = q_b + hv;
-      const float2 *gc = q_c + hv;
-      const uint32_t *gp = q_pos + hv;
-      float al[kFGroup];
-      bool live[kFGroup];   // lane masks (SGPR pairs): the alpha test's verdict is reused for the last-contributor bookkeeping
-      static_assert(kFGroup % 4 == 0, "positions are fetched as 16-byte LDS reads");
-      uint32_t pos[kFGroup];
-#pragma unroll
-      for (int i = 0; i < kFGroup; i += 4) {
-        const uint4 p4 = *reinterpret_cast<const uint4 *>(gp + i);
-        pos[i] = p4.x; pos[i + 1] = p4.y; pos[i + 2] = p4.z; pos[i + 3] = p4.w;
-      }
-#pragma unroll
-      for (int i = 0; i < kFGroup; i++) {
-        const float4 qa = ga[i];
-        const float2 co = *reinterpret_cast<const float2 *>(&gb[i]);
-        const float e = splat_exponent(qa.x - pxf, qa.y - pyf, qa.z, qa.w, co.x, co.y);   // log2(opacity * G)
-        const float alpha = fminf(kAlphaMax, __builtin_amdgcn_exp2f(e));
-        live[i] = (kFull || i < nslots) & (e <= co.y) & (alpha >= kAlphaMin);   // e <= log2 o: power <= 0
-        al[i] = live[i] ? alpha : 0.0f;
-      }
-#pragma unroll
-      for (int i = 0; i < kFGroup; i++) {
-        if (kFull || i < nslots) {  // wave-uniform
-          const float2 rg = *reinterpret_cast<const float2 *>(&gb[i].z);
-          const float2 bz = gc[i];
-          // A saturated pixel is latched by the SIGN of T: the splat that would take T below 1e-4 is not blended and
-          // flips T negative, after which every test_T is negative too (a live pixel always has T >= 1e-4, and
-          // alpha = 0 leaves test_T = T exactly).
-          const float alpha = al[i];
-          const float test_T = T * (1.0f - alpha);
-          const bool ok = test_T >= kTMin;
-          const float ae = ok ? alpha : 0.0f;
-          const float w = ae * T;
-          C0 += rg.x * w; C1 += rg.y * w; C2 += bz.x * w;
-          Dp += bz.y * w;
-          T = ok ? test_T : -fabsf(T);
-          if constexpr (kForBackward) last = (ok & live[i]) ? pos[i] : last;   // ae > 0, from the two masks (no third compare)
-        }
-      }
-      head = (head + kFGroup) & (kFRing - 1);
-      count -= nslots;
-    };
-    bool all_done = false;   // every pixel saturated: checked after every group, not only once per 64 list entries
-    while (count >= kFGroup) {
-      blend_group(std::true_type{}, kFGroup);
-      if (__ballot(T > 0.0f) == 0) { all_done = true; break; }
-    }
-    if (all_done) break;
-    if (last_chunk && count > 0) blend_group(std::false_type{}, count);
-    id0 = id1; a = a1; b = b1; c = c1; id1 = id2;
-  }
-  if constexpr (kForBackward) {
-    if (lane == 0) block_hits[tile * 4 + quad] = nh - (uint32_t)count;   // (block, splat) iterations this wave ran: the P statistic
-  }
-  if (inside) {
-    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
-    T = fabsf(T);
-    if constexpr (kForBackward) {
-      final_T[pix] = T;
-      n_contrib[pix] = last;
-    }
-    out_color[pix] = C0 + T * bg[0];
-    out_color[HW + pix] = C1 + T * bg[1];
-    out_color[2 * HW + pix] = C2 + T * bg[2];
-    out_depth[pix] = Dp;
-    out_alpha[pix] = 1.0f - T;   // = sum of the blend weights (sum_i alpha_i T_i telescopes to 1 - T)
-    if (out_depth_norm) out_depth_norm[pix] = nan_to_num00(Dp / (1.0f - T));   // render()'s depth, as render_tail_kernel forms it
-  }
-}
-
-#endif   // SCORP_EXP_MFMA
 
 int validate(const ScorpGs3dInputs *in) {
   if (!in) { set_error("inputs is NULL"); return SCORP_ERR_INVALID; }
@@ -1212,11 +1051,7 @@ int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, ui
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
         out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib),
         (uint32_t *)(pb + P.hits), (uint32_t *)(base + L.block_hits), out_depth_norm, (float4 *)zero_buf,
-        (uint32_t)zero_per_wave, (uint32_t)zero_total
-#if SCORP_EXP_MFMA
-        , V > 1 ? in->image_height : 0
-#endif
-        );
+        (uint32_t)zero_per_wave, (uint32_t)zero_total, V > 1 ? in->image_height : 0);
   }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;

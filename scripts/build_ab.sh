@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: scripts/build_ab.sh NAME "FLAGS" file1.hip [file2.hip ...]  -> build/variants/libNAME.so
-# The listed kernel files are compiled with FLAGS (e.g. -DSCORP_EXP_MFMA=0), every other object comes from build/*.o
+# The listed kernel files are compiled with FLAGS (e.g. -DSCORP_BWD_WAVES=3), every other object comes from build/*.o
 # (python -m scorp_amd.build first).  For same-box A/B runs through scripts/ab_variants.sh (SCORP_GS_LIB).
 set -e
 cd "$(dirname "$0")/.."

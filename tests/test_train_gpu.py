@@ -384,3 +384,32 @@ def test_post_refine_objects_equals_the_joint_model_where_footprints_are_disjoin
     for o, p in zip(objs2, pert):
         assert torch.equal(o._xyz.detach(), torch.tensor(p["xyz"], device=dev))
         assert not torch.equal(o._features_dc.detach(), torch.tensor(p["features_dc"], device=dev))
+
+
+def test_deterministic_colour_only_replay(dev):
+    """SCORP_BACKWARD_DETERMINISTIC on the colour-only replay (geometry frozen, post_refine_gs.py:53-56) through the
+    one-call view: two views give the same bits, equal to the atomic colour-only gradients within 2e-5 relative L1."""
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.rasterizer3d import PairPolicy, backward_precision
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams
+    from scorp_amd.train_view import train_view
+    raw = make_gaussians(8000, 0, 33, log_scale_mean=math.log(0.03))
+    cam = ring_cameras(5, 208, 144, 3, radius=3.5, device=dev)[1]
+    bg, pipe = torch.tensor([0.2, 0.1, 0.3], device=dev), PipelineParams()
+    gt = torch.rand(3, 144, 208, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+
+    def run(mode):
+        m = GaussianModel.from_raw(raw, 0, device=dev)
+        for n in ("_xyz", "_scaling", "_rotation", "_opacity"):
+            getattr(m, n).requires_grad_(False)
+        with backward_precision(mode):
+            train_view(cam, m, pipe, bg, gt, 0.2)
+        PairPolicy.drain()
+        return m._features_dc.grad.detach().clone()
+    try:
+        d1, d2, a = run("deterministic"), run("deterministic"), run("split")
+        assert torch.equal(d1, d2)
+        assert float((d1.double() - a.double()).abs().sum() / a.double().abs().sum()) < 2e-5
+    finally:
+        PairPolicy.reset()
