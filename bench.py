@@ -487,18 +487,20 @@ def main():
         kern_all = _C.prof_collect()
         dominant = max(kern_all, key=lambda k: kern_all[k][0]) if any(c for _, c in kern_all.values()) else None
 
-    def timed_run(n_warm, n_steps, bracket=None):
+    def timed_run(n_warm, n_steps, bracket=None, lead_in=12):
         """n_warm untimed views, then EXACTLY n_steps views between two hipEvents recorded on the launch stream directly
         behind the warm-up: no host synchronisation opens the timed region (a synchronise leaves the chip idle for a
         moment and the first ~20 views after it run 5-20 % slow, scripts/dev/ramp.py - at the driver's --steps 20 that
-        was the whole region).  barrier + synchronize bracket warm-up + region as a whole; the host clock over the region
-        (enqueue start -> synchronize) is kept as a cross-check.  Returns (event s, host s, host enqueue s, last loss)."""
+        was the whole region).  For the same reason `lead_in` more views are enqueued in front of the warm-up, behind the
+        synchronise that separates this run from the probe / the previous run: with a short --warmup the warm-up itself
+        would otherwise sit on the ramp.  barrier + synchronize bracket the whole; the host clock over the region (enqueue
+        start -> synchronize) is kept as a cross-check.  Returns (event s, host s, host enqueue s, last loss)."""
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         if not args.no_kernel_events:
-            _C.prof_enable(True, only=[])                      # nothing bracketed during the warm-up
-        for i in range(n_warm):
+            _C.prof_enable(True, only=[])                      # nothing bracketed during the lead-in and the warm-up
+        for i in range(lead_in + n_warm):
             step(i)
         if not args.no_kernel_events and bracket:
             _C.check(_C.lib().scorp_prof_select(bracket), "scorp_prof_select")   # only the dominant kernel, from here on
@@ -688,7 +690,9 @@ def main():
             "value_deterministic_backward": None if dt_det is None else round(views / dt_det, 3),
             "ms_per_step_deterministic_backward": None if dt_det is None else round(dt_det / args.steps * 1e3, 4),
             "timing": {"clock": "hipEvents on the launch stream, recorded directly behind the warm-up views and behind the last timed view "
-                                "(max over ranks); barrier + synchronize before the warm-up and after the region",
+                                "(max over ranks); barrier + synchronize before the lead-in + warm-up views and after the region",
+                       "untimed_views_before_the_region": {"probe (every kernel bracketed, then a synchronise)": max(3, min(args.warmup, 8)),
+                                                           "lead-in (keeps the chip off its idle ramp)": 12, "warmup": args.warmup},
                        "host_clock_ms_per_step": round(dt_host / args.steps * 1e3, 4),
                        "note": "host clock = first enqueue of the region -> synchronize returned; it starts while warm-up views are "
                                "still executing, so it reads at most (warm-up backlog) above the event figure"},
