@@ -309,8 +309,10 @@ typedef struct ScorpGs3dTrainView {
   size_t loss_workspace_bytes;
   float *grad_color;             /* [3,H,W] scratch: d loss / d color */
   const ScorpGs3dGrads *grads;   /* gradients w.r.t. the inputs, as for scorp_gs3d_backward */
-  void *backward_scratch;        /* scorp_gs3d_backward_scratch_bytes(N) */
+  void *backward_scratch;        /* scorp_gs3d_backward_scratch_bytes(N) (scorp_gs3d_backward_scratch_bytes_ex with backward_flags) */
   size_t backward_scratch_bytes;
+  uint32_t *out_header;          /* optional, 4 device words {pairs needed, overflow, capacity, 0}: the view's overflow word
+                                    survives the state blob without a copy launch (the scatter kernel writes it) */
 } ScorpGs3dTrainView;
 int scorp_gs3d_train_view(const ScorpGs3dTrainView *view, scorp_stream_t stream);
 

@@ -38,7 +38,7 @@ class ScorpGs3dTrainView(ctypes.Structure):
                 ("mask", ctypes.c_void_p), ("lambda_dssim", ctypes.c_float), ("backward_flags", ctypes.c_uint32),
                 ("out_loss3", ctypes.c_void_p), ("loss_workspace", ctypes.c_void_p), ("loss_workspace_bytes", ctypes.c_size_t),
                 ("grad_color", ctypes.c_void_p), ("grads", ctypes.c_void_p), ("backward_scratch", ctypes.c_void_p),
-                ("backward_scratch_bytes", ctypes.c_size_t)]
+                ("backward_scratch_bytes", ctypes.c_size_t), ("out_header", ctypes.c_void_p)]
 
 
 class ScorpGs2dTrainView(ctypes.Structure):

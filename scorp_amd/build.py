@@ -32,13 +32,14 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
+STAMP = LIB + ".sha"     # the source hash the library next to it was built from (content-based: a checkout or a copy
+                         # that changes mtimes neither forces nor hides a rebuild)
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    deps.append(os.path.join(ROOT, "include", "scorp_gs.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(STAMP).read().strip() != source_sha()
 
 
 def build(force=False, verbose=False):
@@ -66,6 +67,8 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
     cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_sha() + "\n")
     return LIB
 
 

@@ -15,7 +15,7 @@ namespace {
 // N is 1e5..4e5 at initialisation (dataset_readers.py:321,378) and the call happens once per run, so the O(N^2)
 // form is the robust choice: every thread owns a query, the block sweeps all points through LDS 1024 at a time
 // (broadcast reads), 3 smallest squared distances kept in registers.  ~8 VALU per pair: 360k points = 1.3e11 pairs
-// ~ 30 ms.  A point is its own nearest neighbour by index, not by distance, so duplicates count with distance 0.
+// : 34.9 ms measured on an MI355X (round 3, once per run at create_from_pcd).  A point is its own nearest neighbour by index, not by distance, so duplicates count with distance 0.
 constexpr int kKnnTile = 1024;
 __global__ void __launch_bounds__(256)
 knn_dist2_kernel(int N, const float *__restrict__ xyz, float *__restrict__ out) {

@@ -253,16 +253,19 @@ int preprocess3d_impl(const ScorpGs3dInputs *in, int32_t *out_radii, uint8_t *ou
                       scorp_stream_t stream);
 // zero_buf / zero_bytes (optional, a multiple of 16 bytes): memory the blend forward's waves clear on the way (the
 // backward's accumulator rows: the forward is VALU-bound and its stores are free, a separate fill is 9 us per view).
+// header_copy (optional, 16 bytes): {num_pairs, overflow, capacity, long_tiles} of this render, written by the scatter
+// kernel next to the state header itself - a caller that wants the overflow word on the device after the state blob is
+// gone (the one-call views) gets it without a copy launch.
 int render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color, float *out_depth,
                   float *out_alpha, float *out_depth_norm, void *zero_buf, size_t zero_bytes, scorp_stream_t stream,
-                  bool for_backward);
+                  bool for_backward, uint32_t *header_copy = nullptr);
 void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L, const BinRec *bin, const float *acc,
                                 const ScorpGs3dGrads *grads, hipStream_t stream);
 
 // ---- binning shared by the 3DGS and 2DGS paths (gs3d_forward.hip) ----
 int bin_count_and_scan(const StateLayout &L, char *state_base, int N, int debug, hipStream_t stream);
 int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *state_base, char *pairs_base, int N,
-                         uint32_t capacity, int debug, hipStream_t stream);
+                         uint32_t capacity, int debug, hipStream_t stream, uint32_t *header_copy = nullptr);
 
 // ---- host error plumbing ----
 void set_error(const char *fmt, ...);

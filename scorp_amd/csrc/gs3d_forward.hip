@@ -138,12 +138,14 @@ __global__ void __launch_bounds__(256)
 scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
                      uint32_t *__restrict__ tile_count,
                      const uint32_t *__restrict__ tile_start, int tiles_x, uint64_t *__restrict__ keys,
-                     uint32_t capacity, StateHeader *__restrict__ header) {
+                     uint32_t capacity, StateHeader *__restrict__ header, uint32_t *__restrict__ header_copy) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) {
     header->capacity = capacity;
     header->long_tiles = 0;   // (the sort's list of long tiles starts empty)
-    if (header->num_pairs > capacity) header->overflow = 1;
+    const uint32_t np = header->num_pairs, ov = np > capacity ? 1u : header->overflow;
+    if (np > capacity) header->overflow = 1;
+    if (header_copy) { header_copy[0] = np; header_copy[1] = ov; header_copy[2] = capacity; header_copy[3] = 0u; }
   }
   if (i >= N) return;
   const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
@@ -249,12 +251,14 @@ scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, int view_n, cons
                          const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x,
                          const uint32_t *__restrict__ block_hist, uint32_t *__restrict__ tile_start,
                          const uint32_t *__restrict__ tile_count, uint64_t *__restrict__ keys, uint32_t capacity,
-                         StateHeader *__restrict__ header) {
+                         StateHeader *__restrict__ header, uint32_t *__restrict__ header_copy) {
   extern __shared__ uint32_t s_cur[];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     header->capacity = capacity;
     header->long_tiles = 0;   // (the sort's list of long tiles starts empty)
-    if (header->num_pairs > capacity) header->overflow = 1;
+    const uint32_t np = header->num_pairs, ov = np > capacity ? 1u : header->overflow;
+    if (np > capacity) header->overflow = 1;
+    if (header_copy) { header_copy[0] = np; header_copy[1] = ov; header_copy[2] = capacity; header_copy[3] = 0u; }
   }
   const int pass = blockIdx.x / nb, blk = blockIdx.x - pass * nb;
   const int t_lo = pass * tpp, nt = min(tiles - t_lo, tpp);
@@ -928,7 +932,7 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
 }
 
 int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, char *pb, int N, uint32_t capacity,
-                         int debug, hipStream_t stream) {
+                         int debug, hipStream_t stream, uint32_t *header_copy) {
   uint32_t *tile_count = (uint32_t *)(base + L.tile_count), *tile_start = (uint32_t *)(base + L.tile_start);
   uint64_t *keys = (uint64_t *)(pb + P.keys);
   uint32_t *point_list = (uint32_t *)(pb + P.list);
@@ -941,11 +945,11 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
       scatter_pairs_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
           N, per_block, L.nb, tpp, L.bin_n(), (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
           (const uint32_t *)(base + L.block_hist), tile_start, L.scan_in_scatter() ? tile_count : nullptr, keys, capacity,
-          header);
+          header, header_copy);
     } else {
       scatter_pairs_kernel<<<(max(N, 1) + 255) / 256, 256, 0, stream>>>(
           N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), tile_count, tile_start, L.tiles_x,
-          keys, capacity, header);
+          keys, capacity, header, header_copy);
     }
   }
   SCORP_KERNEL_CHECK("scatter_pairs", debug, stream);
@@ -953,7 +957,7 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
     ProfScope prof(kKSortTiles, stream);
     // (tile_count is dead once the pairs are scattered - the next preprocess rewrites it - and holds the long tiles' ids)
     sort_tiles_reg_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys, point_list, capacity, tile_count, header);
-    sort_tiles_long_kernel<<<L.tiles < 1024 ? L.tiles : 1024, 256, 0, stream>>>(tile_start, keys, point_list, capacity, tile_count, header);
+    sort_tiles_long_kernel<<<L.tiles < 512 ? L.tiles : 512, 256, 0, stream>>>(tile_start, keys, point_list, capacity, tile_count, header);
   }
   SCORP_KERNEL_CHECK("sort_tiles", debug, stream);
   return SCORP_OK;
@@ -1022,7 +1026,7 @@ extern "C" int scorp_gs3d_check_overflow(const void *state, scorp_stream_t strea
 
 int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
                          float *out_depth, float *out_alpha, float *out_depth_norm, void *zero_buf, size_t zero_bytes,
-                         scorp_stream_t stream_, bool for_backward) {
+                         scorp_stream_t stream_, bool for_backward, uint32_t *header_copy) {
   if (int e = validate(in)) return e;
   hipStream_t stream = (hipStream_t)stream_;
   const int V = in->num_views > 1 ? in->num_views : 1;
@@ -1038,7 +1042,7 @@ int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, ui
   char *base = (char *)state, *pb = (char *)pairs;
   uint32_t *tile_start = (uint32_t *)(base + L.tile_start);
   uint32_t *point_list = (uint32_t *)(pb + P.list);
-  if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream)) return e;
+  if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream, header_copy)) return e;
   {
     ProfScope prof(kKBlendForward, stream);
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;

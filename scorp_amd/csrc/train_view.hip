@@ -22,7 +22,8 @@ extern "C" int scorp_gs3d_train_view(const ScorpGs3dTrainView *v, scorp_stream_t
   const bool zero_here = v->backward_scratch && acc_bytes > 0 && acc_bytes <= v->backward_scratch_bytes &&
                          ((uintptr_t)v->backward_scratch & 15) == 0;
   if (int e = render3d_impl(in, v->state, v->pairs, v->capacity, v->out_color, v->out_depth_raw, v->out_alpha,
-                            tail ? v->out_depth : nullptr, zero_here ? v->backward_scratch : nullptr, acc_bytes, stream, true)) return e;
+                            tail ? v->out_depth : nullptr, zero_here ? v->backward_scratch : nullptr, acc_bytes, stream, true,
+                            v->out_header)) return e;
   if (int e = scorp_loss_l1_ssim_forward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->out_loss3,
                                          v->loss_workspace, v->loss_workspace_bytes, 1, stream)) return e;
   if (int e = scorp_loss_l1_ssim_backward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,

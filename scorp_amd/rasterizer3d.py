@@ -90,10 +90,17 @@ class PairPolicy:
         cls._ctx[cls.key(N, H, W)] = (int(pairs), int(N))
 
     @classmethod
-    def pend(cls, state, N, H, W):
-        """Queue a forward for drain(): copies the header on the current stream and records an event behind the copy."""
+    def pend(cls, state, N, H, W, header=None):
+        """Queue a forward for drain(): copies the header on the current stream and records an event behind the copy.
+        `header`: a 64-byte tensor the library already filled with the first four header words (scorp_gs3d_train_view's
+        out_header): then nothing is copied."""
         ev = None
-        if torch.cuda.is_current_stream_capturing():
+        if header is not None:
+            hdr = header
+            if not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record()
+        elif torch.cuda.is_current_stream_capturing():
             # a captured replay is checked by its capturer (align.SweepPlan), which reads the live headers at the end of
             # the graph: a view of the state (kept alive by the graph's pool anyway) instead of a copy node per view
             hdr = state[:64]

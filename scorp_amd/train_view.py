@@ -85,8 +85,10 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     v.out_loss3, v.loss_workspace, v.loss_workspace_bytes = loss3.data_ptr(), ws.data_ptr(), ws_bytes
     v.grad_color, v.grads = grad_color.data_ptr(), ctypes.addressof(grads)
     v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes
+    header = new((64,), torch.uint8)                  # {pairs needed, overflow, capacity, 0}: written by the scatter kernel
+    v.out_header = header.data_ptr()
     _C.check(L.scorp_gs3d_train_view(ctypes.byref(v), _stream()), "scorp_gs3d_train_view")
-    header = PairPolicy.pend(state, N, H, W)          # the StateHeader only (see rasterizer3d.PairPolicy.pend)
+    PairPolicy.pend(state, N, H, W, header=header)    # queued for drain(): no copy launch, the state blob is not pinned
     for p, gp in zip(leaves, g):
         if p.requires_grad:
             _accumulate(p, gp.view_as(p))

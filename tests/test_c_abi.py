@@ -49,7 +49,7 @@ def test_struct_layout_matches_header():
     from scorp_amd import _C
     assert ctypes.sizeof(_C.ScorpGs3dInputs) == 40 + 12 * 8 + 8   # 10 ints/floats, 12 pointers, raw_params + padding
     assert ctypes.sizeof(_C.ScorpGs3dGrads) == 9 * 8
-    assert ctypes.sizeof(_C.ScorpGs3dTrainView) == 13 * 8 + 2 * 4 + 7 * 8   # see the struct in include/scorp_gs.h
+    assert ctypes.sizeof(_C.ScorpGs3dTrainView) == 13 * 8 + 2 * 4 + 8 * 8   # see the struct in include/scorp_gs.h
 
 
 def test_header_is_plain_c(tmp_path):
