@@ -267,6 +267,13 @@ int bin_count_and_scan(const StateLayout &L, char *state_base, int N, int debug,
 int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *state_base, char *pairs_base, int N,
                          uint32_t capacity, int debug, hipStream_t stream, uint32_t *header_copy = nullptr);
 
+// ---- loss (loss.hip): the exported pair, with the option of leaving the three loss values to the backward launch ----
+int loss_forward_impl(const float *img, const float *gt, const float *mask, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                      float *out_loss3, void *workspace, size_t workspace_bytes, int32_t need_backward, bool finalize,
+                      hipStream_t stream);
+int loss_backward_impl(const float *img, const float *gt, const float *mask, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                       const void *workspace, const float *grad_out, float *grad_img, float *out_loss3, hipStream_t stream);
+
 // ---- host error plumbing ----
 void set_error(const char *fmt, ...);
 

@@ -670,12 +670,25 @@ sort_tiles_long_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__rest
 #ifndef SCORP_FWD_FMA
 #define SCORP_FWD_FMA 1
 #endif
-constexpr int kFRing = 96, kFChunk = 64, kFGroup = 16;   // ring: at most 15 left-over hits + 64 new ones
+#ifndef SCORP_FWD_RING
+#define SCORP_FWD_RING 96
+#endif
+constexpr int kFRing = SCORP_FWD_RING, kFChunk = 64, kFGroup = 16;   // ring: at most 15 left-over hits + 64 new ones
 
 // (__launch_bounds__(64, 2): at least two waves per SIMD, i.e. at most 256 registers - which is what lets the compiler keep
 // the MFMA results in VGPRs; with the accumulators in AGPRs every exponent costs a v_accvgpr_read before its v_exp)
 #ifndef SCORP_FWD_WAVES
 #define SCORP_FWD_WAVES 2
+#endif
+#ifdef SCORP_FWD_TRACE
+// diagnostic build only (scripts/dev/trace_forward.py): per wave (start, end) on the 100 MHz real-time counter and the
+// hardware id words, to draw the occupancy timeline of one launch
+__device__ unsigned long long g_fwd_trace[3 * 40000];
+#endif
+#ifdef SCORP_FWD_STATS
+// diagnostic build only (scripts/dev/stats_forward.py): how full the 64 lanes are per blended hit, and how many
+// iterations a wave would run if its hits were listed per 8x4 half / per 4x4 quadrant / per pixel instead of per block
+__device__ unsigned long long g_fwd_stats[8];
 #endif
 template <bool kForBackward>
 __global__ void __launch_bounds__(64, SCORP_FWD_WAVES)
@@ -688,6 +701,18 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   __shared__ uint4 q_k[3][kFRing + 1];   // the three bf16 terms of a hit's six coefficients; slot kFRing stays zero
   __shared__ float4 q_col[kFRing];       // r, g, b, depth
   const int lane = threadIdx.x;
+#ifdef SCORP_FWD_TRACE
+  struct TraceEnd {
+    unsigned long long t0; int lane; unsigned b;
+    __device__ ~TraceEnd() {
+      if (lane == 0 && b < 40000u) {
+        g_fwd_trace[3 * b] = t0; g_fwd_trace[3 * b + 1] = __builtin_amdgcn_s_memrealtime();
+        g_fwd_trace[3 * b + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |   // HW_REG_HW_ID
+                                 (unsigned)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));                       // HW_REG_XCC_ID
+      }
+    }
+  } trace_end{__builtin_amdgcn_s_memrealtime(), lane, blockIdx.x};
+#endif
   if (zero_buf) {   // this wave's share of the buffer the launch was asked to clear (every workgroup of the grid takes part)
     const uint32_t z0 = blockIdx.x * zero_per_wave, z1 = min(z0 + zero_per_wave, zero_total);
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -718,6 +743,9 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
                              // slots of a group are head + i without wrap-around: one LDS base, immediate offsets
   uint32_t nh = 0;           // hits found so far (wave-uniform)
   uint32_t consumed = 0;     // hits blended so far: slot i of the next group is hit number consumed + i + 1 of the list
+#ifdef SCORP_FWD_STATS
+  uint32_t st_hits = 0, st_live = 0, st_any = 0, st_q[4] = {0, 0, 0, 0}, st_h[2] = {0, 0}, st_lane = 0;
+#endif
   // The chunk's gathers (list entry -> record) are dependent loads of ~1 us each; they are software-pipelined: while
   // chunk c is blended the records of chunk c+1 and the list entries of chunk c+2 are already in flight.
   auto fetch_id = [&](uint32_t bs) { return (bs + lane < n) ? point_list[beg + bs + lane] : 0xFFFFFFFFu; };
@@ -795,6 +823,17 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
           Dp += col.w * w;
           T = ok ? test_T : -fabsf(T);
           if constexpr (kForBackward) lastg = (ok & live) ? (uint32_t)(i + 1) : lastg;
+#ifdef SCORP_FWD_STATS
+          {
+            const uint64_t m = __ballot(ok & live);
+            st_hits += 1; st_live += (uint32_t)__builtin_popcountll(m);
+            st_any += m != 0;
+            st_q[0] += (m & 0x000000000F0F0F0Full) != 0; st_q[1] += (m & 0x00000000F0F0F0F0ull) != 0;
+            st_q[2] += (m & 0x0F0F0F0F00000000ull) != 0; st_q[3] += (m & 0xF0F0F0F000000000ull) != 0;
+            st_h[0] += (m & 0x00000000FFFFFFFFull) != 0; st_h[1] += (m & 0xFFFFFFFF00000000ull) != 0;
+            st_lane += (ok & live) ? 1u : 0u;
+          }
+#endif
         }
       }
       if constexpr (kForBackward) last = lastg ? consumed + lastg : last;
@@ -830,6 +869,21 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   if constexpr (kForBackward) {
     if (lane == 0) block_hits[tile * 4 + quad] = consumed;   // (block, splat) iterations this wave ran: the P statistic
   }
+#ifdef SCORP_FWD_STATS
+  {
+    uint32_t lm = st_lane;
+    for (int off = 32; off >= 1; off >>= 1) lm = max(lm, (uint32_t)__shfl_xor((int)lm, off, 64));
+    if (lane == 0) {
+      atomicAdd(&g_fwd_stats[0], (unsigned long long)st_hits); atomicAdd(&g_fwd_stats[1], (unsigned long long)st_live);
+      atomicAdd(&g_fwd_stats[2], (unsigned long long)st_any);
+      atomicAdd(&g_fwd_stats[3], (unsigned long long)(st_q[0] + st_q[1] + st_q[2] + st_q[3]));
+      atomicAdd(&g_fwd_stats[4], (unsigned long long)max(max(st_q[0], st_q[1]), max(st_q[2], st_q[3])));
+      atomicAdd(&g_fwd_stats[5], (unsigned long long)(st_h[0] + st_h[1]));
+      atomicAdd(&g_fwd_stats[6], (unsigned long long)max(st_h[0], st_h[1]));
+      atomicAdd(&g_fwd_stats[7], (unsigned long long)lm);
+    }
+  }
+#endif
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
     T = fabsf(T);
@@ -1145,3 +1199,16 @@ extern "C" int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint
   SCORP_HIP_CHECK(hipStreamSynchronize(stream));
   return SCORP_OK;
 }
+
+#ifdef SCORP_FWD_STATS
+extern "C" int scorp_debug_fwd_stats(unsigned long long *out, int reset) {
+  static const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scorp::g_fwd_stats), 64) != hipSuccess) return -2;
+  return reset && hipMemcpyToSymbol(HIP_SYMBOL(scorp::g_fwd_stats), zero, 64) != hipSuccess ? -2 : 0;
+}
+#endif
+#ifdef SCORP_FWD_TRACE
+extern "C" int scorp_debug_fwd_trace(unsigned long long *out, int n_waves) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(scorp::g_fwd_trace), (size_t)n_waves * 24) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -194,22 +194,23 @@ ssim_l1_forward_strip_kernel(const float *__restrict__ img, const float *__restr
   }
 }
 
-// 1024 threads, float2 loads four at a time in flight, then a fixed-order tree in double: a launch-latency-sized kernel
-__global__ void __launch_bounds__(1024)
-loss_finalize_kernel(const float *__restrict__ partials, int nblocks, double n_elems, float lambda, float *__restrict__ out) {
-  __shared__ double s_a[1024], s_b[1024];
+// The loss values from the forward's per-wave partial sums: float2 loads four at a time in flight, then a fixed-order
+// tree in double (kThreads threads of one workgroup; s_a / s_b: kThreads doubles each).
+template <int kThreads>
+__device__ __forceinline__ void finalize_sums(const float *__restrict__ partials, int nblocks, double n_elems, float lambda,
+                                              float *__restrict__ out, double *s_a, double *s_b) {
   const float2 *p2 = reinterpret_cast<const float2 *>(partials);
   double a = 0, b = 0;
-  for (int i0 = threadIdx.x; i0 < nblocks; i0 += 4 * 1024) {
+  for (int i0 = threadIdx.x; i0 < nblocks; i0 += 4 * kThreads) {
     float2 v[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const int i = i0 + 1024 * j; v[j] = i < nblocks ? p2[i] : make_float2(0.0f, 0.0f); }
+    for (int j = 0; j < 4; j++) { const int i = i0 + kThreads * j; v[j] = i < nblocks ? p2[i] : make_float2(0.0f, 0.0f); }
 #pragma unroll
     for (int j = 0; j < 4; j++) { a += v[j].x; b += v[j].y; }
   }
   s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
   __syncthreads();
-  for (int off = 512; off >= 1; off >>= 1) {
+  for (int off = kThreads / 2; off >= 1; off >>= 1) {
     if ((int)threadIdx.x < off) { s_a[threadIdx.x] += s_a[threadIdx.x + off]; s_b[threadIdx.x] += s_b[threadIdx.x + off]; }
     __syncthreads();
   }
@@ -221,14 +222,31 @@ loss_finalize_kernel(const float *__restrict__ partials, int nblocks, double n_e
   }
 }
 
+// a launch-latency-sized kernel (4.8 us on the stream): the forward-only callers'.  The one-call views let the loss
+// backward's extra workgroup do this instead (ssim_l1_backward_kernel, `fin`)
+__global__ void __launch_bounds__(1024)
+loss_finalize_kernel(const float *__restrict__ partials, int nblocks, double n_elems, float lambda, float *__restrict__ out) {
+  __shared__ double s_a[1024], s_b[1024];
+  finalize_sums<1024>(partials, nblocks, n_elems, lambda, out, s_a, s_b);
+}
+
+struct LossFinalize { const float *partials; int nparts; double n_elems; float *out; };   // out == NULL: nothing to do
+
 __global__ void __launch_bounds__(256)
 ssim_l1_backward_kernel(const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ mask,
                         const float *__restrict__ dmaps, int C, int H, int W, Window win, float lambda, float inv_n,
-                        const float *__restrict__ grad_out, float *__restrict__ grad_img) {
+                        const float *__restrict__ grad_out, float *__restrict__ grad_img, LossFinalize fin) {
   // The three derivative maps go through the same two LDS buffers one after the other (13 KB per workgroup instead
   // of 39 KB: occupancy, not arithmetic, limits this kernel); each thread accumulates its four output pixels.
-  __shared__ float s_m[kLP][kLPS];
-  __shared__ float s_h[kLP][kLHS];
+  __shared__ __attribute__((aligned(16))) float s_m[kLP][kLPS];
+  __shared__ __attribute__((aligned(16))) float s_h[kLP][kLHS];
+  if (fin.out && blockIdx.x == gridDim.x - 1) {   // the workgroup appended for the loss values (the partial sums are complete:
+                                                  // the forward ran before this launch on the stream)
+    static_assert(sizeof(s_m) >= 256 * sizeof(double) && sizeof(s_h) >= 256 * sizeof(double), "the tree's scratch fits the tile buffers");
+    finalize_sums<256>(fin.partials, fin.nparts, fin.n_elems, lambda, fin.out, reinterpret_cast<double *>(&s_m[0][0]),
+                       reinterpret_cast<double *>(&s_h[0][0]));
+    return;
+  }
   const LossTile lt = loss_tile((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
   if (!lt.valid) return;
   const int ch = lt.ch, x0 = lt.x0, y0 = lt.y0;
@@ -335,15 +353,17 @@ extern "C" size_t scorp_loss_workspace_bytes(int32_t C, int32_t H, int32_t W) {
   return align_up((size_t)3 * C * H * W * 4, 256) + align_up((size_t)strip_waves(C, H, W) * 8, 256);
 }
 
-extern "C" int scorp_loss_l1_ssim_forward(const float *img, const float *gt, const float *mask, int32_t C, int32_t H,
-                                          int32_t W, float lambda_dssim, float *out_loss3, void *workspace,
-                                          size_t workspace_bytes, int32_t need_backward, scorp_stream_t stream_) {
+namespace scorp {
+// finalize = false: the loss values are left to loss_backward_impl's extra workgroup (out_loss3 there) - the one-call
+// views, which always run both; nothing else may read out_loss3 in between.
+int loss_forward_impl(const float *img, const float *gt, const float *mask, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                      float *out_loss3, void *workspace, size_t workspace_bytes, int32_t need_backward, bool finalize,
+                      hipStream_t stream) {
   if (!img || !gt || !out_loss3 || !workspace) { set_error("NULL argument to scorp_loss_l1_ssim_forward"); return SCORP_ERR_INVALID; }
   if (C <= 0 || H <= 0 || W <= 0) { set_error("bad image shape"); return SCORP_ERR_INVALID; }
   if (workspace_bytes < scorp_loss_workspace_bytes(C, H, W) || ((uintptr_t)workspace & 15)) {
     set_error("loss workspace too small or misaligned"); return SCORP_ERR_INVALID;
   }
-  hipStream_t stream = (hipStream_t)stream_;
   float *dmaps = (float *)workspace;
   float *partials = (float *)((char *)workspace + align_up((size_t)3 * C * H * W * 4, 256));
   const Window win = make_window();
@@ -353,23 +373,44 @@ extern "C" int scorp_loss_l1_ssim_forward(const float *img, const float *gt, con
     ssim_l1_forward_strip_kernel<<<(nparts + 3) / 4, 256, 0, stream>>>(img, gt, mask, C, H, W, win, need_backward ? dmaps : nullptr, partials);
   }
   SCORP_KERNEL_CHECK("ssim_l1_forward", 0, stream);
-  loss_finalize_kernel<<<1, 1024, 0, stream>>>(partials, nparts, (double)C * H * W, lambda_dssim, out_loss3);
-  SCORP_KERNEL_CHECK("loss_finalize", 0, stream);
+  if (finalize) {
+    loss_finalize_kernel<<<1, 1024, 0, stream>>>(partials, nparts, (double)C * H * W, lambda_dssim, out_loss3);
+    SCORP_KERNEL_CHECK("loss_finalize", 0, stream);
+  }
   return SCORP_OK;
+}
+
+// out_loss3 != NULL: also writes the loss values from the forward's partial sums (loss_forward_impl with finalize = false)
+int loss_backward_impl(const float *img, const float *gt, const float *mask, int32_t C, int32_t H, int32_t W, float lambda_dssim,
+                       const void *workspace, const float *grad_out, float *grad_img, float *out_loss3, hipStream_t stream) {
+  if (!img || !gt || !workspace || !grad_img) { set_error("NULL argument to scorp_loss_l1_ssim_backward"); return SCORP_ERR_INVALID; }
+  const int grid = (loss_blocks(C, H, W) + 7) / 8 * 8;
+  const Window win = make_window();
+  LossFinalize fin;
+  fin.partials = (const float *)((const char *)workspace + align_up((size_t)3 * C * H * W * 4, 256));
+  fin.nparts = strip_waves(C, H, W);
+  fin.n_elems = (double)C * H * W;
+  fin.out = out_loss3;
+  {
+    ProfScope prof(kKLossBackward, stream);
+    ssim_l1_backward_kernel<<<grid + (out_loss3 ? 1 : 0), 256, 0, stream>>>(img, gt, mask, (const float *)workspace, C, H, W, win,
+                                                                           lambda_dssim, (float)(1.0 / ((double)C * H * W)), grad_out,
+                                                                           grad_img, fin);
+  }
+  SCORP_KERNEL_CHECK("ssim_l1_backward", 0, stream);
+  return SCORP_OK;
+}
+}  // namespace scorp
+
+extern "C" int scorp_loss_l1_ssim_forward(const float *img, const float *gt, const float *mask, int32_t C, int32_t H,
+                                          int32_t W, float lambda_dssim, float *out_loss3, void *workspace,
+                                          size_t workspace_bytes, int32_t need_backward, scorp_stream_t stream_) {
+  return loss_forward_impl(img, gt, mask, C, H, W, lambda_dssim, out_loss3, workspace, workspace_bytes, need_backward, true,
+                           (hipStream_t)stream_);
 }
 
 extern "C" int scorp_loss_l1_ssim_backward(const float *img, const float *gt, const float *mask, int32_t C, int32_t H,
                                            int32_t W, float lambda_dssim, const void *workspace, const float *grad_out,
                                            float *grad_img, scorp_stream_t stream_) {
-  if (!img || !gt || !workspace || !grad_img) { set_error("NULL argument to scorp_loss_l1_ssim_backward"); return SCORP_ERR_INVALID; }
-  hipStream_t stream = (hipStream_t)stream_;
-  const int grid = (loss_blocks(C, H, W) + 7) / 8 * 8;
-  const Window win = make_window();
-  {
-    ProfScope prof(kKLossBackward, stream);
-    ssim_l1_backward_kernel<<<grid, 256, 0, stream>>>(img, gt, mask, (const float *)workspace, C, H, W, win, lambda_dssim,
-                                                      (float)(1.0 / ((double)C * H * W)), grad_out, grad_img);
-  }
-  SCORP_KERNEL_CHECK("ssim_l1_backward", 0, stream);
-  return SCORP_OK;
+  return loss_backward_impl(img, gt, mask, C, H, W, lambda_dssim, workspace, grad_out, grad_img, nullptr, (hipStream_t)stream_);
 }

@@ -24,10 +24,11 @@ extern "C" int scorp_gs3d_train_view(const ScorpGs3dTrainView *v, scorp_stream_t
   if (int e = render3d_impl(in, v->state, v->pairs, v->capacity, v->out_color, v->out_depth_raw, v->out_alpha,
                             tail ? v->out_depth : nullptr, zero_here ? v->backward_scratch : nullptr, acc_bytes, stream, true,
                             v->out_header)) return e;
-  if (int e = scorp_loss_l1_ssim_forward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->out_loss3,
-                                         v->loss_workspace, v->loss_workspace_bytes, 1, stream)) return e;
-  if (int e = scorp_loss_l1_ssim_backward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,
-                                          v->grad_color, stream)) return e;
+  // (the three loss values are written by the loss backward's launch: no finalize kernel between the two)
+  if (int e = loss_forward_impl(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->out_loss3, v->loss_workspace,
+                                v->loss_workspace_bytes, 1, false, (hipStream_t)stream)) return e;
+  if (int e = loss_backward_impl(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,
+                                 v->grad_color, v->out_loss3, (hipStream_t)stream)) return e;
   return scorp_gs3d_backward_ex(in, v->state, v->pairs, v->capacity, v->grad_color, nullptr, nullptr, v->grads,
                                 v->backward_scratch, v->backward_scratch_bytes,
                                 (v->backward_flags & ~SCORP_BACKWARD_SCRATCH_ZEROED) | (zero_here ? SCORP_BACKWARD_SCRATCH_ZEROED : 0u),
@@ -50,8 +51,8 @@ extern "C" int scorp_gs2d_train_view(const ScorpGs2dTrainView *v, scorp_stream_t
   hipStream_t hs = (hipStream_t)stream;
   if (int e = scorp_gs2d_preprocess(in, v->out_radii, v->state, v->state_bytes, stream)) return e;
   if (int e = scorp_gs2d_render(in, v->state, v->pairs, v->capacity, v->out_color, v->out_allmap, stream)) return e;
-  if (int e = scorp_loss_l1_ssim_forward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->out_loss3,
-                                         v->loss_workspace, v->loss_workspace_bytes, 1, stream)) return e;
+  if (int e = loss_forward_impl(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->out_loss3, v->loss_workspace,
+                                v->loss_workspace_bytes, 1, false, hs)) return e;
   if (reg) {
     if (int e = scorp_gs2d_regularizers_forward(W, H, v->out_allmap, in->viewmatrix, v->rays_d, v->rays_o, v->depth_ratio,
                                                 v->lambda_normal, v->lambda_dist, v->out_reg2, v->reg_workspace,
@@ -59,8 +60,8 @@ extern "C" int scorp_gs2d_train_view(const ScorpGs2dTrainView *v, scorp_stream_t
   } else {
     SCORP_HIP_CHECK(hipMemsetAsync(v->out_reg2, 0, 2 * sizeof(float), hs));
   }
-  if (int e = scorp_loss_l1_ssim_backward(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,
-                                          v->grad_color, stream)) return e;
+  if (int e = loss_backward_impl(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,
+                                 v->grad_color, v->out_loss3, hs)) return e;
   if (reg) {
     if (int e = scorp_gs2d_regularizers_backward(W, H, v->out_allmap, in->viewmatrix, v->rays_d, v->rays_o, v->depth_ratio,
                                                  v->lambda_normal, v->lambda_dist, nullptr, v->grad_allmap, stream)) return e;

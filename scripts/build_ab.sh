@@ -10,7 +10,7 @@ HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectori
 objs=""
 skip=""
 for f in "$@"; do
-  $HIPCC -c $flags scorp_amd/csrc/$f -o build/variants/${name}_$f.o 2>/dev/null &
+  $HIPCC -c $flags scorp_amd/csrc/$f -o build/variants/${name}_$f.o 2>build/variants/${name}_$f.err &
   objs="$objs build/variants/${name}_$f.o"
   skip="$skip|/$f.o"
 done
