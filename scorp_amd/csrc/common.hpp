@@ -18,6 +18,7 @@ constexpr float kFovGuard = 1.3f;
 constexpr float kRadiusSigma = 3.0f;
 constexpr float kLambdaFloor = 0.1f;
 constexpr float kAlphaMax = 0.99f;
+constexpr float kLog2AlphaMax = -0.014499569695115089f;   // log2(kAlphaMax): only a splat with log2(opacity) above it can reach the clamp
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTMin = 0.0001f;
 constexpr float kWEps = 0.0000001f;

@@ -254,7 +254,11 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+#ifdef SCORP_BWD_NOATOMIC
+      if (park_v[k] != 0.0f && capacity == 0xFFFFFFFFu) atomicAdd(acc + park_o[k], park_v[k]);
+#else
       if (park_v[k] != 0.0f) atomicAdd(acc + park_o[k], park_v[k]);
+#endif
       park_v[k] = 0.0f;
     }
   };
@@ -263,9 +267,11 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   // A group is two halves of 8 splats.  Each half: 1a, 1b, then ONE pass over the matrix pipe whose 16 rows are
   // (8 slots) x (first term | second term) [exact form: (8 slots) x (v | w)], so the [row][pixel] matrix in LDS is
   // 16 x 64 dwords whatever the form; the two halves' results wait in registers and leave together.
-  auto process_group = [&](auto full, int nslots, int head, int top) {
+  auto process_group = [&](auto full, auto clampy, int nslots, int head, int top) {
     flush_sums();   // (a later group of the same chunk: the previous one's sums leave now)
     constexpr bool kFull = decltype(full)::value;   // full groups run straight-line; only a wave's last one is partial
+    constexpr bool kClamp = decltype(clampy)::value;   // the chunk holds a splat with opacity > 0.99 (the forward's rule:
+                                                       // only such a splat can reach alpha = 0.99; the others skip the v_min)
     int hv = head;
     asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
     const float4 *gcol = q_col + hv, *gt0 = q_t0 + hv;
@@ -303,7 +309,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
             // alpha = min(0.99, g_o) >= 1/255  <=>  g_o >= 1/255
             const bool ok = (i >= first) & (g_o >= kAlphaMin);
             const float Go = ok ? g_o : 0.0f;
-            const float alpha = fminf(kAlphaMax, Go);
+            const float alpha = kClamp ? fminf(kAlphaMax, Go) : Go;
             const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
             T *= rinv;
             const float w = alpha * T;
@@ -369,7 +375,11 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef SCORP_BWD_NOTAIL
+    if (false) {
+#else
     if (lane < nslots) {  // block-frame moments -> the ten screen-space gradients of slot `lane`
+#endif
       float *m = dbuf + lane * kDStride;
       const float *m2 = m + kGroup * kDStride;
       const float4 a = gt0[lane];     // x - cx, y - cy, A, B
@@ -404,9 +414,14 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
         const float svdx2 = xl * xl * m0 - 2.0f * xl * mx + mxx;
         const float svdxdy = xl * yl * m0 - xl * my - yl * mx + mxy;
         const float svdy2 = yl * yl * m0 - 2.0f * yl * my + myy;
+#ifdef SCORP_BWD_RAWMOM
+        *reinterpret_cast<float4 *>(m) = make_float4(svdx, svdy, -0.5f * svdx2, -svdxdy);
+        *reinterpret_cast<float4 *>(m + 4) = make_float4(-0.5f * svdy2, m0, mm[6], mm[7]);
+#else
         *reinterpret_cast<float4 *>(m) = make_float4(0.5f * W * (-cA * svdx - cB * svdy), 0.5f * H * (-cC * svdy - cB * svdx),
                                                      -0.5f * svdx2, -svdxdy);
         *reinterpret_cast<float4 *>(m + 4) = make_float4(-0.5f * svdy2, m0 / opac, mm[6], mm[7]);
+#endif
         *reinterpret_cast<float2 *>(m + 8) = make_float2(mm[8], mm[9]);
       }
     }
@@ -476,9 +491,11 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     __builtin_amdgcn_wave_barrier();
     const int top = (int)todo - (int)(kChunk * ch);          // 1-based position of slot 0
     const int n = top < kChunk ? top : kChunk;               // hits in this chunk (only the last chunk is short)
+    const bool hot = __ballot(id != 0xFFFFFFFFu && b.y > kLog2AlphaMax - 1e-4f) != 0;   // (b.y = log2(opacity))
     for (int head = 0; head < n; head += kGroup) {
-      if (n - head >= kGroup) process_group(std::true_type{}, kGroup, head, top - head);
-      else process_group(std::false_type{}, n - head, head, top - head);
+      if (n - head < kGroup) process_group(std::false_type{}, std::true_type{}, n - head, head, top - head);
+      else if (hot) process_group(std::true_type{}, std::true_type{}, kGroup, head, top - head);
+      else process_group(std::true_type{}, std::false_type{}, kGroup, head, top - head);
     }
     id = id1; a = a1; b = b1; c = c1; id1 = id2;
   }

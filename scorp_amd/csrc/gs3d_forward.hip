@@ -743,6 +743,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
                              // slots of a group are head + i without wrap-around: one LDS base, immediate offsets
   uint32_t nh = 0;           // hits found so far (wave-uniform)
   uint32_t consumed = 0;     // hits blended so far: slot i of the next group is hit number consumed + i + 1 of the list
+  uint32_t hot_end = 0;      // hits [0, hot_end) may hold a splat with opacity > 0.99 (wave-uniform; see blend_group)
 #ifdef SCORP_FWD_STATS
   uint32_t st_hits = 0, st_live = 0, st_any = 0, st_q[4] = {0, 0, 0, 0}, st_h[2] = {0, 0}, st_lane = 0;
 #endif
@@ -780,6 +781,8 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     }
     count += __builtin_popcountll(m);
     nh += (uint32_t)__builtin_popcountll(m);
+    // (b.y = log2(opacity); the margin keeps exp2(e) <= 0.99 for every other hit whatever the rounding of e)
+    if (__ballot(hit && b.y > kLog2AlphaMax - 1e-4f) != 0) hot_end = nh;   // groups up to this chunk's last hit keep the clamp
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool last_chunk = base + kFChunk >= n;
@@ -791,8 +794,12 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       const int sl = a_on ? hv + a_slot : kFRing;      // the other half of the lanes feeds zeros (exp_mfma.hpp)
       return block_exponents(q_k[0][sl], q_k[1][sl], q_k[2][sl], basis);
     };
-    auto blend_group = [&](auto full, int nslots, const f32x16 &e) -> bool {
+    auto blend_group = [&](auto full, auto clampy, int nslots, const f32x16 &e) -> bool {
       constexpr bool kFull = decltype(full)::value;
+      // alpha = min(0.99, opacity * G) and G <= 1: the clamp can only bind for a splat whose opacity itself exceeds 0.99.
+      // Groups that hold no such hit (all but a few per cent on any scene: opacity > 0.99 is sigmoid(x), x > 4.6) run
+      // without the v_min - one VALU instruction of the fourteen per hit.
+      constexpr bool kClamp = decltype(clampy)::value;
       int hv = head;
       asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
       const float4 *gc = q_col + hv;
@@ -805,7 +812,8 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
             if (__ballot(T > 0.0f) == 0) { all_done = true; break; }
           }
           const float4 col = gc[i];
-          const float alpha = fminf(kAlphaMax, __builtin_amdgcn_exp2f(e[i]));
+          const float g_o = __builtin_amdgcn_exp2f(e[i]);
+          const float alpha = kClamp ? fminf(kAlphaMax, g_o) : g_o;
           const bool live = alpha >= kAlphaMin;
           const float al = live ? alpha : 0.0f;
           // A saturated pixel is latched by the SIGN of T: the splat that would take T below 1e-4 is not blended and
@@ -852,18 +860,23 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
         const bool more = count >= 2 * kFGroup;
         f32x16 e2 = e;
         if (more) e2 = exponents(head + kFGroup == kFRing ? 0 : head + kFGroup);
-        if (blend_group(std::true_type{}, kFGroup, e) || __ballot(T > 0.0f) == 0) { all_done = true; break; }
+        const bool gd = consumed < hot_end ? blend_group(std::true_type{}, std::true_type{}, kFGroup, e)
+                                           : blend_group(std::true_type{}, std::false_type{}, kFGroup, e);
+        if (gd || __ballot(T > 0.0f) == 0) { all_done = true; break; }
         if (!more) break;
         e = e2;
       }
     }
 #else
     while (count >= kFGroup) {
-      if (blend_group(std::true_type{}, kFGroup, exponents(head)) || __ballot(T > 0.0f) == 0) { all_done = true; break; }
+      const f32x16 e = exponents(head);
+      const bool gd = consumed < hot_end ? blend_group(std::true_type{}, std::true_type{}, kFGroup, e)
+                                         : blend_group(std::true_type{}, std::false_type{}, kFGroup, e);
+      if (gd || __ballot(T > 0.0f) == 0) { all_done = true; break; }
     }
 #endif
     if (all_done) break;
-    if (last_chunk && count > 0) blend_group(std::false_type{}, count, exponents(head));
+    if (last_chunk && count > 0) blend_group(std::false_type{}, std::true_type{}, count, exponents(head));   // (one group per wave: not worth a variant)
     id0 = id1; a = a1; b = b1; c = c1; id1 = id2;
   }
   if constexpr (kForBackward) {
