@@ -149,6 +149,34 @@ def test_forward_backward_parity(name, precision, dev):
     compare_grads(t, o.backward(wc, wd, wa), g64_fn=oracle64_grads(kw, wc, wd, wa))
 
 
+@pytest.mark.parametrize("share", [1.0, 0.02])
+@pytest.mark.parametrize("precision", ["split", "exact_fp32"])
+def test_alpha_clamp_and_clamp_free_groups(share, precision, dev):
+    """alpha = min(0.99, opacity * G): the blend kernels run groups of hits without the clamp unless one of the hits has an
+    opacity above 0.99 (gs3d_forward.hip blend_group, gs3d_backward.hip process_group).  Every splat opaque enough to reach
+    the clamp (share 1.0: the clamped form everywhere) and one in fifty (both forms inside most lists, the switch points
+    anywhere in them) against the oracle, which clamps every hit."""
+    from scorp_amd.rasterizer3d import backward_precision
+    case = dict(N=6000, W=160, H=128, deg=1, seed=21, log_scale=math.log(0.08))
+    kw, _ = make_case(**case)
+    rng = np.random.default_rng(99)
+    op = kw["opacities"].copy()
+    hot = rng.uniform(size=op.shape) < share
+    op[hot] = rng.uniform(0.991, 0.9999, size=int(hot.sum())).astype(np.float32)
+    op[~hot] = np.minimum(op[~hot], 0.9)
+    kw["opacities"] = op
+    o = oracle(kw)
+    with backward_precision(precision):
+        out, t = hip_render(kw, dev)
+    compare_forward(out, o)
+    wc, wd, wa = image_weights(kw["H"], kw["W"], case["seed"])
+    color, _, depth, alpha = out
+    loss = (color * torch.tensor(wc, device=dev)).sum() + (depth * torch.tensor(wd, device=dev)).sum() + \
+           (alpha * torch.tensor(wa, device=dev)).sum()
+    loss.backward()
+    compare_grads(t, o.backward(wc, wd, wa), g64_fn=oracle64_grads(kw, wc, wd, wa))
+
+
 @pytest.mark.parametrize("name", ["sh3_bg_mod", "tiny_splats", "huge_splats", "inside_cloud"])
 def test_split_backward_equals_exact_fp32_backward(name, dev):
     """The fast backward (pixel->splat sums on fp16 MFMAs, both factors split into two fp16 terms = 22 bits) against
