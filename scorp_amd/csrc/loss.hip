@@ -70,10 +70,7 @@ __device__ __forceinline__ LossTile loss_tile(int gx, int gy, int C) {
 // separated by barriers as in the backward below, spent most of a workgroup's life waiting and needed 36 KB of LDS:
 // 54 us against 49.)
 // ---------------------------------------------------------------------------------------------------------
-#ifndef SCORP_STRIP_ITERS
-#define SCORP_STRIP_ITERS 4
-#endif
-constexpr int kStripIters = SCORP_STRIP_ITERS;                          // unrolled-by-11 groups of rows per strip
+constexpr int kStripIters = 4;                          // unrolled-by-11 groups of rows per strip
 constexpr int kStripRows = 11 * kStripIters - 10;       // output rows per strip (34)
 constexpr int kRowBuf = 80;                             // floats per row-buffer array (74 used)
 
