@@ -166,7 +166,21 @@ __device__ __forceinline__ void preprocess2d_body(const Pg2Args &a, float *s_sh,
             const float My1 = pb[0] * pc[0] + pb[1] * pc[1] - kk * pb[2] * pc[2];
             const float M11 = pc[0] * pc[0] + pc[1] * pc[1] - kk * pc[2] * pc[2];
             const float dM = Mxx * Myy - Mxy * Mxy;
-            if (Mxx > 0.0f && dM > 0.0f) {
+            // A surfel seen nearly edge-on projects to a sliver (a major axis of 100 px on a minor axis of 0.05 px occurs):
+            // rotated on the pixel grid, its conic has Mxx Myy ~ Mxy^2 and fp32 leaves dM - and with it the centre and the
+            // normalisation - no digits, which dropped blocks the sliver does cross (an isolated pixel of alpha 0.24 in
+            // a fuzz case).  The footprint is trusted only while every difference below keeps at least two digits;
+            // otherwise the surfel is never culled inside its rectangle (the published rasterizer's own behaviour).
+#ifndef SCORP_2D_SOUND_M
+#define SCORP_2D_SOUND_M 1e-3f
+#endif
+#ifndef SCORP_2D_SOUND_D
+#define SCORP_2D_SOUND_D 1e-4f
+#endif
+            const bool sound = Mxx > SCORP_2D_SOUND_M * (pa[0] * pa[0] + pa[1] * pa[1] + kk * pa[2] * pa[2]) &&
+                               Myy > SCORP_2D_SOUND_M * (pb[0] * pb[0] + pb[1] * pb[1] + kk * pb[2] * pb[2]) &&
+                               dM > SCORP_2D_SOUND_D * (Mxx * Myy + Mxy * Mxy);
+            if (sound) {
               const float ox = (My1 * Mxy - Mx1 * Myy) / dM, oy = (Mx1 * Mxy - My1 * Mxx) / dM;
               const float t1 = Mx1 * ox, t2 = My1 * oy;
               const float F = M11 + t1 + t2;

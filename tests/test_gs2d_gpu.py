@@ -143,6 +143,25 @@ def test_fuzz_parity_2d(k, dev):
     _parity_2d(FUZZ_2D[k], dev, outlier_gaussians=FUZZ_2D_EXCEPTIONS.get(k, 0) if _FUZZ_SEED == 20261004 else 0)
 
 
+def test_edge_on_surfel_sliver_is_not_culled(dev):
+    """A large surfel seen nearly edge-on projects to a sliver that owns ONE pixel every few dozen rows, far from its
+    low-pass blob.  Its footprint conic (Mxx Myy ~ Mxy^2) has no digits left in fp32: the exact block culling must then
+    stand back (preprocess2d_kernel, `sound`), or those pixels - alpha 0.24 in this case, found by a fuzz soak with seed
+    777 - are dropped.  The surfel alone, every pixel the oracle covers."""
+    from oracle.gs_oracle import OracleRender2D
+    kw, _ = make_case2d(**fuzz_cases("2d", 160, 777)[54])
+    one = dict(kw)
+    for key in ("means3D", "opacities", "shs", "scales", "rotations"):
+        one[key] = np.ascontiguousarray(kw[key][689:690])
+    o = OracleRender2D(np.float32, **one)
+    (color, radii, allmap), _ = hip_render2d(one, dev, requires_grad=False)
+    a_h, a_o = allmap.detach().cpu().numpy()[1], o.allmap[1]
+    far = (a_o > 0.02)
+    assert far.sum() >= 10 and (np.nonzero(far)[0].max() - np.nonzero(far)[0].min()) > 40    # blob + the isolated pixels
+    assert np.abs(a_h - a_o).max() < 2e-3, f"alpha off by {np.abs(a_h - a_o).max():.3e}"
+    assert np.abs(color.detach().cpu().numpy() - o.color).max() < 2e-3
+
+
 def test_stage_parity_2d(dev):
     """Surfel transforms, centres, normals match the oracle to rounding; radii and rectangles match exactly; the
     per-tile sorted lists are the oracle's with provably non-contributing pairs removed (exact footprint cull)."""
