@@ -53,12 +53,17 @@ def _scene_kw(name, cam_index=0):
                 campos=cam.camera_center.numpy().astype(np.float32), bg=np.zeros(3, np.float32))
 
 
+# SCORP_FULLSIZE_VIEWS="0,35,70,..." : the same tests on other cameras of the ring (one-off soak runs; default: camera 0)
+_VIEWS = [int(v) for v in os.environ.get("SCORP_FULLSIZE_VIEWS", "0").split(",")]
+
+
+@pytest.mark.parametrize("cam", _VIEWS)
 @pytest.mark.parametrize("name", ["S3", "S2"])
-def test_full_size_parity_vs_oracle(name, dev, parallel_oracle):
+def test_full_size_parity_vs_oracle(name, cam, dev, parallel_oracle):
     """One full-size 3DGS view, forward + backward (upstream gradients on colour, depth and alpha), HIP against oracle."""
     from tests.test_gs3d_gpu import compare_forward, compare_grads, hip_render, oracle, oracle64_grads
     from tests.util import image_weights
-    kw = _scene_kw(name)
+    kw = _scene_kw(name, cam)
     o = oracle(kw)
     out, t = hip_render(kw, dev)
     compare_forward(out, o)
@@ -121,10 +126,11 @@ def test_full_size_deterministic_backward(dev):
         PairPolicy.reset()
 
 
-def test_full_size_parity_vs_oracle_2d(dev, parallel_oracle):
+@pytest.mark.parametrize("cam", _VIEWS)
+def test_full_size_parity_vs_oracle_2d(cam, dev, parallel_oracle):
     """S6: 1 M surfels at 1600x1200, SH3 - the 2-D oracle's first full-size frame."""
     from tests.test_gs2d_gpu import _parity_2d
-    kw = _scene_kw("S6")
+    kw = _scene_kw("S6", cam)
     kw["scale_modifier"] = 1.0
     report = {}
     # tie_outliers: at 1 M surfels a few dozen have a pixel ON the low-pass switch (tests.util.assert_grad_close)
