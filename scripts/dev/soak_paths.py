@@ -1,0 +1,79 @@
+"""The one-call views against render + loss + backward, and the deterministic backward against itself and the atomic form,
+on random scenes / image sizes (3-D and 2-D)."""
+import sys
+sys.path.insert(0, '/root/repo')
+import math
+import numpy as np, torch
+from scorp_amd.gaussian_model import GaussianModel
+from scorp_amd.fused_loss import fused_l1_ssim_loss
+from scorp_amd.rasterizer3d import PairPolicy, backward_precision
+from scorp_amd.renderer import render
+from scorp_amd.renderer2d import GaussianModel2D, fused_surfel_regularizers, render as render2d
+from scorp_amd.synthetic import make_gaussians, ring_cameras
+from scorp_amd.train import PipelineParams
+from scorp_amd.train_view import train_view, train_view2d
+dev = torch.device('cuda:0')
+names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+rng = np.random.default_rng(11)
+bad = 0
+pipe = PipelineParams()
+
+
+def close(a, b, tol=2e-3):
+    return float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-12
+
+
+for it in range(40):
+    N = int(rng.choice([1, 17, 500, 4000, 20000])); deg = int(rng.integers(0, 4))
+    W, H = int(rng.integers(8, 420)), int(rng.integers(8, 330))
+    ls = math.log(float(rng.choice([0.01, 0.03, 0.1, 0.4])))
+    tag = f"N={N} deg={deg} {W}x{H} scale={math.exp(ls):.2f}"
+    cam = ring_cameras(5, W, H, it, radius=float(rng.uniform(2.0, 5.0)), device=dev)[it % 5]
+    bg = torch.rand(3, device=dev)
+    gt = torch.rand(3, H, W, device=dev)
+    mask = (torch.rand(1, H, W, device=dev) > 0.3).float() if it % 3 == 0 else None
+    try:
+        raw = make_gaussians(N, 3, 100 + it, log_scale_mean=ls)
+        a = GaussianModel.from_raw(raw, 3, device=dev); a.active_sh_degree = deg
+        b = GaussianModel.from_raw(raw, 3, device=dev); b.active_sh_degree = deg
+        pa = render(cam, a, pipe, bg)
+        la = fused_l1_ssim_loss(pa["render"], gt, 0.2, mask); la.backward()
+        pb = train_view(cam, b, pipe, bg, gt, 0.2, mask=mask)
+        PairPolicy.drain()
+        ok = torch.equal(pa["render"], pb["render"]) and torch.equal(pa["radii"], pb["radii"]) and abs(float(la) - float(pb["loss"])) < 1e-7
+        ok = ok and all(close(getattr(a, n).grad, getattr(b, n).grad) for n in names)
+        # deterministic: twice the same bits, and close to the atomic form
+        gs = []
+        with backward_precision("deterministic"):
+            for _ in range(2):
+                c = GaussianModel.from_raw(raw, 3, device=dev); c.active_sh_degree = deg
+                train_view(cam, c, pipe, bg, gt, 0.2, mask=mask)
+                gs.append([getattr(c, n).grad.clone() for n in names])
+        PairPolicy.drain()
+        ok = ok and all(torch.equal(x, y) for x, y in zip(*gs)) and all(close(getattr(a, n).grad, g) for n, g in zip(names, gs[0]))
+        if not ok:
+            bad += 1; print("3D FAIL", tag)
+    except Exception as e:   # noqa
+        bad += 1; print("3D EXC ", tag, type(e).__name__, str(e)[:300])
+    try:
+        raw = make_gaussians(N, 3, 200 + it, log_scale_mean=ls, scale_dims=2)
+        a = GaussianModel2D.from_raw(raw, 3, device=dev); a.active_sh_degree = deg
+        b = GaussianModel2D.from_raw(raw, 3, device=dev); b.active_sh_degree = deg
+        ln, ld = ((0.05, 100.0), (0.0, 0.0))[it % 2]
+        pa = render2d(cam, a, pipe, bg)
+        tot = fused_l1_ssim_loss(pa["render"], gt, 0.2)
+        if ln or ld:
+            nl, dl = fused_surfel_regularizers(pa, ln, ld); tot = tot + nl + dl
+        tot.backward()
+        pb = train_view2d(cam, b, pipe, bg, gt, 0.2, ln, ld)
+        PairPolicy.drain()
+        ok = torch.equal(pa["render"], pb["render"]) and torch.equal(pa["radii"], pb["radii"]) and torch.equal(pa.allmap, pb["allmap"])
+        ok = ok and abs(float(tot) - float(pb["loss"])) < 1e-5 * max(1.0, abs(float(tot)))
+        ok = ok and all(close(getattr(a, n).grad, getattr(b, n).grad) for n in names)
+        if not ok:
+            bad += 1; print("2D FAIL", tag)
+    except Exception as e:   # noqa
+        bad += 1; print("2D EXC ", tag, type(e).__name__, str(e)[:300])
+PairPolicy.reset()
+torch.cuda.synchronize()
+print("done, failures:", bad)
