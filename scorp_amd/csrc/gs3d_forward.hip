@@ -688,7 +688,7 @@ __device__ unsigned long long g_fwd_trace[3 * 40000];
 #ifdef SCORP_FWD_STATS
 // diagnostic build only (scripts/dev/stats_forward.py): how full the 64 lanes are per blended hit, and how many
 // iterations a wave would run if its hits were listed per 8x4 half / per 4x4 quadrant / per pixel instead of per block
-__device__ unsigned long long g_fwd_stats[8];
+__device__ unsigned long long g_fwd_stats[9];
 #endif
 template <bool kForBackward>
 __global__ void __launch_bounds__(64, SCORP_FWD_WAVES)
@@ -745,7 +745,9 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   uint32_t consumed = 0;     // hits blended so far: slot i of the next group is hit number consumed + i + 1 of the list
   uint32_t hot_end = 0;      // hits [0, hot_end) may hold a splat with opacity > 0.99 (wave-uniform; see blend_group)
 #ifdef SCORP_FWD_STATS
-  uint32_t st_hits = 0, st_live = 0, st_any = 0, st_q[4] = {0, 0, 0, 0}, st_h[2] = {0, 0}, st_lane = 0;
+  uint32_t st_hits = 0, st_live = 0, st_any = 0, st_q[4] = {0, 0, 0, 0}, st_h[2] = {0, 0}, st_lane = 0, st_pairs = 0;
+  uint64_t st_prev = 0;
+  bool st_have = false;
 #endif
   // The chunk's gathers (list entry -> record) are dependent loads of ~1 us each; they are software-pipelined: while
   // chunk c is blended the records of chunk c+1 and the list entries of chunk c+2 are already in flight.
@@ -840,6 +842,9 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
             st_q[2] += (m & 0x0F0F0F0F00000000ull) != 0; st_q[3] += (m & 0xF0F0F0F000000000ull) != 0;
             st_h[0] += (m & 0x00000000FFFFFFFFull) != 0; st_h[1] += (m & 0xFFFFFFFF00000000ull) != 0;
             st_lane += (ok & live) ? 1u : 0u;
+            // greedy pairing of ADJACENT hits whose live lanes are disjoint (no pixel sees both: they could share an iteration)
+            if (st_have && (st_prev & m) == 0) { st_pairs += 1; st_have = false; }
+            else { st_prev = m; st_have = true; }
           }
 #endif
         }
@@ -894,6 +899,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       atomicAdd(&g_fwd_stats[5], (unsigned long long)(st_h[0] + st_h[1]));
       atomicAdd(&g_fwd_stats[6], (unsigned long long)max(st_h[0], st_h[1]));
       atomicAdd(&g_fwd_stats[7], (unsigned long long)lm);
+      atomicAdd(&g_fwd_stats[8], (unsigned long long)st_pairs);
     }
   }
 #endif
@@ -1215,9 +1221,9 @@ extern "C" int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint
 
 #ifdef SCORP_FWD_STATS
 extern "C" int scorp_debug_fwd_stats(unsigned long long *out, int reset) {
-  static const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scorp::g_fwd_stats), 64) != hipSuccess) return -2;
-  return reset && hipMemcpyToSymbol(HIP_SYMBOL(scorp::g_fwd_stats), zero, 64) != hipSuccess ? -2 : 0;
+  static const unsigned long long zero[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scorp::g_fwd_stats), 72) != hipSuccess) return -2;
+  return reset && hipMemcpyToSymbol(HIP_SYMBOL(scorp::g_fwd_stats), zero, 72) != hipSuccess ? -2 : 0;
 }
 #endif
 #ifdef SCORP_FWD_TRACE
