@@ -363,6 +363,7 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="reference call-site convention: torch activations + cat per view")
     ap.add_argument("--spatial-sort", action="store_true", help="GaussianModel.sort_spatially() first: Gaussians stored along a Z-order curve (not the default)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary record (the 2DGS workload S6) of the default N=1 run")
+    ap.add_argument("--lead-in", type=int, default=40, help="untimed views enqueued in front of the warm-up of every timed run (see timed_run)")
     ap.add_argument("--exact-backward", action="store_true", help="all-fp32 MFMA reduction in the blend backward (scorp_gs3d_backward_ex) instead of the fp16 two-term split")
     args = ap.parse_args()
 
@@ -487,13 +488,15 @@ def main():
         kern_all = _C.prof_collect()
         dominant = max(kern_all, key=lambda k: kern_all[k][0]) if any(c for _, c in kern_all.values()) else None
 
-    def timed_run(n_warm, n_steps, bracket=None, lead_in=12):
+    def timed_run(n_warm, n_steps, bracket=None, lead_in=args.lead_in):
         """n_warm untimed views, then EXACTLY n_steps views between two hipEvents recorded on the launch stream directly
         behind the warm-up: no host synchronisation opens the timed region (a synchronise leaves the chip idle for a
         moment and the first ~20 views after it run 5-20 % slow, scripts/dev/ramp.py - at the driver's --steps 20 that
         was the whole region).  For the same reason `lead_in` more views are enqueued in front of the warm-up, behind the
         synchronise that separates this run from the probe / the previous run: with a short --warmup the warm-up itself
-        would otherwise sit on the ramp.  barrier + synchronize bracket the whole; the host clock over the region (enqueue
+        would otherwise sit on the ramp (measured at --steps 20 --warmup 5 on one box: 1 315-1 320 views/s with 12 lead-in
+        views, 1 352-1 355 with 40, 1 355-1 356 with 100; the default 200-step run gives the same with any of them: 40 it is,
+        30 ms per timed run).  barrier + synchronize bracket the whole; the host clock over the region (enqueue
         start -> synchronize) is kept as a cross-check.  Returns (event s, host s, host enqueue s, last loss)."""
         torch.cuda.synchronize()
         if world > 1:
@@ -692,7 +695,7 @@ def main():
             "timing": {"clock": "hipEvents on the launch stream, recorded directly behind the warm-up views and behind the last timed view "
                                 "(max over ranks); barrier + synchronize before the lead-in + warm-up views and after the region",
                        "untimed_views_before_the_region": {"probe (every kernel bracketed, then a synchronise)": max(3, min(args.warmup, 8)),
-                                                           "lead-in (keeps the chip off its idle ramp)": 12, "warmup": args.warmup},
+                                                           "lead-in (keeps the chip off its idle ramp)": args.lead_in, "warmup": args.warmup},
                        "host_clock_ms_per_step": round(dt_host / args.steps * 1e3, 4),
                        "note": "host clock = first enqueue of the region -> synchronize returned; it starts while warm-up views are "
                                "still executing, so it reads at most (warm-up backlog) above the event figure"},
