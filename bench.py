@@ -379,10 +379,13 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
+        import datetime
+        # (a bounded collective timeout: a rank stuck in a secondary record's exchange errors out instead of hanging the job)
+        tmo = datetime.timedelta(minutes=5)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where collective payloads live
 
     from scorp_amd import _C
@@ -605,12 +608,19 @@ def main():
         dist.all_gather(gathered, ll)     # gather of per-rank results (scalars)
 
     # secondary record on every rank count: the 128-rotation sweep (the workload north_star's 8-GPU scaling target is set on)
+    # (every secondary record is guarded: a failure in one of them is reported inside the record and never costs the headline)
     sweep_rec = None
     if args.scene == "S3" and not args.no_secondary and not args.exact_backward and args.streams == 1:
-        sweep_rec = secondary_sweep(dev, cdev, rank, world)
+        try:
+            sweep_rec = secondary_sweep(dev, cdev, rank, world)
+        except Exception as e:   # noqa: BLE001
+            sweep_rec = {"error": f"{type(e).__name__}: {e}"}
     refine_rec = None
     if args.scene == "S3" and not args.no_secondary and not args.exact_backward and args.streams == 1:
-        refine_rec = secondary_post_refine_objects(dev, cdev, rank, world)
+        try:
+            refine_rec = secondary_post_refine_objects(dev, cdev, rank, world)
+        except Exception as e:   # noqa: BLE001
+            refine_rec = {"error": f"{type(e).__name__}: {e}"}
     # N > 1 only: data-parallel training of ONE scene - the code path with a real exchange step
     # (visibility-sparse reduce-scatter + all-gather of the gradient rows over RCCL).  Guarded: a failure here is
     # reported in the record and never costs the headline line.
@@ -757,11 +767,17 @@ def main():
         if dp_rec is not None:
             line.setdefault("secondary", {})["dp_train"] = dp_rec
         if world == 1 and args.scene == "S3" and not args.no_secondary and not args.exact_backward:
-            line.setdefault("secondary", {})["S6"] = secondary_s6(dev, parity=not args.no_cpu_baseline)
+            try:
+                line.setdefault("secondary", {})["S6"] = secondary_s6(dev, parity=not args.no_cpu_baseline)
+            except Exception as e:   # noqa: BLE001
+                line.setdefault("secondary", {})["S6"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:   # noqa: BLE001   (the line is out; a broken group must not turn the run into a failure)
+            print(f"[bench] process group teardown: {type(e).__name__}: {e}", file=sys.stderr)
 
 
 if __name__ == "__main__":
