@@ -354,7 +354,9 @@ int scorp_gs2d_train_view(const ScorpGs2dTrainView *view, scorp_stream_t stream)
  * In place, one launch:  xyz <- ((xyz - c) R^T) * s + c + t;  rotation <- q (x) normalize(rotation) (w,x,y,z; q = the
  * quaternion of R);  scaling <- scaling + log(s) (log-space, `scale_dims` = 3, or 2 for surfels);  features_rest
  * [N, rest_coeffs, 3]: band l = 1..3 (coefficients l^2-1 .. (l+1)^2-2 of it) multiplied by the real Wigner-D block D_l.
- * params: 113 device floats, 16-byte aligned: R[9] (row-major) c[3] t[3] s[3] q[4] D1[9] D2[25] D3[49]. */
+ * params: 113 device floats, 16-byte aligned: R[9] (row-major) c[3] t[3] s[3] q[4] D1[9] D2[25] D3[49].
+ * rotation / scaling / features_rest may each be NULL: that part of the model is then left untouched (a translation
+ * passes only xyz; the reference's gaussians_translate / gaussians_scale never touch the quaternions). */
 int scorp_gaussians_transform(float *xyz, float *rotation, float *scaling, float *features_rest, int32_t num_gaussians,
                               int32_t rest_coeffs, int32_t scale_dims, const float *params, scorp_stream_t stream);
 

@@ -267,6 +267,20 @@ class SweepPlan:
         return out
 
 
+@contextlib.contextmanager
+def _together(dev, what):
+    """The local part of a sharded unit of work, in front of its exchange step: an exception on ANY rank is raised on
+    EVERY rank (parallel.all_ok: one 4-byte all-reduce) instead of leaving the others waiting in the all-gather."""
+    from .parallel import all_ok
+    err = None
+    try:
+        yield
+    except Exception as e:   # noqa: BLE001
+        err = e
+    if not all_ok(err is None, dev):
+        raise RuntimeError(f"{what}: the local part failed on " + ("this rank" if err is not None else "another rank")) from err
+
+
 def align_objects(models, rotations, cameras, targets_per_object, bg, render_fn=render):
     """The rotation sweep with the OBJECT as the unit of sharding (align_3dgs_clpe_9dof.py:489-499 loops over objects
     serially; they share no mutable state): object j -> rank j mod G, every rank sweeps all hypotheses of its objects
@@ -276,9 +290,10 @@ def align_objects(models, rotations, cameras, targets_per_object, bg, render_fn=
     dev = models[0]._xyz.device
     mine = shard_indices(len(models))
     rows = []
-    for j in mine:
-        _, fit, best = rotation_sweep(models[j], rotations, cameras, targets_per_object[j], bg, render_fn=render_fn, shard=False)
-        rows.append(torch.stack([torch.tensor(float(best), device=fit.device), fit[best, 0].float()]))
+    with _together(dev, "align_objects"):
+        for j in mine:
+            _, fit, best = rotation_sweep(models[j], rotations, cameras, targets_per_object[j], bg, render_fn=render_fn, shard=False)
+            rows.append(torch.stack([torch.tensor(float(best), device=fit.device), fit[best, 0].float()]))
     v = torch.stack(rows) if rows else torch.zeros((0, 2), dtype=torch.float32, device=dev)
     _, vals = gather_results(mine, v.to(dev), n_total=len(models))
     return [(int(vals[j, 0]), float(vals[j, 1])) for j in range(len(models))]
@@ -297,9 +312,10 @@ def rotation_sweep(model, rotations, cameras, targets, bg, use_graph=None, plan=
         scores = torch.stack(plan.score(rotations, ids)) if ids else torch.zeros((0, 1), dtype=torch.float32, device=dev)
         return torch.arange(len(ids), device=scores.device), scores, (int(torch.argmax(scores[:, 0])) if ids else -1)
     mine = shard_indices(len(rotations))
-    if plan is None:
-        plan = SweepPlan(model, cameras, targets, bg, use_graph=use_graph, render_fn=render_fn)
-    vals = plan.score(rotations, mine) if mine else []
+    with _together(dev, "rotation_sweep"):
+        if plan is None:
+            plan = SweepPlan(model, cameras, targets, bg, use_graph=use_graph, render_fn=render_fn)
+        vals = plan.score(rotations, mine) if mine else []
     v = torch.stack(vals) if vals else torch.zeros((0, 1), dtype=torch.float32, device=dev)
     ids, scores = gather_results(mine, v.to(dev), n_total=len(rotations))      # ONE fixed-size all-gather, no host sync
     best = int(ids[torch.argmax(scores[:, 0])]) if ids.numel() else -1

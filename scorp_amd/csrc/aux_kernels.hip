@@ -157,7 +157,7 @@ transform_gaussians_kernel(int N, int k_rest, int dims, float *__restrict__ xyz,
     xyz[3 * (size_t)i + 1] = (P.R[3] * x + P.R[4] * y + P.R[5] * z) * P.s[1] + P.c[1] + P.t[1];
     xyz[3 * (size_t)i + 2] = (P.R[6] * x + P.R[7] * y + P.R[8] * z) * P.s[2] + P.c[2] + P.t[2];
   }
-  {
+  if (rot) {   // (NULL: no rotation part - translate / scale leave the quaternions untouched, as utils/gaussians.py:12-40 does)
     float4 b = reinterpret_cast<const float4 *>(rot)[i];
     const float inv = 1.0f / sqrtf(b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w);
     b.x *= inv; b.y *= inv; b.z *= inv; b.w *= inv;
@@ -165,7 +165,9 @@ transform_gaussians_kernel(int N, int k_rest, int dims, float *__restrict__ xyz,
     reinterpret_cast<float4 *>(rot)[i] = make_float4(aw * b.x - ax * b.y - ay * b.z - az * b.w, aw * b.y + ax * b.x + ay * b.w - az * b.z,
                                                       aw * b.z - ax * b.w + ay * b.x + az * b.y, aw * b.w + ax * b.z - ay * b.y + az * b.x);
   }
-  for (int d = 0; d < dims; d++) scaling[(size_t)dims * i + d] += logf(P.s[d]);
+  if (scaling)   // (NULL: no scale part - nothing is written into a tensor the caller may share with another model)
+    for (int d = 0; d < dims; d++) scaling[(size_t)dims * i + d] += logf(P.s[d]);
+  if (!rest) return;
   // SH bands: rest[i][j][ch], j = 0 .. k_rest-1 (coefficient 1 + j of the full set)
   float *r = rest + (size_t)i * k_rest * 3;
   if (k_rest >= 3) {
@@ -212,13 +214,13 @@ transform_gaussians_kernel(int N, int k_rest, int dims, float *__restrict__ xyz,
 
 extern "C" int scorp_gaussians_transform(float *xyz, float *rotation, float *scaling, float *features_rest, int32_t N,
                                          int32_t rest_coeffs, int32_t scale_dims, const float *params, scorp_stream_t stream_) {
-  if (N < 0 || (N > 0 && (!xyz || !rotation || !scaling || !params)) || rest_coeffs < 0 || (rest_coeffs > 0 && !features_rest) ||
-      scale_dims < 1 || scale_dims > 3 || (((uintptr_t)rotation | (uintptr_t)params) & 15)) {
+  if (N < 0 || (N > 0 && (!xyz || !params)) || rest_coeffs < 0 || scale_dims < 1 || scale_dims > 3 ||
+      (((uintptr_t)rotation | (uintptr_t)params) & 15)) {
     set_error("bad arguments to scorp_gaussians_transform"); return SCORP_ERR_INVALID;
   }
   if (N == 0) return SCORP_OK;
   hipStream_t stream = (hipStream_t)stream_;
-  transform_gaussians_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, rest_coeffs, scale_dims, xyz, rotation, scaling, features_rest,
+  transform_gaussians_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, rest_coeffs, scale_dims, xyz, rotation, scaling, rest_coeffs > 0 ? features_rest : nullptr,
                                                                   reinterpret_cast<const scorp::TransformParams *>(params));
   SCORP_KERNEL_CHECK("transform_gaussians", 0, stream);
   return SCORP_OK;

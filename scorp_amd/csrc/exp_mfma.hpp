@@ -55,6 +55,22 @@ __device__ __forceinline__ void splat_block_coefs(float x, float y, float A, flo
   k2 = make_uint4(pack_hi16(t[2][0], t[2][1]), pack_hi16(t[2][2], t[2][3]), pack_hi16(t[2][4], t[2][5]), 0u);
 }
 
+// The reference skips a splat at a pixel where power > 0, i.e. where opacity * G exceeds the opacity itself.  For a
+// positive-definite conic that never happens (up to rounding, within which exp2(e) = o (1 + 1e-5) is the right answer,
+// not "skip"), and the hot loops carry no such test.  It can happen for an INDEFINITE conic (det < 0 passes the
+// reference's cull), so groups that hold one run the guarded instantiation: exp2(e) <= lim with lim = the two-term bf16
+// truncation of o (1 + 4e-5) (>= o (1 + 2.4e-5)), which rides in the spare fourth dword of the first coefficient term -
+// K slots 6, 7 of the A operand, which meet zeros in the B operand (both halves are finite bf16 values, so 0 x them = 0).
+__device__ __forceinline__ uint32_t guard_limit_pack(float opacity) {
+  const float lim = opacity * 1.00004f;
+  const uint32_t t0 = __float_as_uint(lim) & 0xFFFF0000u;
+  const uint32_t t1 = __float_as_uint(lim - __uint_as_float(t0)) & 0xFFFF0000u;
+  return pack_hi16(t0, t1);
+}
+__device__ __forceinline__ float guard_limit_unpack(uint32_t w) { return __uint_as_float(w << 16) + __uint_as_float(w & 0xFFFF0000u); }
+// a record of SplatRec whose conic is not positive-definite: preprocess marks it with kcut = +inf
+__device__ __forceinline__ bool rec_is_indefinite(float kcut) { return kcut == __builtin_inff(); }
+
 // B operand of this lane: the six monomials of its own pixel (lane = pixel of the 8x8 block, row-major), bf16, exact.
 __device__ __forceinline__ uint4 pixel_basis_frag(int lane) {
   const float xl = (float)(lane & 7) - 3.5f, yl = (float)(lane >> 3) - 3.5f;

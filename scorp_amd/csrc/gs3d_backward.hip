@@ -307,7 +307,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
             const float4 col = rc[i8 % kAhead];   // r, g, b, depth
             const float g_o = __builtin_amdgcn_exp2f(ev[i]);
             // alpha = min(0.99, g_o) >= 1/255  <=>  g_o >= 1/255
-            const bool ok = (i >= first) & (g_o >= kAlphaMin);
+            bool ok = (i >= first) & (g_o >= kAlphaMin);
+            if constexpr (kClamp) ok = ok & (g_o <= guard_limit_unpack(q_k[0][hv + i].w));   // the forward's `power > 0` skip
             const float Go = ok ? g_o : 0.0f;
             const float alpha = kClamp ? fminf(kAlphaMax, Go) : Go;
             const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
@@ -481,6 +482,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     if (id != 0xFFFFFFFFu) {
       uint4 k0, k1, k2;
       splat_block_coefs(a.x, a.y, a.z, a.w, b.x, b.y, cx, cy, k0, k1, k2);
+      k0.w = guard_limit_pack(c.w);   // the forward's bits (exp_mfma.hpp)
       q_k[0][lane] = k0; q_k[1][lane] = k1; q_k[2][lane] = k2;
       q_col[lane] = make_float4(b.z, b.w, c.x, c.y);
       q_t0[lane] = make_float4(a.x - cx, a.y - cy, a.z, a.w);
@@ -491,7 +493,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     __builtin_amdgcn_wave_barrier();
     const int top = (int)todo - (int)(kChunk * ch);          // 1-based position of slot 0
     const int n = top < kChunk ? top : kChunk;               // hits in this chunk (only the last chunk is short)
-    const bool hot = __ballot(id != 0xFFFFFFFFu && b.y > kLog2AlphaMax - 1e-4f) != 0;   // (b.y = log2(opacity))
+    // (b.y = log2(opacity); an indefinite conic takes the same instantiation for its `power > 0` guard)
+    const bool hot = __ballot(id != 0xFFFFFFFFu && (b.y > kLog2AlphaMax - 1e-4f || rec_is_indefinite(c.z))) != 0;
     for (int head = 0; head < n; head += kGroup) {
       if (n - head < kGroup) process_group(std::false_type{}, std::true_type{}, n - head, head, top - head);
       else if (hot) process_group(std::true_type{}, std::true_type{}, kGroup, head, top - head);

@@ -769,7 +769,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     const uint32_t id2 = fetch_id(base + 2 * kFChunk);
     bool hit = false;
     if (id0 != 0xFFFFFFFFu)   // the record holds -k * conic and k * cutoff (k > 0): the test is scale-invariant
-      hit = conic_min_over_box(a.x, a.y, -a.z, -0.5f * a.w, -b.x, bx0, bx1, by0, by1) <= c.z;
+      hit = rec_is_indefinite(c.z) || conic_min_over_box(a.x, a.y, -a.z, -0.5f * a.w, -b.x, bx0, bx1, by0, by1) <= c.z;
     const uint64_t m = __ballot(hit);
     if (hit) {
       const uint32_t rank = nh + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
@@ -777,6 +777,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       qi = qi >= kFRing ? qi - kFRing : qi;
       uint4 k0, k1, k2;
       splat_block_coefs(a.x, a.y, a.z, a.w, b.x, b.y, cx, cy, k0, k1, k2);
+      k0.w = guard_limit_pack(c.w);   // (spare K slots: exp_mfma.hpp)
       q_k[0][qi] = k0; q_k[1][qi] = k1; q_k[2][qi] = k2;
       q_col[qi] = make_float4(b.z, b.w, c.x, c.y);
       if constexpr (kForBackward) my_hits[rank] = id0;   // (rank < n: inside this tile's slice of the region)
@@ -784,7 +785,8 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     count += __builtin_popcountll(m);
     nh += (uint32_t)__builtin_popcountll(m);
     // (b.y = log2(opacity); the margin keeps exp2(e) <= 0.99 for every other hit whatever the rounding of e)
-    if (__ballot(hit && b.y > kLog2AlphaMax - 1e-4f) != 0) hot_end = nh;   // groups up to this chunk's last hit keep the clamp
+    // ... and an indefinite conic needs the `power > 0` guard, which the same instantiation carries
+    if (__ballot(hit && (b.y > kLog2AlphaMax - 1e-4f || rec_is_indefinite(c.z))) != 0) hot_end = nh;   // groups up to this chunk's last hit keep the clamp
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const bool last_chunk = base + kFChunk >= n;
@@ -805,6 +807,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       int hv = head;
       asm volatile("" : "+v"(hv));   // keep the group's LDS bases in VGPRs (else every ds_read re-moves an SGPR base)
       const float4 *gc = q_col + hv;
+      const uint4 *gk = q_k[0] + hv;
       bool all_done = false;
       uint32_t lastg = 0;   // 1-based slot of the group's last contributor to this pixel (inline constants, no SGPR moves)
 #pragma unroll
@@ -816,7 +819,8 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
           const float4 col = gc[i];
           const float g_o = __builtin_amdgcn_exp2f(e[i]);
           const float alpha = kClamp ? fminf(kAlphaMax, g_o) : g_o;
-          const bool live = alpha >= kAlphaMin;
+          bool live = alpha >= kAlphaMin;
+          if constexpr (kClamp) live = live & (g_o <= guard_limit_unpack(gk[i].w));   // the reference's `power > 0` skip (exp_mfma.hpp)
           const float al = live ? alpha : 0.0f;
           // A saturated pixel is latched by the SIGN of T: the splat that would take T below 1e-4 is not blended and
           // flips T negative, after which every test_T is negative too (a live pixel always has T >= 1e-4, and

@@ -121,7 +121,12 @@ __device__ __forceinline__ SplatGeom splat_geometry(const PgArgs &a, const float
           // alpha >= 1/255 needs q <= 2 ln(255 o): tiles (here) and 8x8 pixel blocks (blend kernels) whose minimum q
           // is larger are skipped without changing a single output bit (common.hpp: conic_min_over_box).
           kcut = 1.01f * 2.0f * logf(fmaxf(255.0f * op, 1.0f)) + 0.02f;
-          if (x1 - x0 <= 8 && y1 - y0 <= 8) {
+          // det < 0 (an indefinite conic: fp32 cancellation on a huge or near-camera splat, or a cov3D_precomp that is not
+          // positive semi-definite) passes the reference's `det == 0` cull and is then drawn wherever power <= 0.  The exact
+          // culling below assumes a convex q, so such a splat keeps its whole rectangle, and kcut = +inf tells the blend
+          // kernels both to skip their block test and to run the group with the `power > 0` guard (gs3d_forward.hip).
+          if (!(det > 0.0f)) { kcut = __builtin_inff(); mask = kMaskAll; }
+          else if (x1 - x0 <= 8 && y1 - y0 <= 8) {
             for (int ty = y0; ty < y1; ty++)
               for (int tx = x0; tx < x1; tx++)
                 if (conic_min_over_box(sx, sy, cA, cB, cC, (float)(tx * kTile), (float)(tx * kTile + kTile - 1),

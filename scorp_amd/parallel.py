@@ -2,14 +2,43 @@
 pose hypotheses — so the only collectives are one broadcast of the Gaussians at start and one gather of small results
 at the end; nothing on the per-view critical path.  Backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in CPU tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+# A process group of ONE rank short-circuits every helper below (nothing to exchange).  With this switch (or
+# SCORP_SINGLE_RANK_COLLECTIVES=1 in the environment) an initialised group of one rank issues its collectives anyway:
+# trivial exchanges, but the real code path - init_process_group(device_id=...), broadcast, all_gather_into_tensor,
+# reduce_scatter_tensor on device tensors over RCCL - which is how tests/test_rccl_gpu.py executes the "nccl" branches
+# on the one GPU a test box has.
+SINGLE_RANK_COLLECTIVES = os.environ.get("SCORP_SINGLE_RANK_COLLECTIVES", "0") == "1"
 
 
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def collective():
+    """True where the helpers have to talk: more than one rank, or one rank with SINGLE_RANK_COLLECTIVES."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or SINGLE_RANK_COLLECTIVES
+
+
+def all_ok(local_ok, device="cpu"):
+    """Collective agreement that every rank got through its local part: all-reduce(MIN) of one int.  Call it between the
+    local part of a unit of work and its exchange step, so that a rank that failed does not leave the others waiting in
+    a collective it never enters (it raises on every rank instead)."""
+    if not collective():
+        return bool(local_ok)
+    if dist.get_backend() == "nccl" and torch.device(device).type != "cuda":
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
 
 
 def shard_indices(n, rank=None, world_size=None):
@@ -25,7 +54,7 @@ def broadcast_tensors(tensors, src=0):
     buffer: one collective instead of one per tensor (xGMI is point-to-point - few, large messages).  Every
     rank passes tensors of the same shapes; the source's values arrive in place."""
     r, w = world()
-    if w > 1 and tensors:
+    if collective() and tensors:
         keys = sorted(tensors)
         flat = torch.cat([tensors[k].reshape(-1) for k in keys]) if r == src else \
             torch.empty(sum(tensors[k].numel() for k in keys), dtype=tensors[keys[0]].dtype, device=tensors[keys[0]].device)
@@ -50,21 +79,19 @@ def gather_results(ids, values, n_total=None):
     _, w = world()
     dev = values.device
     ids = torch.as_tensor(ids, dtype=torch.int64, device=dev)
-    if w > 1 and n_total is not None and n_total < (1 << 24):
+    if collective() and n_total is not None and n_total < (1 << 24):
         m, c = -(-int(n_total) // w), values.shape[1]
         buf = torch.full((m, c + 1), -1.0, dtype=torch.float32, device=dev)
         buf[: ids.numel(), 0] = ids.to(torch.float32)
         buf[: ids.numel(), 1:] = values.to(torch.float32)
         out = torch.empty((w * m, c + 1), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(out, buf)
-        # rank r's row k is unit r + k * world: the valid rows and their order follow from n_total alone
-        unit = torch.arange(w * m, device=dev)
-        unit = (unit // m) + (unit % m) * w
-        keep = unit < n_total
-        order = torch.argsort(unit[keep])
-        rows = out[keep][order]
+        # rank r's row k is unit r + k * world, so unit u sits in row (u mod world) * m + u div world: the valid rows and
+        # their order follow from n_total alone - index arithmetic, no boolean mask (out[mask] is a host synchronisation)
+        unit = torch.arange(int(n_total), device=dev)
+        rows = out[(unit % w) * m + unit // w]
         return rows[:, 0].to(torch.int64), rows[:, 1:].to(values.dtype)
-    if w > 1:
+    if collective():
         counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(w)]
         dist.all_gather(counts, torch.tensor([ids.numel()], dtype=torch.int64, device=dev))
         m = int(max(c.item() for c in counts))
@@ -103,7 +130,7 @@ def average_gradients(params, bucket_bytes=64 << 20):
     point-to-point, so a ring all-reduce is per-link bound (~153 GB/s) and wants few, large messages.
     Parameters whose .grad is None on this rank (nothing visible) contribute zeros."""
     _, w = world()
-    if w == 1:
+    if not collective():
         return
     params = [p for p in params if p.requires_grad]
     bucket, size = [], 0
@@ -134,7 +161,7 @@ def average_gradients(params, bucket_bytes=64 << 20):
     flush()
 
 
-def average_gradients_sparse(params, visible, bucket_bytes=64 << 20):
+def average_gradients_sparse(params, visible, bucket_bytes=64 << 20, dense_above=0.6):
     """The same average as `average_gradients`, moving only the rows that can be non-zero: a Gaussian's gradient row is
     zero on a rank where it was not rendered (radii == 0), so rows outside the UNION of the ranks' visibility masks are
     zero everywhere and need no traffic (train_3dgs.py:56-193 with one view per rank).
@@ -146,22 +173,28 @@ def average_gradients_sparse(params, visible, bucket_bytes=64 << 20):
       3. the averaged rows are scattered back; every other row of .grad is zero.
 
     `params`: per-Gaussian parameter tensors ([N, ...]); `visible`: bool[N] of this rank's view.  Returns the number
-    of rows moved.  In a large scene seen from inside a view shows a fraction of the Gaussians and the 248 MB dense
-    all-reduce shrinks by that fraction; on an object seen whole (the synthetic S3) the union is everything and this is
-    the dense reduction plus one small collective."""
+    of rows in the union.  In a large scene seen from inside a view shows a fraction of the Gaussians and the 248 MB dense
+    all-reduce shrinks by that fraction; where the union covers more than `dense_above` of the Gaussians the rows are not
+    packed at all and the dense bucketed average runs (decided from the reduced mask, so every rank takes the same branch)."""
     r, w = world()
-    if w == 1:
+    if not collective():
         return int(visible.sum())
     params = [p for p in params if p.requires_grad]
     dev = params[0].device
     union = visible.to(torch.uint8).clone()
     dist.all_reduce(union, op=dist.ReduceOp.MAX)
-    idx = torch.nonzero(union, as_tuple=False).squeeze(-1)
-    n = int(idx.numel())
+    n = int(union.sum())                       # (the same number on every rank: the branch below is taken together)
     if n == 0:
         for p in params:
             p.grad = torch.zeros_like(p)
         return 0
+    if n > dense_above * union.numel():
+        # The union is (nearly) everything - an object seen whole, the synthetic S3: the packed form would move the dense
+        # payload AND pay a row gather before and a row scatter after the exchange (2 x 248 MB of indexed copies at 1 M
+        # Gaussians; the round-3 rehearsal measured 46 it/s sparse against 52 dense for exactly this reason).
+        average_gradients(params, bucket_bytes)
+        return n
+    idx = torch.nonzero(union, as_tuple=False).squeeze(-1)
     rows = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(p.shape[0], -1)[idx] for p in params]
     widths = [x.shape[1] for x in rows]
     flat = torch.cat(rows, dim=1).reshape(-1)                     # [n, sum(widths)] row-major
@@ -196,7 +229,7 @@ def gather_rows(rows_by_unit, n_units, widths, c=None, device=None):
     if c is None:
         c = next(iter(rows_by_unit.values())).shape[1]
     dev = device if device is not None else next(iter(rows_by_unit.values())).device
-    if w == 1:
+    if not collective():
         return [rows_by_unit[j] for j in range(n_units)]
     shares = [sum(widths[j] for j in range(k, n_units, w)) for k in range(w)]    # rows every rank contributes
     m = max(shares) if shares else 0

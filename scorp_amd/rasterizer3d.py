@@ -79,10 +79,23 @@ class PairPolicy:
         """Pairs to reserve for a forward of this context."""
         got, n0 = cls._ctx.get(cls.key(N, H, W), (0, 0))
         if got > 0 and n0 > 0 and int(N) != n0:
-            got = max(int(got * (int(N) / n0)) + 1024, 1 << 16)     # same pairs per Gaussian on the resized model
+            got = cls._rescaled(got, n0, N, H, W)
         if got <= 0 and cls.reserve <= 0:
             got = max(4 * int(N), 1 << 20)
         return max(got, int(cls.reserve))
+
+    @classmethod
+    def _rescaled(cls, got, n0, N, H, W):
+        """What a context learned on n0 Gaussians, for a model of N: the same pairs per Gaussian while the model is the SAME
+        model resized (densify_and_prune: within 0.5x ... 2x); anything else is another scene that happens to share the
+        resolution and the stream - a 10 k-Gaussian object that fills the screen (200 pairs per Gaussian, align's eager
+        sweeps) says nothing about a multi-million-Gaussian scene - and starts from the default, as a context nobody has
+        sized.  Never more than every Gaussian in every tile."""
+        ratio = int(N) / n0
+        if not 0.5 <= ratio <= 2.0:
+            return 0
+        tiles = ((int(W) + 15) // 16) * ((int(H) + 15) // 16)
+        return min(max(int(got * ratio) + 1024, 1 << 16), max(tiles * int(N), 1 << 16))
 
     @classmethod
     def set_context(cls, N, H, W, pairs):
@@ -128,7 +141,7 @@ class PairPolicy:
                 need = int(n.value * cls.slack) + 1024
                 got, n0 = cls._ctx.pop(p.key, (0, 0))
                 if n0 > 0 and p.n > 0 and n0 != p.n:
-                    got = int(got * (p.n / n0))                       # what was learned, at this view's model size
+                    got = int(got * (p.n / n0)) if 0.5 <= p.n / n0 <= 2.0 else 0   # what was learned, at this view's model size (_rescaled)
                 cls._ctx[p.key] = (max(got, need), p.n if p.n > 0 else n0)   # (re-inserted last: most recently learned)
                 while len(cls._ctx) > cls._MAX_CTX:
                     cls._ctx.pop(next(iter(cls._ctx)))

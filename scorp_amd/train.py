@@ -24,7 +24,7 @@ import torch.distributed as dist
 from .fused_loss import fused_l1_ssim_loss
 from .rasterizer3d import PairPolicy
 from .loss import depth_losses, isotropic_loss, psnr
-from .parallel import average_gradients, average_gradients_sparse, world
+from .parallel import average_gradients, average_gradients_sparse, collective, world
 from .renderer import render
 
 
@@ -39,8 +39,7 @@ class PipelineParams:
 def _sync_densification_stats(gaussians):
     """Before a densify / prune decision every replica must see the same statistics: sums of the screen-space gradient
     norms and visit counts, max of the screen radii."""
-    _, w = world()
-    if w > 1:
+    if collective():
         dist.all_reduce(gaussians.xyz_gradient_accum, op=dist.ReduceOp.SUM)
         dist.all_reduce(gaussians.denom, op=dist.ReduceOp.SUM)
         dist.all_reduce(gaussians.max_radii2D, op=dist.ReduceOp.MAX)
@@ -51,8 +50,12 @@ def _shared_overflow(pkg, data_parallel):
     that skipped its Adam step alone would stop being bit-identical to the others (next densification: different N,
     mismatched all-reduce shapes).  One 4-byte all-reduce(MAX) on the device word, no host synchronisation; the reduced
     word then guards the optimizer step and masks the statistics on every rank."""
-    if data_parallel and world()[1] > 1:
-        dist.all_reduce(pkg["overflow"], op=dist.ReduceOp.MAX)
+    if data_parallel and collective():
+        # (a clone: pkg["overflow"] is a view of the 64-byte header PairPolicy.drain() reads for THIS rank's bookkeeping -
+        # reduced in place, a rank that did not overflow could read overflow = 1 with num_pairs <= capacity there)
+        ovf = pkg["overflow"].clone()
+        dist.all_reduce(ovf, op=dist.ReduceOp.MAX)
+        return ovf
     return pkg["overflow"]
 
 
@@ -166,7 +169,7 @@ def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, backgr
             ks.append(stack.pop())
         k = ks[rank]
         loss, _ = training_iteration(gaussians, cameras[k], gt_images[k], opt, pipe, background, it,
-                                     data_parallel=data_parallel and w > 1, **kw)
+                                     data_parallel=data_parallel and collective(), **kw)
         losses.append(loss.detach())
         if kw.get("fused_view") and it % 32 == 0:
             _drain_reservation()
@@ -235,10 +238,16 @@ def post_refine_objects(objects, cameras, gt_images, object_alphas, opt, iterati
     refine_fn = refine_fn or post_refine
     n = len(objects)
     mine = shard_indices(n)
-    losses = {}
-    for j in mine:
-        losses[j] = refine_fn(objects[j], cameras, gt_images, object_alphas[j], opt, iterations=iterations, pipe=pipe,
-                              background=background, seed=seed + j)
+    losses, err = {}, None
+    try:
+        for j in mine:
+            losses[j] = refine_fn(objects[j], cameras, gt_images, object_alphas[j], opt, iterations=iterations, pipe=pipe,
+                                  background=background, seed=seed + j)
+    except Exception as e:   # noqa: BLE001   (raised on every rank below, not only here: nobody waits in the all-gather)
+        err = e
+    from .parallel import all_ok
+    if not all_ok(err is None, objects[0]._features_dc.device):
+        raise RuntimeError("post_refine_objects: refinement failed on " + ("this rank" if err is not None else "another rank")) from err
     widths = [int(o._features_dc.shape[0]) for o in objects]
     rows = {j: objects[j]._features_dc.detach().reshape(widths[j], -1) for j in mine}
     # (a rank without an object - more ranks than objects - still takes part in the collective)

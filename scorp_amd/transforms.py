@@ -60,7 +60,9 @@ def _use_kernel(g, *host_args):
     has: numpy rotations / RANSAC results); device-resident parameters (a captured sweep's rotation buffer) keep the
     torch formulation, which needs no host round trip."""
     return g._xyz.is_cuda and all(a is None or not (torch.is_tensor(a) and a.is_cuda) for a in host_args) \
-        and not torch.cuda.is_current_stream_capturing()
+        and not torch.cuda.is_current_stream_capturing() \
+        and all(getattr(g, n).data.is_contiguous() and getattr(g, n).dtype == torch.float32
+                for n in ("_xyz", "_rotation", "_scaling", "_features_rest"))   # (else: the torch formulation below)
 
 
 @torch.no_grad()
@@ -94,8 +96,12 @@ def gaussians_transform(g, R=None, T=None, scale=None, fix_center=False, blocks=
         if not t.is_contiguous() or t.dtype != torch.float32:
             raise RuntimeError(f"gaussians_transform: {name} must be a contiguous float32 tensor")
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    _C.check(L.scorp_gaussians_transform(p(g._xyz.data), p(g._rotation.data), p(g._scaling.data),
-                                         p(g._features_rest.data) if k_rest else None, g._xyz.shape[0], k_rest,
+    # parts a transform does not have are not passed: a translation or a scale leaves the quaternions alone (the kernel
+    # would rewrite them normalised), a rotation writes nothing into `_scaling` (which a shallow copy of the model shares)
+    rotating, scaling = R is not None, scale is not None
+    _C.check(L.scorp_gaussians_transform(p(g._xyz.data), p(g._rotation.data) if rotating else None,
+                                         p(g._scaling.data) if scaling else None,
+                                         p(g._features_rest.data) if (k_rest and rotating) else None, g._xyz.shape[0], k_rest,
                                          int(g._scaling.shape[1]), p(params), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
              "scorp_gaussians_transform")
 

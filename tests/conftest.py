@@ -28,7 +28,7 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """Tally of tests.util.assert_grad_close: gradient tensors checked / tensors that needed the oracle's own band."""
     from tests.util import BAND_TALLY
     if BAND_TALLY["checked"]:
-        cap = int(os.environ.get("SCORP_BAND_CAP", "24"))
+        cap = int(os.environ.get("SCORP_BAND_CAP", "15"))
         terminalreporter.write_line(f"assert_grad_close: {BAND_TALLY['checked']} gradient tensors checked, "
                                     f"{BAND_TALLY['fallback']} needed the oracle's own band (cap {cap})")
         for n in BAND_TALLY["names"]:
@@ -37,6 +37,6 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
 
 def pytest_sessionfinish(session, exitstatus):
     from tests.util import BAND_TALLY
-    cap = int(os.environ.get("SCORP_BAND_CAP", "24"))
+    cap = int(os.environ.get("SCORP_BAND_CAP", "15"))
     if BAND_TALLY["fallback"] > cap and session.exitstatus == 0:
         session.exitstatus = 1      # too many tensors passed only through the band: treated as a failed session

@@ -25,22 +25,8 @@ def dev():
 
 
 def hip_render2d(kw, dev, requires_grad=True):
-    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    T = lambda a, rg=False: None if a is None else torch.tensor(a, device=dev, requires_grad=rg and requires_grad)
-    N = kw["means3D"].shape[0]
-    t = dict(means3D=T(kw["means3D"], True), opacities=T(kw["opacities"].reshape(N, 1), True), shs=T(kw.get("shs"), True),
-             colors_precomp=T(kw.get("colors_precomp"), True), scales=T(kw.get("scales"), True),
-             rotations=T(kw.get("rotations"), True))
-    means2D = torch.zeros(N, 3, device=dev, requires_grad=requires_grad)
-    s = GaussianRasterizationSettings(
-        image_height=kw["H"], image_width=kw["W"], tanfovx=kw["tanfovx"], tanfovy=kw["tanfovy"], bg=T(kw["bg"]),
-        scale_modifier=kw.get("scale_modifier", 1.0), viewmatrix=T(kw["view"]), projmatrix=T(kw["proj"]),
-        sh_degree=kw.get("sh_degree", 0), campos=T(kw["campos"]), prefiltered=False, debug=False)
-    out = GaussianRasterizer(raster_settings=s)(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"],
-                                                colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"],
-                                                cov3D_precomp=None)
-    t["means2D"] = means2D
-    return out, t
+    from scorp_amd.refcall import render2d_reference_call
+    return render2d_reference_call(kw, dev, requires_grad=requires_grad)
 
 
 def assert_radii_match(got, ref):
@@ -68,8 +54,10 @@ def test_forward_backward_parity_2d(name, dev):
     _parity_2d(CASES[name], dev)
 
 
-def _parity_2d(case, dev, report=None, outlier_gaussians=0, kw=None, tie_outliers=0):
-    """`case`: arguments of make_case2d - or, with `kw` given (a full-size scene), only its "seed" is used."""
+def _parity_2d(case, dev, report=None, outlier_gaussians=0, kw=None, tie_outliers=0, f64_report=None):
+    """`case`: arguments of make_case2d - or, with `kw` given (a full-size scene), only its "seed" is used.
+    `f64_report` (a dict): every gradient tensor is ALSO held against the float64 build of the oracle
+    (tests.util.assert_no_further_from_f64) and (relL1(HIP, f64), relL1(oracle32, f64)) is left there per tensor."""
     from oracle.gs_oracle import OracleRender2D
     if kw is None:
         kw, _ = make_case2d(**case)
@@ -96,14 +84,22 @@ def _parity_2d(case, dev, report=None, outlier_gaussians=0, kw=None, tie_outlier
     def ref64(nm):
         if "g" not in cache:   # the oracle's own band (float64 build, two perturbed fp32 runs): only for a tensor that misses
             from tests.test_gs3d_gpu import perturbed
-            cache["g"] = [OracleRender2D(np.float64, **kw).backward(wc, wa),
+            cache["g"] = [g64() if f64_report is not None else OracleRender2D(np.float64, **kw).backward(wc, wa),
                           OracleRender2D(np.float32, **perturbed(kw, +1)).backward(wc, wa),
                           OracleRender2D(np.float32, **perturbed(kw, -1)).backward(wc, wa)]
         return [x[nm] for x in cache["g"]]
 
+    def g64():
+        if "g64" not in cache:
+            cache["g64"] = OracleRender2D(np.float64, **kw).backward(wc, wa)
+        return cache["g64"]
+
     def close(nm, got, key):
         got = got.detach().cpu().numpy().reshape(g[key].shape).copy()
         refs = [g[key]]
+        if f64_report is not None:
+            from tests.util import assert_no_further_from_f64
+            f64_report[nm] = assert_no_further_from_f64(key, got, g[key], g64()[key])
         if outlier_gaussians:   # a NAMED exception (FUZZ_2D_EXCEPTIONS): the worst few surfels are checked loosely, apart
             err = np.abs(got - g[key]).reshape(got.shape[0], -1).max(1)
             rows = np.argsort(-err)[:outlier_gaussians]

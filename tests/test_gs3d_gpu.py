@@ -28,23 +28,8 @@ def dev():
 
 
 def hip_render(kw, dev, requires_grad=True, debug=False):
-    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    T = lambda a, rg=False: None if a is None else torch.tensor(a, device=dev, requires_grad=rg and requires_grad)
-    N = kw["means3D"].shape[0]
-    t = dict(means3D=T(kw["means3D"], True), opacities=T(kw["opacities"].reshape(N, 1), True),
-             shs=T(kw.get("shs"), True), colors_precomp=T(kw.get("colors_precomp"), True),
-             scales=T(kw.get("scales"), True), rotations=T(kw.get("rotations"), True),
-             cov3D_precomp=T(kw.get("cov3D_precomp"), True))
-    means2D = torch.zeros(N, 3, device=dev, requires_grad=requires_grad)
-    s = GaussianRasterizationSettings(
-        image_height=kw["H"], image_width=kw["W"], tanfovx=kw["tanfovx"], tanfovy=kw["tanfovy"], bg=T(kw["bg"]),
-        scale_modifier=kw.get("scale_modifier", 1.0), viewmatrix=T(kw["view"]), projmatrix=T(kw["proj"]),
-        sh_degree=kw.get("sh_degree", 0), campos=T(kw["campos"]), prefiltered=False, debug=debug)
-    out = GaussianRasterizer(raster_settings=s)(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"],
-                                                shs=t["shs"], colors_precomp=t["colors_precomp"], scales=t["scales"],
-                                                rotations=t["rotations"], cov3D_precomp=t["cov3D_precomp"])
-    t["means2D"] = means2D
-    return out, t
+    from scorp_amd.refcall import render3d_reference_call
+    return render3d_reference_call(kw, dev, requires_grad=requires_grad, debug=debug)
 
 
 def oracle(kw):
@@ -624,3 +609,42 @@ def test_deterministic_backward_is_bit_reproducible_and_equals_the_atomic_form(n
         got = d1[k].double()
         l1 = float((got - ref.double()).abs().sum() / ref.double().abs().sum().clamp_min(1e-300))
         assert l1 < 2e-5, f"{k}: deterministic vs atomic rel L1 {l1:.2e}"
+
+
+def _indefinite_case():
+    """A precomputed-covariance scene in which every third 3-D covariance has its largest eigenvalue negated: not positive
+    semi-definite, so the projected 2-D conic of most of them is INDEFINITE (det < 0), which the reference's `det == 0`
+    cull lets through and its blend then draws wherever power <= 0 (the region between the branches of a hyperbola)."""
+    kw, _ = make_case(N=900, W=112, H=80, deg=0, seed=21, precomp_cov=True, log_scale=math.log(0.05))
+    c = kw["cov3D_precomp"].astype(np.float64)
+    S = np.zeros((c.shape[0], 3, 3))
+    S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2] = c.T
+    S[:, 1, 0], S[:, 2, 0], S[:, 2, 1] = S[:, 0, 1], S[:, 0, 2], S[:, 1, 2]
+    sel = np.arange(c.shape[0]) % 3 == 0
+    w, V = np.linalg.eigh(S[sel])
+    w[:, 2] *= -1.0
+    S[sel] = np.einsum("nij,nj,nkj->nik", V, w, V)
+    kw["cov3D_precomp"] = np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).astype(np.float32)
+    return kw, sel
+
+
+@pytest.mark.parametrize("precision", ["split", "exact_fp32"])
+def test_indefinite_conic_is_skipped_where_power_is_positive(precision, dev):
+    """the blend kernels dropped the reference's `if (power > 0) continue` (an exponent from the matrix cores
+    has no such test in its hot loop).  A conic that is not positive-definite then blended with alpha up to 0.99 - or, in
+    a clamp-free group, with alpha > 1 and a dead pixel - where the reference skips it.  Such splats now carry a marker
+    from preprocess and run the guarded instantiation: image and gradients equal the oracle's, which has the test."""
+    from scorp_amd.rasterizer3d import backward_precision
+    kw, sel = _indefinite_case()
+    o = oracle(kw)
+    without = dict(kw)
+    without["opacities"] = np.where(sel, 0.0, kw["opacities"].reshape(-1)).astype(np.float32).reshape(kw["opacities"].shape)
+    assert np.abs(o.color - oracle(without).color).mean() > 1e-2, "the indefinite splats are not drawn: the case tests nothing"
+    with backward_precision(precision):
+        out, t = hip_render(kw, dev)
+    compare_forward(out, o)
+    wc, wd, wa = image_weights(kw["H"], kw["W"], 21)
+    color, _, depth, alpha = out
+    ((color * torch.tensor(wc, device=dev)).sum() + (depth * torch.tensor(wd, device=dev)).sum()
+     + (alpha * torch.tensor(wa, device=dev)).sum()).backward()
+    compare_grads(t, o.backward(wc, wd, wa), g64_fn=oracle64_grads(kw, wc, wd, wa))

@@ -78,9 +78,23 @@ def grad_errors(got, ref):
             float(np.abs(got - ref).sum() / max(np.abs(ref).sum(), 1e-300)))
 
 
+def assert_no_further_from_f64(name, got, ref32, ref64, floor=1e-4, factor=1.25):
+    """The float64 build of the oracle as the third party: the HIP path's relative L1 distance to it may not exceed
+    max(floor, factor x the fp32 oracle's own distance to it).  north_star's tolerance (1e-4) is the floor; where fp32
+    itself cannot hold it - the fp32 oracle misses its own float64 build by more - the HIP path has to be (about) as close
+    to float64 as the fp32 oracle is.  Returns (relL1(HIP, f64), relL1(oracle32, f64))."""
+    e_hip, e_o32 = grad_errors(got, ref64)[1], grad_errors(ref32, ref64)[1]
+    import os
+    if os.environ.get("SCORP_F64_REPORT_ONLY"):   # (one-off exploration runs: print the table without asserting)
+        return e_hip, e_o32
+    assert e_hip <= max(floor, factor * e_o32), (f"grad {name}: relL1(HIP, f64) {e_hip:.3e} > max({floor:g}, {factor} x "
+                                                 f"relL1(oracle32, f64) {e_o32:.3e})")
+    return e_hip, e_o32
+
+
 # How often a gradient tensor needed the oracle's own band (below) instead of passing against the fp32 oracle as it
 # stands.  tests/conftest.py prints the tally at the end of the session and FAILS the session if more than
-# SCORP_BAND_CAP tensors (default 24 of the ~1 700 checked by the -m gpu suite) needed it: the fallback must stay the
+# SCORP_BAND_CAP tensors (default 15 of the ~1 700 checked by the -m gpu suite) needed it: the fallback must stay the
 # exception it was introduced as, and a kernel change that makes it the norm shows up here.
 BAND_TALLY = {"checked": 0, "fallback": 0, "names": []}
 
@@ -124,6 +138,7 @@ def assert_grad_close(name, got, ref32, band_fn, max_tol, l1_tol, k=3.0, outlier
     over = excess > max_tol * scale
     max_ok = excess.max() / scale < max_tol or (int(over.sum()) <= outliers and excess.max() / scale < outlier_tol)
     ok = max_ok and excess.sum() / total < l1_tol and needed < 5e-3
+    BAND_TALLY.setdefault("beyond", []).append((name, int(over.sum())))
     assert ok, (f"grad {name}: vs fp32 oracle max {e32[0]:.3e} L1 {e32[1]:.3e}; beyond {k} x the oracle's own band: max "
                 f"{excess.max() / scale:.3e} L1 {excess.sum() / total:.3e}, elements that needed the band {needed:.2e}, "
                 f"elements beyond the max-norm tolerance {int(over.sum())} (allowed {outliers})")
