@@ -155,14 +155,15 @@ int scorp_gs3d_backward(const ScorpGs3dInputs *in, const void *state, const void
  * scorp_gs3d_train_view uses it: there the blend FORWARD's waves, whose memory pipes idle, clear the rows on the way. */
 #define SCORP_BACKWARD_SCRATCH_ZEROED 2u
 /* SCORP_BACKWARD_DETERMINISTIC: no float atomics.  Every (8x8 block, hit) writes its ten sums as one plain 64-byte row
- * (partial[quad][position in the block's hit list]); a second kernel then sums, per Gaussian, the rows of the blocks it
- * hit in a FIXED order - its tiles in rectangle order, the four blocks of a tile in order, its position in a block's
- * depth-sorted hit list found by binary search on (depth, index).  Two runs on the same inputs give the same bits:
- * `get_mask3d` votes on the SIGN of repeated backward passes on one forward (utils/mask.py:52,65,89,124), which atomic
- * accumulation order can flip for sums near zero.  Needs the larger scratch of scorp_gs3d_backward_scratch_bytes_ex. */
+ * partial[4 * pair + block], pair = the ordinal of its (Gaussian, tile) pair in Gaussian-major order (an exclusive scan of
+ * the Gaussians' tile counts + the tile's rank in the Gaussian's tile mask), with one flag byte per row; a second kernel
+ * then adds, per Gaussian, its rows - contiguous by construction - in a FIXED order: its tiles in mask order, the four
+ * blocks of a tile in order.  Two runs on the same inputs give the same bits: `get_mask3d` votes on the SIGN of repeated
+ * backward passes on one forward (utils/mask.py:52,65,89,124), which atomic accumulation order can flip for sums near
+ * zero.  Needs the larger scratch of scorp_gs3d_backward_scratch_bytes_ex. */
 #define SCORP_BACKWARD_DETERMINISTIC 4u
 /* scratch size for scorp_gs3d_backward_ex with `flags`: the accumulator rows (num_gaussians * 64 bytes), plus, for
- * SCORP_BACKWARD_DETERMINISTIC, one word per 8x8 block and 4 * capacity rows of 64 bytes */
+ * SCORP_BACKWARD_DETERMINISTIC, num_gaussians + 1 pair ordinals, 4 * capacity flag bytes and 4 * capacity rows of 64 bytes */
 size_t scorp_gs3d_backward_scratch_bytes_ex(int32_t num_gaussians, int32_t image_width, int32_t image_height, uint64_t capacity,
                                             uint32_t flags);
 int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,

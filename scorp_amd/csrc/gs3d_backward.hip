@@ -120,7 +120,9 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
                            const float *__restrict__ bg, const float *__restrict__ final_T,
                            const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
                            const float *__restrict__ dL_ddepth, const float *__restrict__ dL_dalpha,
-                           float *__restrict__ acc, float *__restrict__ partial, uint32_t *__restrict__ block_todo) {
+                           float *__restrict__ acc, float *__restrict__ partial, uint8_t *__restrict__ row_flags,
+                           const uint32_t *__restrict__ pair_base, const BinRec *__restrict__ bin,
+                           const uint64_t *__restrict__ tile_mask) {
   // staged hits: the three bf16 terms of the six block-frame coefficients of log2(opacity * G) (exp_mfma.hpp), the
   // blended values (r, g, b, depth) for the recurrence, and what the moment step needs: (x - cx, y - cy, A, B), (C, opacity), id
   __shared__ uint4 q_k[3][kChunk];
@@ -151,10 +153,10 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   const int a_slot = a_operand_slot(lane);
   if (lane < 3) *reinterpret_cast<uint4 *>(&xm[(13 + lane) * kXStride + 64]) = make_uint4(0u, 0u, 0u, 0u);
   const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
-  // deterministic mode (partial != NULL): the sums leave as plain rows partial[quad][hit-list position], and the
-  // per-Gaussian reduction needs to know how many of a block's hits were replayed
+  // deterministic mode: the sums leave as plain rows partial[4 * pair + quad], pair = the (Gaussian, tile) pair's ordinal
+  // in GAUSSIAN-major order (pair_base[id] + the tile's rank in the Gaussian's tile mask), with a flag byte per row
   constexpr bool det = kDet;
-  if (end == beg) { if (det && lane == 0) block_todo[tile * 4 + quad] = 0u; return; }
+  if (end == beg) return;
   const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
   // all of the pixel's loads are issued together (no load waits on `last`); pixels nothing was blended into drop
   // their upstream gradient afterwards by a select (it may be NaN: depth / alpha at empty pixels)
@@ -169,7 +171,6 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   }
   if (last == 0) { dpix0 = dpix1 = dpix2 = ddep = dalp = 0.0f; }
   const uint32_t todo = wave_max_u32(last);   // wave-uniform (SGPR): the chunk loop and the slot indices live in SGPRs
-  if (det && lane == 0) block_todo[tile * 4 + quad] = todo;
   if (todo == 0) return;
   // split form: one power-of-two scale per wave from the block's largest upstream gradient
   float sv = 1.0f, inv_sv = 1.0f;
@@ -242,7 +243,6 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   uint32_t park_o[4] = {det ? 0xFFFFFFFFu : 0u, det ? 0xFFFFFFFFu : 0u, det ? 0xFFFFFFFFu : 0u, det ? 0xFFFFFFFFu : 0u};
                                                 // ... and their float offsets in acc (N * 16 < 2^32, checked at the entry
                                                 // point); det: offsets in `partial`, 0xFFFFFFFF = nothing parked
-  const uint32_t prow0 = (uint32_t)quad * capacity + beg;   // det: first row of this block's slice of `partial`
   auto flush_sums = [&]() {
     if (det) {   // rows are written whole (zeros included): nothing was cleared beforehand
 #pragma unroll
@@ -440,10 +440,12 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       park_v[k] = 0.0f;
       if (det) {
         park_o[k] = 0xFFFFFFFFu;
-        if (sl < nslots && col < 10) {   // slot sl of this group is hit number top - sl (1-based) of the block's list
+        const uint32_t pair = sl < nslots ? q_id[head + sl] : 0xFFFFFFFFu;   // (det: the staging lane left the pair ordinal here)
+        if (pair < capacity && col < 10) {   // (an ordinal beyond the reservation: an overflowed view, discarded anyway)
           const bool used = kColorOnly ? (col >= 6 && col < 9) : true;
           park_v[k] = used ? dbuf[sl * kDStride + col] : 0.0f;
-          park_o[k] = (prow0 + (uint32_t)(top - sl) - 1u) * (uint32_t)kAccStride + col;
+          park_o[k] = (pair * 4u + (uint32_t)quad) * (uint32_t)kAccStride + col;
+          if (col == 0) row_flags[pair * 4u + (uint32_t)quad] = 1;
         }
       } else if (sl < nslots && (kColorOnly ? (col >= 6 && col < 9) : col < 10)) {
         park_v[k] = dbuf[sl * kDStride + col];
@@ -487,7 +489,19 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
       q_col[lane] = make_float4(b.z, b.w, c.x, c.y);
       q_t0[lane] = make_float4(a.x - cx, a.y - cy, a.z, a.w);
       q_t1[lane] = make_float2(b.x, c.w);
-      q_id[lane] = id;
+      if constexpr (det) {
+        // the (Gaussian, tile) pair's ordinal, Gaussian-major: pair_base[id] + the rank of this tile among the tiles the
+        // Gaussian reaches (for_each_tile's order: the set bits of its mask, or its whole rectangle row by row)
+        const uint4 raw = reinterpret_cast<const uint4 *>(bin)[id];
+        const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
+        const uint64_t mk = tile_mask[id];
+        const int tx = tile % tiles_x, ty = tile / tiles_x;
+        const uint32_t rank = mk == kMaskAll ? (uint32_t)((ty - br.y0) * (br.x1 - br.x0) + (tx - br.x0))
+                                             : (uint32_t)__builtin_popcountll(mk & ((1ull << ((ty - br.y0) * 8 + (tx - br.x0))) - 1ull));
+        q_id[lane] = pair_base[id] + rank;
+      } else {
+        q_id[lane] = id;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -507,51 +521,90 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Deterministic mode, second half: one thread per Gaussian sums the partial rows of the (8x8 block, hit) pairs it
-// belongs to, in a fixed order: tiles of its rectangle (those its exact tile mask keeps) in row-major order, the four
-// blocks of a tile in order.  A block's hit list is depth-sorted - by (depth bits, index), the key of the tile sort - so
-// the Gaussian's position in it is found by binary search; it may be absent (the block's exact footprint test dropped
-// it) or beyond the part of the list the backward replayed (block_todo): then it has no row there.
+// Deterministic mode.  The rows are addressed by the (Gaussian, tile) pair's ordinal in Gaussian-major order, so the rows
+// of one Gaussian are CONTIGUOUS - partial[4 * pair_base[i] ... 4 * pair_base[i + 1]) - and the ordered per-Gaussian sum
+// is a streaming read with no search (round 3 found a Gaussian's row in every block's depth-sorted hit list by binary
+// search: ~190 dependent loads per Gaussian, 2.7 ms of a 3.5 ms view).
+//   pair_count_kernel / pair_base_kernel : pair_base[i] = number of (Gaussian, tile) pairs of the Gaussians before i
+//                                          (a two-level exclusive scan of the tile counts the binning used)
+//   reduce_pair_rows_kernel              : sixteen lanes per Gaussian (lane = float of a row) add the flagged rows in the
+//                                          fixed order tiles of the mask x blocks 0..3
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kScanBlock = 1024;   // Gaussians per workgroup of the pair-count scan
+__device__ __forceinline__ uint32_t pairs_of(const BinRec &br, uint64_t mask) {
+  if ((br.radius & kRadiusMask) == 0) return 0u;
+  return mask == kMaskAll ? (uint32_t)((br.x1 - br.x0) * (br.y1 - br.y0)) : (uint32_t)__builtin_popcountll(mask);
+}
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *s_red) {   // 256 threads
+  for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
 __global__ void __launch_bounds__(256)
-reduce_partials_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
-                       const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ hits, uint32_t capacity,
-                       int tiles_x, const uint32_t *__restrict__ block_todo, const float *__restrict__ partial,
-                       float *__restrict__ acc) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  float sum[10];
-#pragma unroll
-  for (int c = 0; c < 10; c++) sum[c] = 0.0f;
-  const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
-  const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
-  if ((br.radius & kRadiusMask) != 0) {
-    const uint64_t my_key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
-    for_each_tile(br.x0, br.y0, br.x1, br.y1, tile_mask[i], tiles_x, [&](int t) {
-      const uint32_t beg = min(tile_start[t], capacity);
-      for (int q = 0; q < 4; q++) {
-        const uint32_t n = block_todo[t * 4 + q];
-        const uint32_t *list = hits + (size_t)q * capacity + beg;
-        uint32_t lo = 0, hi = n;   // first position whose key is >= mine
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          const uint32_t id = list[mid];
-          const uint64_t key = ((uint64_t)bin[id].depth_bits << 32) | id;
-          if (key < my_key) lo = mid + 1; else hi = mid;
-        }
-        if (lo < n && list[lo] == (uint32_t)i) {
-          const float4 *row = reinterpret_cast<const float4 *>(partial + ((size_t)q * capacity + beg + lo) * kAccStride);
-          const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-          sum[0] += r0.x; sum[1] += r0.y; sum[2] += r0.z; sum[3] += r0.w; sum[4] += r1.x; sum[5] += r1.y;
-          sum[6] += r1.z; sum[7] += r1.w; sum[8] += r2.x; sum[9] += r2.y;
-        }
-      }
-    });
+pair_count_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask, uint32_t *__restrict__ block_sums) {
+  __shared__ uint32_t s_red[4];
+  uint32_t v = 0;
+  for (int k = 0; k < kScanBlock / 256; k++) {
+    const int i = blockIdx.x * kScanBlock + k * 256 + threadIdx.x;
+    if (i < N) {
+      const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
+      v += pairs_of(*reinterpret_cast<const BinRec *>(&raw), tile_mask[i]);
+    }
   }
-  float4 *dst = reinterpret_cast<float4 *>(acc + (size_t)i * kAccStride);
-  dst[0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
-  dst[1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
-  dst[2] = make_float4(sum[8], sum[9], 0.0f, 0.0f);
+  v = block_sum_u32(v, s_red);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = v;
+}
+__global__ void __launch_bounds__(256)
+pair_base_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__restrict__ tile_mask,
+                 const uint32_t *__restrict__ block_sums, uint32_t *__restrict__ pair_base) {
+  __shared__ uint32_t s_red[4], s_wave[4];
+  // the pairs of the workgroups before this one (at most ~1000 words for a million Gaussians: every workgroup adds them itself)
+  uint32_t before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += block_sums[b];
+  uint32_t run = block_sum_u32(before, s_red);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = 0; k < kScanBlock / 256; k++) {
+    const int i = blockIdx.x * kScanBlock + k * 256 + threadIdx.x;
+    uint32_t c = 0;
+    if (i < N) {
+      const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
+      c = pairs_of(*reinterpret_cast<const BinRec *>(&raw), tile_mask[i]);
+    }
+    uint32_t inc = c;   // inclusive prefix inside the wave
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wv; w++) wbase += s_wave[w];
+    if (i < N) pair_base[i] = run + wbase + inc - c;
+    run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) pair_base[N] = run;
+}
+
+__global__ void __launch_bounds__(256)
+reduce_pair_rows_kernel(int N, const uint32_t *__restrict__ pair_base, uint32_t capacity, const uint8_t *__restrict__ row_flags,
+                        const float *__restrict__ partial, float *__restrict__ acc) {
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), col = threadIdx.x & 15;
+  if (i >= N) return;
+  const uint32_t r0 = min(pair_base[i], capacity) * 4u, r1 = min(pair_base[i + 1], capacity) * 4u;
+  float sum = 0.0f;
+  for (uint32_t r = r0; r < r1; r += 4) {   // one (Gaussian, tile) pair: its four blocks in order
+    const uint32_t f = *reinterpret_cast<const uint32_t *>(row_flags + r);
+    if (f == 0) continue;
+    const float *row = partial + (size_t)r * kAccStride + col;
+    if (f & 0x000000FFu) sum += row[0];
+    if (f & 0x0000FF00u) sum += row[kAccStride];
+    if (f & 0x00FF0000u) sum += row[2 * kAccStride];
+    if (f & 0xFF000000u) sum += row[3 * kAccStride];
+  }
+  acc[(size_t)i * kAccStride + col] = col < 10 ? sum : 0.0f;
 }
 
 }  // namespace
@@ -559,14 +612,27 @@ reduce_partials_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__
 
 using namespace scorp;
 
-extern "C" size_t scorp_gs3d_backward_scratch_bytes_ex(int32_t N, int32_t W, int32_t H, uint64_t capacity, uint32_t flags) {
-  size_t bytes = align_up((size_t)(N > 0 ? N : 1) * kAccStride * sizeof(float), 256);
-  if (flags & SCORP_BACKWARD_DETERMINISTIC) {
-    const StateLayout L(N, W, H);
-    bytes += align_up((size_t)L.tiles * 4 * sizeof(uint32_t), 256);
-    bytes += align_up((size_t)(capacity > 0 ? capacity : 1) * 4 * kAccStride * sizeof(float), 256);
+// deterministic scratch: [accumulator rows][pair_base N + 1][block sums of the scan][one flag byte per row][4 x capacity rows]
+struct DetLayout {
+  size_t acc, pair_base, block_sums, flags, partial, total;
+  int scan_blocks;
+  DetLayout(int N, uint64_t capacity) {
+    const size_t n = N > 0 ? (size_t)N : 1, c = capacity > 0 ? (size_t)capacity : 1;
+    scan_blocks = (int)((n + kScanBlock - 1) / kScanBlock);
+    size_t off = 0;
+    acc = off; off = align_up(off + n * kAccStride * sizeof(float), 256);
+    pair_base = off; off = align_up(off + (n + 1) * sizeof(uint32_t), 256);
+    block_sums = off; off = align_up(off + (size_t)scan_blocks * sizeof(uint32_t), 256);
+    flags = off; off = align_up(off + c * 4, 256);
+    partial = off; off = align_up(off + c * 4 * kAccStride * sizeof(float), 256);
+    total = off;
   }
-  return bytes;
+};
+
+extern "C" size_t scorp_gs3d_backward_scratch_bytes_ex(int32_t N, int32_t W, int32_t H, uint64_t capacity, uint32_t flags) {
+  (void)W; (void)H;
+  if (flags & SCORP_BACKWARD_DETERMINISTIC) return DetLayout(N, capacity).total;
+  return align_up((size_t)(N > 0 ? N : 1) * kAccStride * sizeof(float), 256);
 }
 
 extern "C" size_t scorp_gs3d_backward_scratch_bytes(int32_t N) {
@@ -606,12 +672,20 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
   }
   const char *base = (const char *)state, *pb = (const char *)pairs;
   float *acc = (float *)scratch;
-  uint32_t *block_todo = nullptr;
   float *partial = nullptr;
-  if (det) {   // [accumulator rows][one word per block][4 x capacity partial rows]
-    char *p = (char *)scratch + align_up((size_t)N * kAccStride * sizeof(float), 256);
-    block_todo = (uint32_t *)p;
-    partial = (float *)(p + align_up((size_t)L.tiles * 4 * sizeof(uint32_t), 256));
+  uint8_t *row_flags = nullptr;
+  uint32_t *pair_base = nullptr;
+  const DetLayout DL(N, capacity);
+  if (det) {
+    char *p = (char *)scratch;
+    partial = (float *)(p + DL.partial);
+    row_flags = (uint8_t *)(p + DL.flags);
+    pair_base = (uint32_t *)(p + DL.pair_base);
+    uint32_t *block_sums = (uint32_t *)(p + DL.block_sums);
+    SCORP_HIP_CHECK(hipMemsetAsync(row_flags, 0, (size_t)(capacity > 0 ? capacity : 1) * 4, stream));
+    pair_count_kernel<<<DL.scan_blocks, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), block_sums);
+    pair_base_kernel<<<DL.scan_blocks, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), block_sums, pair_base);
+    SCORP_KERNEL_CHECK("pair_base", in->debug, stream);
   } else if (!(flags & SCORP_BACKWARD_SCRATCH_ZEROED)) {
     SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAccStride * sizeof(float), stream));
   }
@@ -631,14 +705,13 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
     wk<<<blocks, 64, 0, stream>>>(
         (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.hits), (const SplatRec *)(base + L.rec),
         (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),
-        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc, partial, block_todo);
+        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_ddepth, dL_dalpha, acc, partial, row_flags, pair_base,
+        (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask));
   }
   SCORP_KERNEL_CHECK("blend_backward", in->debug, stream);
   if (det) {
-    reduce_partials_kernel<<<(N + 255) / 256, 256, 0, stream>>>(
-        N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), (const uint32_t *)(base + L.tile_start),
-        (const uint32_t *)(pb + P.hits), (uint32_t)capacity, L.tiles_x, block_todo, partial, acc);
-    SCORP_KERNEL_CHECK("reduce_partials", in->debug, stream);
+    reduce_pair_rows_kernel<<<(N + 15) / 16, 256, 0, stream>>>(N, pair_base, (uint32_t)capacity, row_flags, partial, acc);
+    SCORP_KERNEL_CHECK("reduce_pair_rows", in->debug, stream);
   }
   {
     ProfScope prof(kKPreprocessBackward, stream);

@@ -32,18 +32,20 @@ __device__ __forceinline__ float body(float T, float e, float c, float &C0, floa
 template <int WAVES>   // waves per workgroup: 1 (today) or 4 (tile-level)
 __global__ void __launch_bounds__(64 * WAVES, 2) k_blend(const int *__restrict__ hits, int tiles, int barriers_per_chunk, float *out) {
   __shared__ float lds[kLdsPerWave * WAVES];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // (wave-uniform values are forced into SGPRs: left in VGPRs, the loop counter and the LDS addresses of the four-wave
+  // form cost 1.6x the VALU instructions of the one-wave form - the first version of this file measured exactly that)
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int tile, quad;
   if (WAVES == 4) { const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3; tile = kk * 8 + xcd; quad = wv; }
   else { const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3; tile = (kk >> 2) * 8 + xcd; quad = kk & 3; }
   if (tile >= tiles) return;
   float *my = lds + wv * kLdsPerWave;
   for (int i = lane; i < 96 * 4; i += 64) my[i] = (float)(i & 15) * -0.37f;
-  const int h = hits[tile * 4 + quad];
+  const int h = __builtin_amdgcn_readfirstlane(hits[tile * 4 + quad]);
   int n_chunks = 1;
   if (WAVES == 4) {
     const int total = hits[tile * 4] + hits[tile * 4 + 1] + hits[tile * 4 + 2] + hits[tile * 4 + 3];
-    n_chunks = max(1, ((int)(total / 1.85f) + 255) / 256);
+    n_chunks = __builtin_amdgcn_readfirstlane(max(1, ((int)(total / 1.85f) + 255) / 256));
     __syncthreads();
   }
   float T = 1.0f, C0 = 0, C1 = 0, C2 = 0, D = 0;
