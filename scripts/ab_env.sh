@@ -10,12 +10,12 @@ for spec in "$@"; do
   (
     if [ "$lib" != default ]; then export SCORP_GS_LIB=$PWD/$lib; fi
     for e in "${envs[@]}"; do export "$e"; done
-    python3 bench.py --no-cpu-baseline --steps ${STEPS:-40} --warmup 10 ${BENCH_ARGS} > $out/tmp.json 2> $out/tmp.err || { echo "$spec FAILED" >> $out/ab.txt; tail -3 $out/tmp.err >> $out/ab.txt; exit 0; }
+    python3 bench.py --no-cpu-baseline --no-secondary --steps ${STEPS:-40} --warmup 10 ${BENCH_ARGS} > $out/tmp.json 2> $out/tmp.err || { echo "$spec FAILED" >> $out/ab.txt; tail -3 $out/tmp.err >> $out/ab.txt; exit 0; }
     python3 - "$spec" $out/tmp.json >> $out/ab.txt << 'PY'
 import json, sys
 d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
-k = d["kernels"]
-print(f"{sys.argv[1]:56s} views/s {d['value']:8.1f}  " + "  ".join(f"{n.replace('blend_','b').replace('preprocess','pp').replace('ssim_l1_','loss_')}={v['avg_us']:.1f}" for n, v in k.items()))
+k = d["kernels_us_GBs"]
+print(f"{sys.argv[1]:56s} views/s {d['value']:8.1f}  " + "  ".join(f"{n.replace('blend_','b').replace('preprocess','pp').replace('ssim_l1_','loss_')}={v[0]:.1f}" for n, v in k.items()))
 PY
   )
 done
