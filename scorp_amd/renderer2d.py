@@ -170,6 +170,26 @@ class GaussianModel2D(GaussianModel):
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter], dim=-1, keepdim=True)
         self.denom[update_filter] += 1
 
+    # ---- the "tuning mask" of gs2dgs/scene/gaussian_model.py:60,210-222,498-508: the surfels present when
+    # prepare_gs_tuning_mask() was called (the first `num_mask` rows: later ones are appended by densification) are held
+    # fixed - their gradients are zeroed before the optimizer step and reset_opacity() leaves their opacity alone.  No
+    # script of the reference calls these; they are here so that a caller that does finds them.
+    _num_mask = 0
+
+    def prepare_gs_tuning_mask(self):
+        self._num_mask = len(self._xyz)
+
+    def gs_tuning_mask_grad(self):
+        if self._xyz.grad is not None:
+            for p in (self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity):
+                if p.grad is not None:
+                    p.grad[: self._num_mask] *= 0.0
+
+    def reset_opacity(self):
+        op = self.get_opacity
+        capped = torch.min(op[self._num_mask:], torch.ones_like(op[self._num_mask:]) * 0.01)
+        self.replace_tensor_to_optimizer(inverse_sigmoid(torch.cat([op[: self._num_mask], capped])), "opacity")
+
 
 class RenderPackage(dict):
     """The dict render() returns (the reference's nine keys) that also remembers the rasterizer's allmap and the camera,

@@ -160,7 +160,9 @@ def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, backgr
     rank, w = world() if data_parallel else (0, 1)
     rng = random.Random(seed)            # same seed on every rank: identical camera order
     stack, losses = [], []
-    for it in range(1, (iterations or opt.iterations) + 1):
+    first_checked, retries = False, 0
+    it = 1
+    while it <= (iterations or opt.iterations):
         ks = []
         for _ in range(w):
             if not stack:
@@ -170,29 +172,48 @@ def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, backgr
         k = ks[rank]
         loss, _ = training_iteration(gaussians, cameras[k], gt_images[k], opt, pipe, background, it,
                                      data_parallel=data_parallel and collective(), **kw)
+        if kw.get("fused_view") and not first_checked:
+            # The FIRST fused view of a run sizes the reservation: verified at once (one host synchronisation per run).
+            # If it overflowed it was discarded on the device and the reservation has grown: the same views run again,
+            # instead of a context's default being wrong for every iteration up to the first periodic drain.
+            retries += 1
+            first_checked = _drain_reservation(quiet=retries < 3) or data_parallel or retries >= 3   # (data-parallel replicas must not diverge in their camera order)
+            if not first_checked:
+                stack.extend(reversed(ks))
+                continue
         losses.append(loss.detach())
         if kw.get("fused_view") and it % 32 == 0:
             _drain_reservation()
+        it += 1
     if kw.get("fused_view"):
         _drain_reservation()
     return [float(l) for l in losses]
 
 
-def _drain_reservation():
+def _drain_reservation(quiet=False):
     """Fused views reserve their pair buffer instead of asking for the count.  A view that overflowed its reservation was
     blended from truncated tile lists (nothing is written out of bounds) and was DISCARDED on the device: its optimizer
     step was skipped and it did not enter the densification statistics (training_iteration).  drain() has grown the
-    reservation; training goes on, the user is told how that happened."""
+    reservation; training goes on, the user is told how that happened.  Returns False if a view had overflowed."""
     try:
         PairPolicy.drain()
+        return True
     except RuntimeError as e:
-        import warnings
-        warnings.warn(f"train(fused_view=True): {e}; the overflowed views were skipped (no optimizer step, no statistics)")
+        if not quiet:
+            import warnings
+            warnings.warn(f"train(fused_view=True): {e}; the overflowed views were skipped (no optimizer step, no statistics)")
+        return False
 
 
-def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, pipe=None, background=None, seed=0):
+def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, pipe=None, background=None, seed=0,
+                fused_view=None):
     """post_refine_gs.py: colours only (`_opacity/_rotation/_scaling/_xyz` frozen, :53-56), SH degree 0 (:47),
-    loss on image*mask vs gt*mask (:103-111).  Returns per-iteration losses."""
+    loss on image*mask vs gt*mask (:103-111).  Returns per-iteration losses.
+
+    `fused_view` (default: whenever the model lives on the GPU with raw leaves and the pipe has fused activations): an
+    iteration is ONE library call - the masked one-call view (train_view.train_view(mask=...): render + masked L1 / SSIM
+    + the colour-only replay of the backward) followed by the guarded FusedAdam step - instead of render() + fused loss
+    + autograd: the same kernels, ~10 % less host and launch time per iteration (DESIGN.md section 5, config #4)."""
     assert gaussians.max_sh_degree == 0, "post-refinement runs on SH-0 objects (post_refine_gs.py:47)"
     pipe = pipe or PipelineParams()
     dev = gaussians.get_xyz.device
@@ -201,20 +222,43 @@ def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, p
         gaussians.training_setup(opt)
     for name in ("_opacity", "_rotation", "_scaling", "_xyz"):
         gaussians.set_freeze(name, True)
+    if fused_view is None:
+        fused_view = dev.type == "cuda" and hasattr(gaussians, "raw_leaves") and getattr(pipe, "fused_activations", False)
     rng = random.Random(seed)
     stack, losses = [], []
-    for it in range(1, iterations + 1):
+    sized, retries, it = False, 0, 1
+    while it <= iterations:
         if not stack:
             stack = list(range(len(cameras)))
             rng.shuffle(stack)
         k = stack.pop()
-        pkg = render(cameras[k], gaussians, pipe, background)
-        loss = fused_l1_ssim_loss(pkg["render"], gt_images[k], opt.lambda_dssim, mask=gt_alphas[k])
-        loss.backward()
+        if fused_view:
+            from .train_view import train_view
+            pkg = train_view(cameras[k], gaussians, pipe, background, gt_images[k], opt.lambda_dssim, mask=gt_alphas[k])
+            loss = pkg["loss"]
+            if hasattr(gaussians.optimizer, "skip_flag"):      # a view that overflowed its pair reservation moves nothing
+                gaussians.optimizer.skip_flag = pkg["overflow"]
+        else:
+            pkg = render(cameras[k], gaussians, pipe, background)
+            loss = fused_l1_ssim_loss(pkg["render"], gt_images[k], opt.lambda_dssim, mask=gt_alphas[k])
+            loss.backward()
         with torch.no_grad():
             gaussians.optimizer.step()
             gaussians.optimizer.zero_grad(set_to_none=True)
+        if fused_view and not sized:
+            # the first one-call view sizes the pair reservation (see train()): checked at once, run again if it overflowed
+            # (objects that fill the screen need more than the default four pairs per Gaussian)
+            retries += 1
+            sized = _drain_reservation(quiet=retries < 3) or retries >= 3
+            if not sized:
+                stack.append(k)
+                continue
         losses.append(loss.detach())
+        if fused_view and it % 32 == 0:
+            _drain_reservation()
+        it += 1
+    if fused_view:
+        _drain_reservation()
     return [float(l) for l in losses]
 
 

@@ -71,3 +71,32 @@ def test_oracle2d_f32_and_edges():
     assert o.num_pairs == 0 and (o.radii == 0).all() and (o.allmap == 0).all()
     g = o.backward(np.ones((3, 96, 128), np.float32), np.ones((7, 96, 128), np.float32))
     assert all(np.all(v == 0) for v in g.values() if v is not None)
+
+
+def test_surfel_model_tuning_mask():
+    """gs2dgs/scene/gaussian_model.py:60,210-222,498-508: the surfels present at prepare_gs_tuning_mask() are held fixed -
+    gs_tuning_mask_grad() zeroes their gradients on all six leaves, reset_opacity() caps only the later rows at 0.01."""
+    import torch
+    from scorp_amd.gaussian_model import OptimizationParams
+    from scorp_amd.renderer2d import GaussianModel2D
+    from scorp_amd.synthetic import make_gaussians
+    m = GaussianModel2D.from_raw(make_gaussians(50, 1, 3, scale_dims=2), 1, device="cpu")
+    m.training_setup(OptimizationParams())
+    leaves = lambda: (m._xyz, m._features_dc, m._features_rest, m._scaling, m._rotation, m._opacity)
+    for p in leaves():
+        p.grad = torch.ones_like(p)
+    m.gs_tuning_mask_grad()                                  # no mask yet: nothing is held
+    assert all(float(p.grad.abs().min()) == 1.0 for p in leaves())
+    m.prepare_gs_tuning_mask()
+    m.densification_postfix(*[t[:5].detach().clone() for t in (m._xyz, m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation)])
+    assert m._xyz.shape[0] == 55
+    for p in leaves():
+        p.grad = torch.ones_like(p)
+    m.gs_tuning_mask_grad()
+    for p in leaves():
+        assert float(p.grad[:50].abs().sum()) == 0.0 and float(p.grad[50:].abs().min()) == 1.0
+    before = m.get_opacity.detach().clone()
+    m.reset_opacity()
+    after = m.get_opacity.detach()
+    assert torch.allclose(before[:50], after[:50], atol=1e-6) and float(after[50:].max()) <= 0.01 + 1e-6
+    assert float(before[:50].max()) > 0.5                    # (the held rows really were above the cap)
