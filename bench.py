@@ -419,6 +419,7 @@ def main():
     ap.add_argument("--spatial-sort", action="store_true", help="GaussianModel.sort_spatially() first: Gaussians stored along a Z-order curve (not the default)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary record (the 2DGS workload S6) of the default N=1 run")
     ap.add_argument("--lead-in", type=int, default=40, help="untimed views enqueued in front of the warm-up of every timed run (see timed_run)")
+    ap.add_argument("--no-twins", action="store_true", help="skip the two extra timed runs (all-fp32 backward, deterministic backward): profiling passes")
     ap.add_argument("--exact-backward", action="store_true", help="all-fp32 MFMA reduction in the blend backward (scorp_gs3d_backward_ex) instead of the fp16 two-term split")
     args = ap.parse_args()
 
@@ -591,7 +592,7 @@ def main():
     # the same step with the blend backward's pixel->splat reduction on fp32 MFMAs throughout (SCORP_BACKWARD_EXACT_FP32),
     # same protocol: the headline next to its all-fp32 twin
     dt_exact = dt_det = None
-    if fused_view and side_streams is None and not args.exact_backward:
+    if fused_view and side_streams is None and not args.exact_backward and not args.no_twins:
         prev_flags = getattr(R._tls, "backward_flags", 0)
         R._tls.backward_flags = _C.BACKWARD_EXACT_FP32
         try:

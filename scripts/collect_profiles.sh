@@ -10,13 +10,13 @@ mkdir -p $out
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 for sc in S3 S6; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$sc -- python3 bench.py --scene $sc --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $out/stats_$sc.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$sc -- python3 bench.py --scene $sc --steps 30 --warmup 5 --no-twins --cams 8 --no-cpu-baseline --no-secondary > $out/stats_$sc.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${sc}_$c -- python3 bench.py --scene $sc --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $out/pmc_${sc}_$c.log 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${sc}_$c -- python3 bench.py --scene $sc --steps 3 --warmup 1 --lead-in 2 --no-twins --cams 8 --no-cpu-baseline --no-kernel-events --no-secondary > $out/pmc_${sc}_$c.log 2>&1
   done
 done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $out/sq1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $out/sq1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS --kernel-trace --output-format csv -d $out/sq2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary > $out/sq2.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --kernel-trace --output-format csv -d $out/sq1 -- python3 bench.py --steps 3 --warmup 1 --lead-in 2 --no-twins --cams 8 --no-cpu-baseline --no-kernel-events --no-secondary > $out/sq1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS --kernel-trace --output-format csv -d $out/sq2 -- python3 bench.py --steps 3 --warmup 1 --lead-in 2 --no-twins --cams 8 --no-cpu-baseline --no-kernel-events --no-secondary > $out/sq2.log 2>&1
 # summaries (small files; the raw counter CSVs stay under gpurun_out/)
 f() { find $out/$1 -name '*counter_collection.csv' | head -1; }
 python3 scripts/make_traffic.py S3 "$(f pmc_S3_FETCH_SIZE)" "$(f pmc_S3_WRITE_SIZE)" S6 "$(f pmc_S6_FETCH_SIZE)" "$(f pmc_S6_WRITE_SIZE)" > $out/traffic_summary.json

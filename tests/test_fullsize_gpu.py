@@ -147,7 +147,7 @@ def test_full_size_parity_vs_oracle_2d(cam, dev, parallel_oracle):
         print("  elements beyond the max-norm tolerance after the band: " + ", ".join(f"{n} {c}" for n, c in BAND_TALLY.get("beyond", [])[-6:]))
 
 
-_S6_TIE_OUTLIERS = 64
+_S6_TIE_OUTLIERS = 17      # measured on S6 view 0: 13 elements (scales), 2 (means2D), 2 (rotations) beyond the band; + 4
 
 
 def test_config1_S1_parity(dev):
