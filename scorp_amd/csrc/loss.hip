@@ -70,8 +70,13 @@ __device__ __forceinline__ LossTile loss_tile(int gx, int gy, int C) {
 // separated by barriers as in the backward below, spent most of a workgroup's life waiting and needed 36 KB of LDS:
 // 54 us against 49.)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kStripIters = 4;                          // unrolled-by-11 groups of rows per strip
-constexpr int kStripRows = 11 * kStripIters - 10;       // output rows per strip (34)
+#ifndef SCORP_LOSS_STRIP_ITERS
+#define SCORP_LOSS_STRIP_ITERS 3
+#endif
+constexpr int kStripIters = SCORP_LOSS_STRIP_ITERS;     // unrolled-by-11 groups of rows per strip
+constexpr int kStripRows = 11 * kStripIters - 10;       // output rows per strip: 23 (3 975 waves = 3.9 per SIMD; rocprof, same box:
+                                                        // 2 iterations 50.6 us, 3: 42.0, 4: 44.5, 5: 45.8, 6: 53.1 - the kernel
+                                                        // is short of waves, not of arithmetic)
 constexpr int kRowBuf = 80;                             // floats per row-buffer array (74 used)
 
 struct StripJob { int ch, cx0, ry0; bool valid; };
