@@ -25,7 +25,7 @@ def run(args, dev, cdev, rank, world):
     cams = ring_cameras(16, args.width, args.height, 2, device=dev)
     gts = render_views_gt(teacher, cams)
     out = {}
-    for sparse in (False, True):
+    for sparse in ((True, False) if os.environ.get("SCORP_DP_SPARSE_FIRST") else (False, True)):
         m = GaussianModel.from_raw(raw, 3, device=dev)
         m.active_sh_degree = 3
         m._features_dc.data.add_(0.2)
