@@ -540,6 +540,9 @@ def main():
     # table and tell which kernel dominates
     kern_all, dominant = {}, None
     if not args.no_kernel_events:
+        for i in range(3):       # first launches of the step's kernels (code objects, scratch): not in the per-kernel table
+            step(i)
+        PairPolicy.drain()
         _C.prof_enable(True)
         for i in range(max(3, min(args.warmup, 8))):
             step(i)

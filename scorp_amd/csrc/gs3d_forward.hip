@@ -671,14 +671,16 @@ sort_tiles_long_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__rest
 #define SCORP_FWD_FMA 1
 #endif
 #ifndef SCORP_FWD_RING
-#define SCORP_FWD_RING 96
+#define SCORP_FWD_RING 80
 #endif
 constexpr int kFRing = SCORP_FWD_RING, kFChunk = 64, kFGroup = 16;   // ring: at most 15 left-over hits + 64 new ones
 
-// (__launch_bounds__(64, 2): at least two waves per SIMD, i.e. at most 256 registers - which is what lets the compiler keep
-// the MFMA results in VGPRs; with the accumulators in AGPRs every exponent costs a v_accvgpr_read before its v_exp)
+// __launch_bounds__(64, 6): six waves per SIMD = at most 80 registers.  The kernel needs 84 - 86 left to itself since it
+// compacts the hit list (round 4); held to 80 it spills ONE register outside the per-hit loop and keeps its sixth wave
+// (same box, rocprof: 157.4 us at five waves per SIMD, 153.4 at six; 148.7 before the compaction, which takes 22 us off
+// the backward).  The MFMA results stay in VGPRs either way (no accumulator-register reads in front of the v_exp).
 #ifndef SCORP_FWD_WAVES
-#define SCORP_FWD_WAVES 2
+#define SCORP_FWD_WAVES 6
 #endif
 #ifdef SCORP_FWD_TRACE
 // diagnostic build only (scripts/dev/trace_forward.py): per wave (start, end) on the 100 MHz real-time counter and the
@@ -700,6 +702,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
                           float4 *__restrict__ zero_buf, uint32_t zero_per_wave, uint32_t zero_total, int band_h) {
   __shared__ uint4 q_k[3][kFRing + 1];   // the three bf16 terms of a hit's six coefficients; slot kFRing stays zero
   __shared__ float4 q_col[kFRing];       // r, g, b, depth
+  __shared__ uint32_t q_id[kFRing];      // the hit's splat: written to the block's hit list only if some pixel took it (blend_group)
   const int lane = threadIdx.x;
 #ifdef SCORP_FWD_TRACE
   struct TraceEnd {
@@ -742,7 +745,8 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   int head = 0, count = 0;   // head stays a multiple of kFGroup (only a wave's final group is partial), so the
                              // slots of a group are head + i without wrap-around: one LDS base, immediate offsets
   uint32_t nh = 0;           // hits found so far (wave-uniform)
-  uint32_t consumed = 0;     // hits blended so far: slot i of the next group is hit number consumed + i + 1 of the list
+  uint32_t consumed = 0;     // hits blended so far ((block, splat) iterations: the P statistic)
+  uint32_t kept_n = 0;       // ... of which some pixel took: the length of the hit list left for the backward (wave-uniform)
   uint32_t hot_end = 0;      // hits [0, hot_end) may hold a splat with opacity > 0.99 (wave-uniform; see blend_group)
 #ifdef SCORP_FWD_STATS
   uint32_t st_hits = 0, st_live = 0, st_any = 0, st_q[4] = {0, 0, 0, 0}, st_h[2] = {0, 0}, st_lane = 0, st_pairs = 0;
@@ -780,7 +784,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       k0.w = guard_limit_pack(c.w);   // (spare K slots: exp_mfma.hpp)
       q_k[0][qi] = k0; q_k[1][qi] = k1; q_k[2][qi] = k2;
       q_col[qi] = make_float4(b.z, b.w, c.x, c.y);
-      if constexpr (kForBackward) my_hits[rank] = id0;   // (rank < n: inside this tile's slice of the region)
+      if constexpr (kForBackward) q_id[qi] = id0;
     }
     count += __builtin_popcountll(m);
     nh += (uint32_t)__builtin_popcountll(m);
@@ -810,6 +814,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       const uint4 *gk = q_k[0] + hv;
       bool all_done = false;
       uint32_t lastg = 0;   // 1-based slot of the group's last contributor to this pixel (inline constants, no SGPR moves)
+      uint32_t kept16 = 0;  // wave-uniform: bit i = slot i was taken by at least one pixel of the block
 #pragma unroll
       for (int i = 0; i < kFGroup; i++) {
         if (kFull || i < nslots) {  // wave-uniform
@@ -836,7 +841,13 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
           C0 += col.x * w; C1 += col.y * w; C2 += col.z * w;
           Dp += col.w * w;
           T = ok ? test_T : -fabsf(T);
-          if constexpr (kForBackward) lastg = (ok & live) ? (uint32_t)(i + 1) : lastg;
+          if constexpr (kForBackward) {
+            const bool took = ok & live;
+            lastg = took ? (uint32_t)(i + 1) : lastg;
+            // (each ballot of a plain compare IS that compare's lane mask, and the AND of two 64-bit scalars is scalar work; the
+            // ballot of `took` itself - an AND of two conditions - goes through a VGPR 0 / 1 and a second v_cmp: +2 VALU per hit)
+            kept16 |= ((__builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(live)) != 0ull ? 1u : 0u) << i;
+          }
 #ifdef SCORP_FWD_STATS
           {
             const uint64_t m = __ballot(ok & live);
@@ -853,7 +864,19 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
 #endif
         }
       }
-      if constexpr (kForBackward) last = lastg ? consumed + lastg : last;
+      if constexpr (kForBackward) {
+        // The block's HIT LIST keeps only the hits some pixel took.  A hit passes the exact block test when the conic's
+        // minimum over the 8x8 box is below the cutoff - a minimum that may lie between pixel centres, or behind pixels that
+        // are already saturated: 6.6 % of the hits of an S3 view have no taker (scripts/dev/stats_forward.py), and the
+        // backward, which replays the list, would run its whole per-hit pipeline (and an atomic row of zeros' worth of
+        // bookkeeping) for each.  Positions are those of the compacted list: kept hits before this group + rank in it.
+        if (lastg) last = kept_n + (uint32_t)__builtin_popcount(kept16 & ((1u << lastg) - 1u));
+        if (lane < nslots && ((kept16 >> lane) & 1u))   // (v_mbcnt: the kept slots below this lane's, no lane mask held in a register)
+          my_hits[kept_n + __builtin_amdgcn_mbcnt_lo(kept16, 0u)] = q_id[hv + lane];
+        kept_n += (uint32_t)__builtin_popcount(kept16);
+        __builtin_amdgcn_sched_barrier(0);   // (keeps this tail out of the next group's exponent MFMAs: their sixteen results and
+                                             // the tail's temporaries together cost the sixth wave per SIMD)
+      }
       head = head + kFGroup == kFRing ? 0 : head + kFGroup;
       count -= nslots;
       consumed += (uint32_t)nslots;
