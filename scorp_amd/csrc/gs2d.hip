@@ -472,55 +472,62 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   }
 }
 
-// Twenty wave-wide sums as one butterfly: each level halves the number of live values by pairing them (the lane
-// keeps one of the pair and receives the partner's copy of it), so the whole reduction costs ~42 instructions instead
-// of 20 x 6.  Levels 32 and 16 are v_permlane{32,16}_swap + add; in-row levels 8 and 4 are two DPP adds (the partner
-// lanes are whole banks, so bank_mask picks which value a lane keeps), levels 2 and 1 a select pair + a DPP add.
-// reduce20_slot() gives each lane the index of the value whose total it ends up holding (or -1).
-__device__ __forceinline__ float fold32(float a, float b) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+// ---------------------------------------------------------------------------------------------------------
+// The pixel -> surfel reduction of the 2-D backward on the matrix cores (round 4; it was a twenty-value butterfly of
+// v_permlane32 / 16_swap + DPP adds: 15 swaps at 8.4 issue cycles + 27 adds per hit, 44 % of the kernel).
+//
+// The twenty sums of a hit factor, like the ten of the 3-D kernel, into a handful of per-pixel VALUES times per-pixel
+// BASES that do not depend on the hit:
+//     dp0, dp1, dp2  x {x, y, 1}                (nine sums: d/d pa, pb, pc; x, y = the pixel about the block centre - the offset to
+//                                                the surfel's accumulation point is a per-hit constant applied afterwards)
+//     zr, z2, t x {1};   t2 x {x, y, 1}         (depth, low-pass depth, opacity; the low-pass centre gradient)
+//     w x {dL/dn (3), dL/drgb (3)}              (normal and colour)
+// Eight values per (hit, pixel).  Each leaves the lane as TWO fp16 terms (x = h1 + h2, h1 = rtz16(x), h2 = rtz16(x - h1):
+// 22 bits, exact products, fp32 accumulation), both in ONE dword, so a hit costs eight ds_write_b32; rows of the matrix
+// are (hit of the pair, kind), its K dimension (pixel, term); B holds each basis value twice (once per term: the MFMA
+// adds the two terms by itself) - columns 0 = 1, 1 = x, 2 = y, 3..8 = the first fp16 term of the six upstream gradients,
+// 9..14 = their remainder.  Two hits per pass, four v_mfma_f32_16x16x32_f16 per pass.
+// Range: the upstream gradients are pre-scaled by a power of two chosen per wave from the block's largest |dL/dpixel|
+// (everything the recurrence produces is linear in them, so t, dL/dz come out scaled, exactly); the blend weight is
+// carried as w * 2^10; and the four values that contain 1 / p.z (p.z ~ surfel extent^2 in pixels: anything from 1e-3 to
+// 1e3) are scaled per hit by the power of two below |p.z| at the block centre.  The conversion saturates (round toward
+// zero) instead of overflowing.  The sums are unscaled by exact powers of two when they are read out.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4_2d __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_2d __attribute__((ext_vector_type(8)));
+union Frag2 { f16x8_2d v; uint4 q; uint32_t d[4]; };
+constexpr int k2XStride = 68;                // dwords per row of the [16][64] value matrix (16-byte aligned rows, conflict-free row writes)
+constexpr int k2DStride = 17;                // floats per row of the 16 x 16 result tile (odd: the read-out lanes hit distinct banks)
+constexpr int k2TargetExp = 2;               // the block's largest |upstream gradient| is scaled into [2^2, 2^3): the values carry
+                                             // factors of depth (<= 100), 1 / p.z scaled to <= 4 and the cutoff radius 3 on top
+constexpr float k2WScale = 1024.0f;
+__device__ __forceinline__ uint32_t pack_rtz16_2d(float lo, float hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+__device__ __forceinline__ float half_lo_2d(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p & 0xFFFFu)); }
+__device__ __forceinline__ float half_hi_2d(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p >> 16)); }
+// (a, b) -> da = (h1(a) | h2(a) << 16), db = (h1(b) | h2(b) << 16)
+__device__ __forceinline__ void split_two(float a, float b, uint32_t &da, uint32_t &db) {
+  const uint32_t p1 = pack_rtz16_2d(a, b);
+  const uint32_t p2 = pack_rtz16_2d(__builtin_fmaf(half_lo_2d(p1), -1.0f, a), __builtin_fmaf(half_hi_2d(p1), -1.0f, b));
+  da = __builtin_amdgcn_perm(p2, p1, 0x05040100u);
+  db = __builtin_amdgcn_perm(p2, p1, 0x07060302u);
 }
-__device__ __forceinline__ float fold16(float a, float b) {
-  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-template <int CTRL>
-__device__ __forceinline__ float fold_row(float a, float b, bool upper) {
-  const float keep = upper ? b : a, send = upper ? a : b;
-  return keep + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(send), CTRL, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float fold8_banked(float a, float b) {   // lanes 0-7 of a row: a[l] + a[l^8]; lanes 8-15: b
-  float t = dpp_add<0x128>(a);
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(t) : "v"(b));
-  return t;
-}
-__device__ __forceinline__ float fold4_banked(float a, float b) {   // lanes with bit 2 clear: a[l] + a[7-l]; set: b
-  float t = dpp_add<0x141>(a);
-  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(t) : "v"(b));
-  return t;
-}
-__device__ __forceinline__ int reduce20_slot(int lane) {
-  const int h = lane >> 5, r = (lane >> 4) & 1, b8 = (lane >> 3) & 1, b4 = (lane >> 2) & 1, b2 = (lane >> 1) & 1, b1 = lane & 1;
-  if (b1) return -1;
-  if (!b2) return 8 * b4 + 4 * b8 + 2 * r + h;
-  return (b8 == 0 && b4 == 0) ? 16 + 2 * r + h : -1;
-}
-__device__ __forceinline__ float reduce20(const float *g, int lane) {
-  float w[10], x[5], y[3];
-#pragma unroll
-  for (int j = 0; j < 10; j++) w[j] = fold32(g[2 * j], g[2 * j + 1]);
-#pragma unroll
-  for (int j = 0; j < 5; j++) x[j] = fold16(w[2 * j], w[2 * j + 1]);
-  y[0] = fold8_banked(x[0], x[1]);
-  y[1] = fold8_banked(x[2], x[3]);
-  y[2] = dpp_add<0x128>(x[4]);
-  // in-row partners must stay inside the lane group that holds the same value: xor 8 = row_ror:8, then
-  // row_half_mirror (l <-> 7 - l), then quad_perm [2,3,0,1] and [1,0,3,2]
-  const float z0 = fold4_banked(y[0], y[1]);
-  const float z1 = dpp_add<0x141>(y[2]);
-  const float u = fold_row<0x4E>(z0, z1, (lane & 2) != 0);
-  return dpp_add<0xB1>(u);
+// What lane `o` (0..19 of either half of the wave) reads out of the result tile: out = alpha * D[row][c1] + beta * D[row][c2],
+// beta one of {0, 1, ox, oy, kF * offx, kF * offy} by `bsel`; `cls`: which unscaling applies (0: 1 / (sv Sh), 1: 1 / sv, 2: 1 / (sv 2^10))
+struct ReadOut { int row, c1, c2, bsel, cls; float alpha; };
+__device__ __forceinline__ ReadOut read_out_of(int o) {
+  ReadOut r;
+  r.row = 0; r.c1 = 0; r.c2 = 0; r.bsel = 0; r.cls = 1; r.alpha = 1.0f;
+  if (o < 3) { r.row = o; r.c1 = 1; r.bsel = 2; r.cls = 0; }                       // d/d pa = sum dp (x + ox)
+  else if (o < 6) { r.row = o - 3; r.c1 = 2; r.bsel = 3; r.cls = 0; }              // d/d pb = sum dp (y + oy)
+  else if (o < 9) { r.row = o - 6; r.cls = 0; }                                    // d/d pc
+  else if (o == 9) { r.row = 3; r.cls = 0; }                                       // d/d D (zr)
+  else if (o == 10) { r.row = 4; }                                                 // low-pass depth (z2)
+  else if (o == 11) { r.row = 5; r.c1 = 1; r.bsel = 4; r.alpha = -kFilterInvSq; }  // kF t2 (offx - x)
+  else if (o == 12) { r.row = 5; r.c1 = 2; r.bsel = 5; r.alpha = -kFilterInvSq; }
+  else if (o < 16) { r.row = 7; r.c1 = 3 + (o - 13); r.c2 = 9 + (o - 13); r.bsel = 1; r.cls = 2; }    // w x dL/dn (first term + remainder)
+  else if (o == 16) { r.row = 6; r.alpha = -1.0f; }                                // - sum t
+  else if (o < 20) { r.row = 7; r.c1 = 6 + (o - 17); r.c2 = 12 + (o - 17); r.bsel = 1; r.cls = 2; }   // w x dL/drgb
+  return r;
 }
 
 constexpr int k2BChunk = 64;
@@ -534,7 +541,12 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
                              const float *__restrict__ dL_dallmap, float *__restrict__ acc,
                              const uint32_t *__restrict__ hits) {
   __shared__ float4 q0[k2BChunk], q1[k2BChunk], q2[k2BChunk], q3[k2BChunk], q4[k2BChunk], q5[k2BChunk];
-  __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];   // q0..q3: SurfelLin, q4: (normal, r), q5: (g, b, 1 / opacity, -)
+  __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];   // q0..q3: SurfelLin, q4: (normal, r), q5: (g, b, ox, oy)
+  __shared__ float2 q6[k2BChunk];                        // (Sh, 1 / Sh): the hit's power-of-two scale for the 1 / p.z values
+  // [row = hit of the pair x kind][pixel] matrix of (h1 | h2 << 16) dwords; the 16 x 16 result tile reuses its first rows
+  __shared__ __attribute__((aligned(16))) uint32_t xm2[16 * k2XStride];
+  float *dbuf = reinterpret_cast<float *>(xm2);
+  static_assert(16 * k2DStride <= 4 * k2XStride && 64 * 6 <= 16 * k2XStride, "the result tile and the prologue scratch fit the matrix");
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
@@ -567,13 +579,93 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   }
   if (last == 0) { final_D = final_D2 = dpix0 = dpix1 = dpix2 = ddep = dacc = dn0 = dn1 = dn2 = dmed = dreg = 0.0f; med_c = 0; }
   const float final_A = 1.0f - T_final;
-  const float bg_dot = bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2;
   const float fn = kFarZ / (kFarZ - kNearZ);
   uint32_t todo = last;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
   todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // wave-uniform: keeps the chunk loop's counters in SGPRs
-  const int slot = reduce20_slot(lane);
+  // one power-of-two scale per wave from the block's largest upstream gradient (exact; everything below is linear in them)
+  float sv, inv_sv;
+  {
+    float amax = fmaxf(fmaxf(fabsf(dpix0), fabsf(dpix1)), fabsf(dpix2));
+    if (kHasMap) amax = fmaxf(fmaxf(fmaxf(amax, fabsf(ddep)), fmaxf(fabsf(dacc), fabsf(dmed))),
+                              fmaxf(fmaxf(fabsf(dn0), fabsf(dn1)), fmaxf(fabsf(dn2), fabsf(dreg))));
+    const int eb = (int)((wave_max_u32(__float_as_uint(amax)) >> 23) & 0xFFu);   // biased exponent; 0: zero / denormal
+    const int sb = eb == 0 ? 127 : min(max(254 + k2TargetExp - eb, 1), 253);
+    sv = __uint_as_float((uint32_t)sb << 23);
+    inv_sv = __uint_as_float((uint32_t)(254 - sb) << 23);
+  }
+  dpix0 *= sv; dpix1 *= sv; dpix2 *= sv; ddep *= sv; dacc *= sv; dn0 *= sv; dn1 *= sv; dn2 *= sv; dmed *= sv; dreg *= sv;
+  const float bg_dot = bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2;   // (of the SCALED gradients, like everything below)
+  // B operand.  A lane supplies ONE column bn of the basis for the pixels 16 m + 4 bk + j (MFMA m, j = 0..3), each value twice
+  // (once per fp16 term of the A side).  The six gradient columns come from the other lanes through LDS (the matrix is idle).
+  Frag2 bh[4];
+  {
+    float *xs = reinterpret_cast<float *>(xm2);
+    xs[lane * 6 + 0] = dn0; xs[lane * 6 + 1] = dn1; xs[lane * 6 + 2] = dn2;
+    xs[lane * 6 + 3] = dpix0; xs[lane * 6 + 4] = dpix1; xs[lane * 6 + 5] = dpix2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int bn = lane & 15, bk = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = 16 * m + 4 * bk + j;
+        float b = 0.0f;
+        b = bn == 0 ? 1.0f : b;
+        b = bn == 1 ? (float)(q & 7) - 3.5f : b;
+        b = bn == 2 ? (float)(q >> 3) - 3.5f : b;
+        if (bn >= 3 && bn <= 14) {
+          const float g = xs[q * 6 + (bn - 3) % 6];
+          const float g1 = half_lo_2d(pack_rtz16_2d(g, 0.0f));
+          b = bn <= 8 ? g1 : g - g1;                       // columns 3..8: first fp16 term, 9..14: the remainder
+        }
+        const uint32_t hb = pack_rtz16_2d(b, 0.0f) & 0xFFFFu;
+        bh[m].d[j] = hb | (hb << 16);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const ReadOut ro = read_out_of(lane & 31);
+  const float ro_unscale = ro.cls == 2 ? inv_sv * (1.0f / k2WScale) : inv_sv;
+  const int abase = (lane & 15) * k2XStride + 4 * (lane >> 4);
+  // Two hits per pass over the matrix pipe: `pend` halves of the matrix are filled (slots pend_s[0], pend_s[1] of the chunk)
+  int pend = 0, pend_s0 = 0, pend_s1 = 0;
+  auto flush_pair = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    Frag2 af[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) af[m].q = *reinterpret_cast<const uint4 *>(&xm2[abase + 16 * m]);
+    f32x4_2d d = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m].v, bh[m].v, d, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // every lane has its A operands: the result tile may overwrite the matrix
+#pragma unroll
+    for (int i = 0; i < 4; i++) dbuf[(4 * (lane >> 4) + i) * k2DStride + (lane & 15)] = d[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int hh = lane >> 5;
+    if ((lane & 31) < kAcc2Stride && hh < pend) {   // lanes 0..19: the first hit of the pair, 32..51: the second
+      const int sl = hh ? pend_s1 : pend_s0;
+      const float4 gb = q5[sl];
+      const float4 a2 = q2[sl];
+      const float2 sh = q6[sl];
+      float beta = ro.bsel == 1 ? 1.0f : 0.0f;
+      beta = ro.bsel == 2 ? gb.z : beta;
+      beta = ro.bsel == 3 ? gb.w : beta;
+      beta = ro.bsel == 4 ? kFilterInvSq * (a2.z - bxc) : beta;
+      beta = ro.bsel == 5 ? kFilterInvSq * (a2.w - byc) : beta;
+      const float *row = dbuf + (ro.row + 8 * hh) * k2DStride;
+      const float v = (ro.alpha * row[ro.c1] + beta * row[ro.c2]) * (ro.cls == 0 ? ro_unscale * sh.y : ro_unscale);
+      atomicAdd(acc + (size_t)q_id[sl] * kAcc2Stride + (lane & 31), v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the next hits' rows overwrite the result tile
+    pend = 0;
+  };
   float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f, last_dL_dT = 0.0f;
   // gathers software-pipelined two chunks deep over the block's hit list (left by the forward), back to front: lane l of
   // the chunk that starts dn hits from the end takes the hit at 0-based position todo - 1 - dn - l
@@ -609,6 +701,17 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       // (ox, oy) = block centre - the surfel's accumulation point (its centre clamped into the image)
       q5[qi] = make_float4(r4.x, r4.y, bxc - fminf(fmaxf(r2.y, 0.0f), (float)(W - 1)), byc - fminf(fmaxf(r2.z, 0.0f), (float)(H - 1)));
       q_id[qi] = id; q_pos[qi] = top - (uint32_t)lane + 1u;
+      // The power of two below |p.z| at the block centre (L.e2.x): 1 / p.z times it stays within [1/3, 4] over the block as
+      // long as p.z = e2.x + e0.z qx + e1.y qy (|qx|, |qy| <= 3.5) stays within half of its centre value.  Where it does not - a
+      // large surfel whose horizon passes near the block - the centre says nothing about the pixels that count, and the
+      // scale is taken from the hit's largest |1 / p.z| over its valid pixels when the hit is replayed (Sh = 0 asks for it).
+      const float pzc = fabsf(L.e2.x);
+#ifndef SCORP_2D_STEADY_FRAC
+#define SCORP_2D_STEADY_FRAC 0.5f
+#endif
+      const bool steady = 3.5f * (fabsf(L.e0.z) + fabsf(L.e1.y)) <= SCORP_2D_STEADY_FRAC * pzc;
+      const uint32_t eb = min(max(__float_as_uint(pzc) & 0x7F800000u, 0x10000000u), 0x6F000000u);
+      q6[qi] = steady ? make_float2(__uint_as_float(eb), __uint_as_float(0x7F000000u - eb)) : make_float2(0.0f, 0.0f);
     }
     const int cnt = (int)min(todo - done_n, (uint32_t)k2BChunk);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -655,32 +758,35 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         dL_dal -= T_final * rinv * bg_dot;
         t = -h.Go * dL_dal;          // dL/dG * (-G), G = Go / opacity
       }
-      // acc row: d/d pa (3), d/d pb (3), d/d pc (3), d/d D, d/d Tw.z (low-pass depth), d/d (cx, cy), normal (3),
-      // opacity, rgb (3)
-      float g[20];
+      // The eight per-pixel values of this hit (zero on the lanes it does not touch), as two fp16 terms each, into the
+      // matrix half `pend`; the products with the bases and the sums over the block's pixels are the matrix cores' work.
       {
         const bool u3 = valid & h.use3d;
-        const float s0 = u3 ? h.s0 : 0.0f, s1 = u3 ? h.s1 : 0.0f, rz = u3 ? h.rz : 0.0f, dep = u3 ? h.depth : 0.0f;
+        const float s0 = u3 ? h.s0 : 0.0f, s1 = u3 ? h.s1 : 0.0f, dep = u3 ? h.depth : 0.0f;
+        float Sh = q6[s].x;                                                 // (wave-uniform: one LDS broadcast)
+        if (Sh == 0.0f) {   // no steady scale for this hit (see the staging): 2^-e of its largest |1 / p.z| over the valid 3-D pixels
+          const uint32_t em = min(max(wave_max_u32(u3 ? (__float_as_uint(h.rz) & 0x7F800000u) : 0u), 0x10000000u), 0x6F000000u);
+          Sh = __uint_as_float(0x7F000000u - em);
+          if (lane == 0) q6[s_] = make_float2(Sh, __uint_as_float(em));       // the read-out unscales with it
+        }
+        const float rzs = u3 ? h.rz * Sh : 0.0f;                            // 1 / p.z times the hit's power-of-two scale
         const float t2 = h.use3d ? 0.0f : t, z2 = h.use3d ? 0.0f : dL_dz;   // low-pass branch (t, dL_dz are 0 if !valid)
-        const float tr = t * rz;
+        const float tr = t * rzs;
         const float dp0 = tr * s0, dp1 = tr * s1;
-        const float zr = dL_dz * rz;                                        // depth = D / pz
+        const float zr = dL_dz * rzs;                                       // depth = D / pz
         const float dp2 = -(dp0 * s0 + dp1 * s1) - zr * dep;
-        const float ax = qxb + gb.z, ay = qyb + gb.w;   // x - ex, y - ey: the pixel about the surfel's accumulation point
-        g[0] = dp0 * ax; g[1] = dp1 * ax; g[2] = dp2 * ax;
-        g[3] = dp0 * ay; g[4] = dp1 * ay; g[5] = dp2 * ay;
-        g[6] = dp0; g[7] = dp1; g[8] = dp2;
-        g[9] = zr;
-        g[10] = z2;
-        g[11] = t2 * (kFilterInvSq * h.dx);
-        g[12] = t2 * (kFilterInvSq * h.dy);
-        g[13] = kHasMap ? w * dn0 : 0.0f; g[14] = kHasMap ? w * dn1 : 0.0f; g[15] = kHasMap ? w * dn2 : 0.0f;
-        g[16] = -t;                                                         // opacity * G * dL/dalpha (the per-surfel kernel divides by the opacity)
-        g[17] = w * dpix0; g[18] = w * dpix1; g[19] = w * dpix2;
+        uint32_t *rowp = xm2 + (8 * pend) * k2XStride + lane;
+        uint32_t da, db;
+        split_two(dp0, dp1, da, db); rowp[0] = da; rowp[k2XStride] = db;
+        split_two(dp2, zr, da, db); rowp[2 * k2XStride] = da; rowp[3 * k2XStride] = db;
+        split_two(z2, t2, da, db); rowp[4 * k2XStride] = da; rowp[5 * k2XStride] = db;
+        split_two(t, w * k2WScale, da, db); rowp[6 * k2XStride] = da; rowp[7 * k2XStride] = db;
       }
-      const float v = reduce20(g, lane);
-      if (slot >= 0) atomicAdd(acc + (size_t)q_id[s] * kAcc2Stride + slot, v);
+      if (pend == 0) pend_s0 = s_; else pend_s1 = s_;
+      pend++;
+      if (pend == 2) flush_pair();
     }
+    if (pend) flush_pair();   // (before the next chunk's staging overwrites the slots the read-out looks at)
     hit = hit1; id = id1; r0 = nx0; r1 = nx1; r2 = nx2; r3 = nx3; r4 = nx4;
     hit1 = hit2; id1 = id2;
   }
