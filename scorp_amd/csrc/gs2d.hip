@@ -530,7 +530,11 @@ __device__ __forceinline__ ReadOut read_out_of(int o) {
   return r;
 }
 
-constexpr int k2BChunk = 64;
+#ifndef SCORP_2D_BCHUNK
+#define SCORP_2D_BCHUNK 32
+#endif
+constexpr int k2BChunk = SCORP_2D_BCHUNK;   // hits staged per chunk: 32 (the staging arrays are 112 bytes per hit; with 64 the wave's 11.5 KB of
+                                            // LDS held the kernel at 13 waves per CU where its 124 registers allow 16: 706 -> 665 us)
 
 template <bool kHasMap>
 __global__ void __launch_bounds__(64, 3)
@@ -671,7 +675,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   // the chunk that starts dn hits from the end takes the hit at 0-based position todo - 1 - dn - l
   const uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
   auto fetch_idx = [&](uint32_t dn, bool &hit_, uint32_t &id_) {
-    hit_ = dn + lane < todo;
+    hit_ = lane < k2BChunk && dn + lane < todo;
     id_ = hit_ ? my_hits[todo - 1 - dn - lane] : 0u;
   };
   auto fetch_rec = [&](bool hit_, uint32_t id_, float4 &a0_, float4 &a1_, float4 &a2_, float4 &a3_, float4 &a4_) {
