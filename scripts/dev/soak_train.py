@@ -21,7 +21,7 @@ def psnr_of(model, cams, gts, rf, pipe):
     v = views(model, cams, rf, pipe)
     return float(torch.stack([-10.0 * torch.log10(((a - b) ** 2).mean()) for a, b in zip(v, gts)]).mean())
 dev = torch.device('cuda:0')
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2900   # not a multiple of the opacity reset interval: the last reset has 900 iterations to recover
 for surfels in (False, True):
     Model = GaussianModel2D if surfels else GaussianModel
     N, deg = 150_000, 2
