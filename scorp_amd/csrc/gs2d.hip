@@ -324,6 +324,14 @@ __device__ __forceinline__ bool eval_surfel(const float4 e0, const float4 e1, co
   const float p0 = __builtin_fmaf(e0.x, qx, __builtin_fmaf(e0.w, qy, e1.z));
   const float p1 = __builtin_fmaf(e0.y, qx, __builtin_fmaf(e1.x, qy, e1.w));
   h.pz = __builtin_fmaf(e0.z, qx, __builtin_fmaf(e1.y, qy, e2.x));
+#ifdef SCORP_2D_PROBE_P
+  {   // measurement build only: the six multiply-adds of p a second time (what taking them off the vector pipe could save)
+    const float x0 = __builtin_fmaf(e0.y, qx, __builtin_fmaf(e0.z, qy, e1.w));
+    const float x1 = __builtin_fmaf(e0.w, qx, __builtin_fmaf(e1.y, qy, e2.x));
+    const float x2 = __builtin_fmaf(e0.x, qx, __builtin_fmaf(e1.x, qy, e1.z));
+    asm volatile("" ::"v"(x0), "v"(x1), "v"(x2));
+  }
+#endif
   h.rz = __builtin_amdgcn_rcpf(h.pz);
   h.s0 = p0 * h.rz; h.s1 = p1 * h.rz;
   const float rho3d = __builtin_fmaf(h.s0, h.s0, h.s1 * h.s1);
@@ -338,12 +346,25 @@ __device__ __forceinline__ bool eval_surfel(const float4 e0, const float4 e1, co
   return (h.pz != 0.0f) & (h.depth >= kNearZ) & (h.alpha >= kAlphaMin);
 }
 
-constexpr int k2FRing = 128, k2FChunk = 64, k2FGroup = 8;
+// Hits per straight-line group and the waves per SIMD the kernel is held to.  Groups of 8 behind a 128-slot ring (rounds
+// 2 - 3) cost 164 registers and 11.8 KB of LDS per wave: three waves per SIMD, 13 per CU by LDS.  Groups of 4 behind a
+// 68-slot ring: 96 registers, 6.3 KB - five waves per SIMD.  Same box, rocprof, S6: 298 -> 272 us (render-only form
+// 293 -> 262); groups of 8 squeezed into 128 registers (spills): 334; groups of 2 need more registers than groups of 4.
+// The blend order does not depend on the group size (bit-identical images and hit lists).
+#ifndef SCORP_2D_FGROUP
+#define SCORP_2D_FGROUP 4
+#endif
+#ifndef SCORP_2D_FWAVES
+#define SCORP_2D_FWAVES 5
+#endif
+constexpr int k2FChunk = 64, k2FGroup = SCORP_2D_FGROUP;
+// ring: at most k2FGroup - 1 left-over hits + 64 new ones, a multiple of the group (a group's slots never wrap)
+constexpr int k2FRing = (k2FChunk + k2FGroup - 1 + k2FGroup - 1) / k2FGroup * k2FGroup;
 
 // kForBackward = false (scorp_gs2d_render_image): no cull verdicts, per-pixel state or contributor bookkeeping is left
 // behind for a backward pass.
 template <bool kForBackward>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, SCORP_2D_FWAVES)
 blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                             const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                             const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ allmap,
@@ -395,7 +416,8 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
     const uint64_t m = __ballot(hit);
     if (hit) {
       const uint32_t rank = nh + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-      const int qi = (head + count + (int)(rank - nh)) & (k2FRing - 1);
+      int qi = head + count + (int)(rank - nh);
+      qi = qi >= k2FRing ? qi - k2FRing : qi;
       const SurfelLin L = surfel_lin(r0, r1, r2, bxc, byc);
       q0[qi] = L.e0; q1[qi] = L.e1; q2[qi] = L.e2; q3[qi] = L.e3; q4[qi] = r3; q5[qi] = make_float2(r4.x, r4.y);
       q_pos[qi] = rank + 1u;
@@ -415,9 +437,19 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
       const float4 *g0 = q0 + hv, *g1 = q1 + hv, *g2 = q2 + hv, *g3 = q3 + hv, *g4 = q4 + hv;
       const float2 *g5 = q5 + hv;
       const uint32_t *gp = q_pos + hv;
-      static_assert(k2FGroup == 8, "positions are fetched as two 16-byte LDS reads");
-      const uint4 pl = *reinterpret_cast<const uint4 *>(gp), ph = *reinterpret_cast<const uint4 *>(gp + 4);
-      const uint32_t pos[k2FGroup] = {pl.x, pl.y, pl.z, pl.w, ph.x, ph.y, ph.z, ph.w};
+      static_assert(k2FGroup == 8 || k2FGroup == 4 || k2FGroup == 2, "positions are fetched as 16- or 8-byte LDS reads");
+      uint32_t pos[k2FGroup];
+      if constexpr (k2FGroup == 2) {
+        const uint2 pl = *reinterpret_cast<const uint2 *>(gp);
+        pos[0] = pl.x; pos[1] = pl.y;
+      } else {
+        const uint4 pl = *reinterpret_cast<const uint4 *>(gp);
+        pos[0] = pl.x; pos[1] = pl.y; pos[2] = pl.z; pos[3] = pl.w;
+        if constexpr (k2FGroup == 8) {
+          const uint4 ph = *reinterpret_cast<const uint4 *>(gp + 4);
+          pos[4] = ph.x; pos[5] = ph.y; pos[6] = ph.z; pos[7] = ph.w;
+        }
+      }
       float al[k2FGroup], dz[k2FGroup], mm[k2FGroup];
 #pragma unroll
       for (int i = 0; i < k2FGroup; i++) {
@@ -451,7 +483,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
           if constexpr (kForBackward) last = contributes ? pos[i] : last;
         }
       }
-      head = (head + k2FGroup) & (k2FRing - 1);
+      head = head + k2FGroup == k2FRing ? 0 : head + k2FGroup;
       count -= nslots;
     };
     while (count >= k2FGroup) blend_group(std::true_type{}, k2FGroup);
@@ -536,8 +568,12 @@ __device__ __forceinline__ ReadOut read_out_of(int o) {
 constexpr int k2BChunk = SCORP_2D_BCHUNK;   // hits staged per chunk: 32 (the staging arrays are 112 bytes per hit; with 64 the wave's 11.5 KB of
                                             // LDS held the kernel at 13 waves per CU where its 124 registers allow 16: 706 -> 665 us)
 
+// 122 registers: four waves per SIMD.  Held to five (96 registers) it spills 26 dwords: 673 -> 740 us (same box).
+#ifndef SCORP_2D_BWAVES
+#define SCORP_2D_BWAVES 3
+#endif
 template <bool kHasMap>
-__global__ void __launch_bounds__(64, 3)
+__global__ void __launch_bounds__(64, SCORP_2D_BWAVES)
 blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                              const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                              const float *__restrict__ bg, const float *__restrict__ final_T,
