@@ -128,8 +128,7 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
                 average_gradients(ps)
         if densify and iteration < opt.densify_until_iter:
             vis, radii = pkg["visibility_filter"], pkg["radii"]
-            gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis].float())
-            gaussians.add_densification_stats(pkg["viewspace_points"], vis)
+            gaussians.accumulate_view_stats(pkg["viewspace_points"], vis, radii)   # train_3dgs.py:180-181, no mask indexing
             if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
                 size_threshold = opt.max_screen_size if iteration > opt.opacity_reset_interval else None   # train_3dgs.py:184
                 if data_parallel:

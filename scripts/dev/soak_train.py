@@ -1,6 +1,6 @@
 """Dev soak: a few thousand fused-view training iterations with densification on a mid-size synthetic scene (3DGS and
 2DGS): finishes, finite losses, PSNR up, memory flat.  python scripts/dev/soak_train.py [iterations]"""
-import math, sys, time
+import math, os, sys, time
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from scorp_amd.gaussian_model import GaussianModel, OptimizationParams, OptimizationParams2D
@@ -24,7 +24,7 @@ dev = torch.device('cuda:0')
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2900   # not a multiple of the opacity reset interval: the last reset has 900 iterations to recover
 for surfels in (False, True):
     Model = GaussianModel2D if surfels else GaussianModel
-    N, deg = 150_000, 2
+    N, deg = int(os.environ.get('SOAK_N', 150_000)), 2
     raw = make_gaussians(N, deg, 11, log_scale_mean=math.log(0.012))
     if surfels:
         raw["scaling"] = raw["scaling"][:, :2].copy()
@@ -34,7 +34,8 @@ for surfels in (False, True):
     raw2["xyz"] += rng.normal(0, 0.01, raw2["xyz"].shape).astype(np.float32)
     raw2["features_dc"] += rng.normal(0, 0.3, raw2["features_dc"].shape).astype(np.float32)
     student = Model.from_raw(raw2, deg, device=dev); student.active_sh_degree = deg
-    cams = ring_cameras(24, 800, 600, 4, radius=3.5, device=dev)
+    W_, H_ = (int(v) for v in os.environ.get('SOAK_WH', '800x600').split('x'))
+    cams = ring_cameras(24, W_, H_, 4, radius=3.5, device=dev)
     kw = dict(surfels=True) if surfels else {}
     rf = render2d if surfels else render3d
     pipe = PipelineParams(); pipe.fused_activations = True

@@ -369,3 +369,35 @@ def test_hip_transform_kernel_matches_wigner_table_and_torch_formulation(dev):
     TR.gaussians_rotate(m2, R.to(dev), fix_center=True)    # torch ops
     for n in ("_xyz", "_rotation", "_features_rest"):
         assert (getattr(m1, n) - getattr(m2, n)).abs().max() < 5e-6, n
+
+
+@pytest.mark.gpu
+def test_view_statistics_kernel_equals_the_masked_indexing(dev):
+    """GaussianModel.accumulate_view_stats (one launch of scorp_densification_stats) against the reference's three
+    boolean-mask updates (train_3dgs.py:180-181, gaussian_model.py:603-605), with and without the device-side skip word."""
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.synthetic import make_gaussians
+    n = 20011
+    g = torch.Generator(device="cpu").manual_seed(5)
+
+    class VS:   # what the loop hands over: something with a .grad of shape [N, 3]
+        pass
+
+    ours = GaussianModel.from_raw(make_gaussians(n, 1, 3), 1, device=dev)
+    ours.training_setup(OptimizationParams())
+    ref_max, ref_acc, ref_den = ours.max_radii2D.clone(), ours.xyz_gradient_accum.clone(), ours.denom.clone()
+    for view in range(3):
+        vs = VS()
+        vs.grad = torch.randn(n, 3, generator=g).to(dev) * 1e-3
+        radii = torch.randint(0, 40, (n,), generator=g, dtype=torch.int32).to(dev)
+        vis = (radii > 0) & (torch.rand(n, generator=g).to(dev) > 0.3)
+        skip = torch.tensor([1 if view == 1 else 0], dtype=torch.int32, device=dev)   # the second view "overflowed"
+        ours.accumulate_view_stats(vs, vis, radii, skip_flag=skip if view else None)
+        if view != 1:
+            ref_max[vis] = torch.max(ref_max[vis], radii[vis].float())
+            ref_acc[vis] += torch.norm(vs.grad[vis, :2], dim=-1, keepdim=True)
+            ref_den[vis] += 1
+    torch.cuda.synchronize()
+    assert torch.equal(ours.max_radii2D, ref_max) and torch.equal(ours.denom, ref_den)
+    torch.testing.assert_close(ours.xyz_gradient_accum, ref_acc, rtol=1e-6, atol=0)
+    assert float(ref_den.max()) == 2.0 and float(ref_den.min()) == 0.0

@@ -1,0 +1,31 @@
+"""Host logic of the Gaussian model that needs no GPU."""
+import torch
+
+
+def test_view_statistics_without_mask_indexing_equal_the_reference_form():
+    """accumulate_view_stats on CPU tensors (the torch.where form) against train_3dgs.py:180-181 written as in the
+    reference: same max_radii2D, denom and gradient accumulator, also behind a skip word."""
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.synthetic import make_gaussians
+    n = 777
+    g = torch.Generator().manual_seed(3)
+    m = GaussianModel.from_raw(make_gaussians(n, 1, 3), 1, device="cpu")
+    m.training_setup(OptimizationParams())
+    ref_max, ref_acc, ref_den = m.max_radii2D.clone(), m.xyz_gradient_accum.clone(), m.denom.clone()
+
+    class VS:
+        pass
+
+    for view in range(3):
+        vs = VS()
+        vs.grad = torch.randn(n, 3, generator=g) * 1e-3
+        radii = torch.randint(0, 40, (n,), generator=g, dtype=torch.int32)
+        vis = (radii > 0) & (torch.rand(n, generator=g) > 0.3)
+        skip = torch.tensor([1 if view == 1 else 0], dtype=torch.int32)
+        m.accumulate_view_stats(vs, vis, radii, skip_flag=skip if view else None)
+        if view != 1:
+            ref_max[vis] = torch.max(ref_max[vis], radii[vis].float())
+            ref_acc[vis] += torch.norm(vs.grad[vis, :2], dim=-1, keepdim=True)
+            ref_den[vis] += 1
+    assert torch.equal(m.max_radii2D, ref_max) and torch.equal(m.denom, ref_den)
+    torch.testing.assert_close(m.xyz_gradient_accum, ref_acc, rtol=1e-6, atol=0)
