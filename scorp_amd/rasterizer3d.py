@@ -127,26 +127,38 @@ class PairPolicy:
     @classmethod
     def drain(cls):
         """Verify every forward issued in "reserve" mode since the last drain (each on its own stream's event)."""
-        L = _C.lib()
         pend, cls._pending = cls._pending, []
         worst = 0
         err = None
+        if not pend:
+            return worst
         for p in pend:
             if p.event is not None:
-                p.event.synchronize()     # the header copy was made on the stream that rendered the view
-            n = ctypes.c_uint64(0)
-            code = L.scorp_gs3d_check_overflow(p.header.data_ptr(), _stream(), ctypes.byref(n))
-            worst = max(worst, n.value)
+                p.event.synchronize()     # the header was written on the stream that rendered the view
+        # ONE device-to-host copy for all pending headers (first four words: pairs needed, overflow, capacity, -), per
+        # device.  One scorp_gs3d_check_overflow per view was a copy and a stream synchronisation each - 32 of them per
+        # drain, ~0.1 ms per training iteration of a 100k-Gaussian object.
+        words = [None] * len(pend)
+        by_dev = {}
+        for i, p in enumerate(pend):
+            by_dev.setdefault(p.header.device, []).append(i)
+        for dev, idx in by_dev.items():
+            rows = torch.stack([pend[i].header.reshape(-1).view(torch.uint8)[:16] for i in idx]).cpu().numpy().view("<u4")
+            for i, r in zip(idx, rows):
+                words[i] = r
+        for p, w in zip(pend, words):
+            n, overflow, capacity = int(w[0]), int(w[1]), int(w[2])
+            worst = max(worst, n)
             if p.key is not None:
-                need = int(n.value * cls.slack) + 1024
+                need = int(n * cls.slack) + 1024
                 got, n0 = cls._ctx.pop(p.key, (0, 0))
                 if n0 > 0 and p.n > 0 and n0 != p.n:
                     got = int(got * (p.n / n0)) if 0.5 <= p.n / n0 <= 2.0 else 0   # what was learned, at this view's model size (_rescaled)
                 cls._ctx[p.key] = (max(got, need), p.n if p.n > 0 else n0)   # (re-inserted last: most recently learned)
                 while len(cls._ctx) > cls._MAX_CTX:
                     cls._ctx.pop(next(iter(cls._ctx)))
-            if code != 0 and err is None:
-                err = L.scorp_last_error().decode()
+            if overflow and err is None:
+                err = f"pair buffer overflow: {n} pairs needed, capacity {capacity}"
         if err:
             raise RuntimeError(f"pair reservation too small ({err}); the context's reservation has been grown, re-run the view(s)")
         return worst

@@ -186,7 +186,15 @@ def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, backgr
         it += 1
     if kw.get("fused_view"):
         _drain_reservation()
-    return [float(l) for l in losses]
+    return _to_floats(losses)
+
+
+def _to_floats(losses):
+    """The per-iteration loss tensors as Python floats with ONE device-to-host copy (float(l) per element is a
+    synchronisation per iteration: 20 us each, as much as a whole short refinement's launch overhead)."""
+    if not losses:
+        return []
+    return torch.stack([l.reshape(()) for l in losses]).tolist()
 
 
 def _drain_reservation(quiet=False):
@@ -258,7 +266,7 @@ def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, p
         it += 1
     if fused_view:
         _drain_reservation()
-    return [float(l) for l in losses]
+    return _to_floats(losses)
 
 
 def post_refine_objects(objects, cameras, gt_images, object_alphas, opt, iterations=800, pipe=None, background=None, seed=0,
