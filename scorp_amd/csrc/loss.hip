@@ -122,11 +122,65 @@ ssim_l1_forward_strip_kernel(const float *__restrict__ img, const float *__restr
     if (mask) { const float *mr = mask + ro; v.ma = mr[oa]; v.mb = mr[ob]; }
     return v;
   };
+  const int rbeg = ry0 - kLH;
+  if (mask) {
+    // A strip whose whole support (its rows +- 5, its columns +- 5) lies where the mask is zero - most of the image when the
+    // mask is one object's silhouette (post_refine_gs.py:103-111) - has x = y = 0 everywhere: SSIM is the constant below,
+    // |x - y| = 0, and the derivative maps are constants too.  One pass over the mask decides it; the values are formed by
+    // the same instructions as in the loop below (hardware reciprocals of operands the compiler cannot fold), the sums in
+    // the same order: same bits as the long way round.  (Pixels of a NaN / infinite image under a zero mask come out clean
+    // here and NaN there.)
+    // (unconditional loads from clamped rows and columns, ALL of the support's rows in flight together - one memory round
+    // trip; the registers are free here.  A row clamped into the image is one of the support's own rows, a clamped column is
+    // masked by cin_a / cin_b)
+    bool any = false;
+    {
+      constexpr int kSupport = kStripRows + 2 * kLH;
+      float ma[kSupport], mb[kSupport];
+#pragma unroll
+      for (int u = 0; u < kSupport; u++) {
+        const float *mr = mask + (size_t)min(max(rbeg + u, 0), H - 1) * W;
+        ma[u] = mr[oa]; mb[u] = mr[ob];
+      }
+#pragma unroll
+      for (int u = 0; u < kSupport; u++) any |= (cin_a & (ma[u] != 0.0f)) | (cin_b & (mb[u] != 0.0f));
+    }
+    if (__ballot(any) == 0) {
+      float c1 = kC1, c2 = kC2, zero = 0.0f;
+      asm volatile("" : "+v"(c1), "+v"(c2), "+v"(zero));
+      const float m1 = zero, m2 = zero, ess = zero, e12 = zero;
+      const float m1s = m1 * m1, m2s = m2 * m2, m12 = m1 * m2;
+      const float s12 = e12 - m12;
+      const float A1 = 2 * m12 + c1, A2 = 2 * s12 + c2, B1 = m1s + m2s + c1, B2 = (ess - m1s - m2s) + c2;
+      const float rB2 = __builtin_amdgcn_rcpf(B2);
+      const float inv = __builtin_amdgcn_rcpf(B1) * rB2;
+      const float ssim = A1 * A2 * inv;
+      float ssim_sum = 0.0f;
+      for (int ro = ry0; ro < min(ry0 + kStripRows, H); ro++) {
+        if (gx < W) {
+          ssim_sum += ssim;
+          if (dmaps) {
+            float *d0 = dmaps + ch * HW + (size_t)ro * W;
+            d0[(uint32_t)gx] = (2 * m2 * (A2 - A1) - 2 * m1 * ssim * (B2 - B1)) * inv;
+            (d0 + CHW)[(uint32_t)gx] = -ssim * rB2;
+            (d0 + 2 * CHW)[(uint32_t)gx] = 2 * A1 * inv;
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) ssim_sum += __shfl_xor(ssim_sum, off, 64);
+      if (lane == 0) {
+        const int wave = blockIdx.x * 4 + wv;
+        partials[2 * wave] = 0.0f;
+        partials[2 * wave + 1] = ssim_sum;
+      }
+      return;
+    }
+  }
   float hist[4][11], cx[11], cy[11];                       // rings, slot = row mod 11 (static: the loop is unrolled by 11)
 #pragma unroll
   for (int k = 0; k < 11; k++) { hist[0][k] = hist[1][k] = hist[2][k] = hist[3][k] = 0.0f; cx[k] = cy[k] = 0.0f; }
   float l1_sum = 0.0f, ssim_sum = 0.0f;
-  const int rbeg = ry0 - kLH;
   RowRegs n0 = fetch(rbeg), n1 = fetch(rbeg + 1);
 #pragma unroll 1
   for (int it = 0; it < kStripIters; it++) {
@@ -237,6 +291,9 @@ loss_finalize_kernel(const float *__restrict__ partials, int nblocks, double n_e
 
 struct LossFinalize { const float *partials; int nparts; double n_elems; float *out; };   // out == NULL: nothing to do
 
+// kMasked: a separate instantiation, so that the unmasked one (every training view) keeps its 74 registers and six waves
+// per SIMD - with the mask's early exit as a run-time branch the allocator took 84 and the kernel lost a wave.
+template <bool kMasked>
 __global__ void __launch_bounds__(256)
 ssim_l1_backward_kernel(const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ mask,
                         const float *__restrict__ dmaps, int C, int H, int W, Window win, float lambda, float inv_n,
@@ -259,19 +316,45 @@ ssim_l1_backward_kernel(const float *__restrict__ img, const float *__restrict__
   const int c = threadIdx.x % kLT, r0 = (threadIdx.x / kLT) * 4;
   const float go = grad_out ? grad_out[0] : 1.0f;
   float xv[4], yv[4], mk[4], acc[4];
-  // the thread's own four pixels: all loads issued together from clamped addresses, out-of-image ones zeroed by a
-  // select (with the bounds test around the loads each pixel was two dependent round trips to memory)
+  if constexpr (kMasked) {
+    // The mask first (one extra round trip for masked calls only): a tile it zeroes entirely - most tiles when the mask is
+    // one object's silhouette - has a zero gradient whatever the maps hold, and leaves before anything else is fetched.
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      const int gy = y0 + r0 + o, gx = x0 + c;
+      const float m = mask[(size_t)min(gy, H - 1) * W + min(gx, W - 1)];
+      mk[o] = (gy < H && gx < W) ? m : 0.0f;
+    }
+    const bool any = (mk[0] != 0.0f) | (mk[1] != 0.0f) | (mk[2] != 0.0f) | (mk[3] != 0.0f);
+    int *s_any = reinterpret_cast<int *>(&s_h[0][0]);   // (the tile buffers are idle; every writer writes the same 1)
+    if (threadIdx.x == 0) *s_any = 0;
+    __syncthreads();
+    if (any) *s_any = 1;
+    __syncthreads();
+    const bool some = *s_any != 0;
+    __syncthreads();                                    // (before the buffer is a tile buffer again)
+    if (!some) {   // (workgroup-uniform)
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        const int gy = y0 + r0 + o, gx = x0 + c;
+        if (gy < H && gx < W) grad_img[ch * HW + (size_t)gy * W + gx] = 0.0f;
+      }
+      return;
+    }
+  } else {
+#pragma unroll
+    for (int o = 0; o < 4; o++) mk[o] = (y0 + r0 + o < H && x0 + c < W) ? 1.0f : 0.0f;
+  }
+  // the thread's own four pixels: all loads issued together from clamped addresses, out-of-image ones zeroed by the mask
+  // (with the bounds test around the loads each pixel was two dependent round trips to memory)
 #pragma unroll
   for (int o = 0; o < 4; o++) {
     const int gy = y0 + r0 + o, gx = x0 + c;
     const size_t p = (size_t)min(gy, H - 1) * W + min(gx, W - 1);
-    mk[o] = mask ? mask[p] : 1.0f;
     xv[o] = img[ch * HW + p]; yv[o] = gt[ch * HW + p];
   }
 #pragma unroll
   for (int o = 0; o < 4; o++) {
-    const bool in = y0 + r0 + o < H && x0 + c < W;
-    mk[o] = in ? mk[o] : 0.0f;
     xv[o] *= mk[o]; yv[o] *= mk[o];
     acc[o] = 0.0f;
   }
@@ -398,7 +481,12 @@ int loss_backward_impl(const float *img, const float *gt, const float *mask, int
   fin.out = out_loss3;
   {
     ProfScope prof(kKLossBackward, stream);
-    ssim_l1_backward_kernel<<<grid + (out_loss3 ? 1 : 0), 256, 0, stream>>>(img, gt, mask, (const float *)workspace, C, H, W, win,
+    if (mask)
+      ssim_l1_backward_kernel<true><<<grid + (out_loss3 ? 1 : 0), 256, 0, stream>>>(img, gt, mask, (const float *)workspace, C, H, W, win,
+                                                                           lambda_dssim, (float)(1.0 / ((double)C * H * W)), grad_out,
+                                                                           grad_img, fin);
+    else
+      ssim_l1_backward_kernel<false><<<grid + (out_loss3 ? 1 : 0), 256, 0, stream>>>(img, gt, mask, (const float *)workspace, C, H, W, win,
                                                                            lambda_dssim, (float)(1.0 / ((double)C * H * W)), grad_out,
                                                                            grad_img, fin);
   }

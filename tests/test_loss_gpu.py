@@ -44,3 +44,32 @@ def test_fused_loss_matches_torch_formulation(shape, masked, lam, dev):
     assert abs(got.item() - ref.item()) < 5e-6
     scale = x2.grad.abs().max().item()
     assert (x1.grad - x2.grad).abs().max().item() < 2e-3 * scale
+
+
+@pytest.mark.parametrize("shape,box", [((3, 200, 300), (60, 120, 100, 180)), ((3, 1200, 1600), (500, 700, 640, 980)),
+                                       ((1, 97, 131), (0, 9, 120, 131)), ((3, 64, 200), (0, 0, 0, 0))])
+def test_masked_loss_over_mostly_empty_mask_takes_the_same_values(shape, box, dev):
+    """A mask that is one object's silhouette (post_refine_gs.py:103-111) leaves most strips / tiles of the image empty; the
+    kernels answer those from constants.  Against the torch formulation, and BIT FOR BIT against the same kernels run the
+    long way round (no mask, inputs multiplied by it beforehand): the loss value, and the gradient = unmasked gradient x mask."""
+    from scorp_amd.fused_loss import fused_l1_ssim_loss
+    from scorp_amd.loss import l1_loss, ssim
+    lam = 0.2
+    g = torch.Generator(device=dev).manual_seed(shape[2])
+    x = torch.rand(shape, device=dev, generator=g)
+    y = (x + 0.1 * torch.randn(shape, device=dev, generator=g)).clamp(0, 1)
+    mask = torch.zeros((1,) + shape[1:], device=dev)
+    mask[:, box[0]:box[1], box[2]:box[3]] = (torch.rand((1, box[1] - box[0], box[3] - box[2]), device=dev, generator=g) > 0.1).float()
+    x1 = x.clone().requires_grad_(True)
+    l_masked = fused_l1_ssim_loss(x1, y, lam, mask)
+    l_masked.backward()
+    xm = (x * mask).requires_grad_(True)
+    l_plain = fused_l1_ssim_loss(xm, y * mask, lam)
+    l_plain.backward()
+    assert l_masked.item() == l_plain.item()
+    assert torch.equal(x1.grad, xm.grad * mask)
+    x2 = x.clone().requires_grad_(True)
+    ref = (1 - lam) * l1_loss(x2 * mask, y * mask) + lam * (1 - ssim(x2 * mask, y * mask))
+    ref.backward()
+    assert abs(l_masked.item() - ref.item()) < 5e-6
+    assert (x1.grad - x2.grad).abs().max().item() <= 2e-3 * max(x2.grad.abs().max().item(), 1e-12)
