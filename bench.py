@@ -667,6 +667,43 @@ def main():
         gathered = [torch.zeros_like(ll) for _ in range(world)]
         dist.all_gather(gathered, ll)     # gather of per-rank results (scalars)
 
+    # extra (not part of `value`), N = 1: FULL training iterations on the same model and cameras - the one-call view, the
+    # per-view densification statistics (scorp_densification_stats) and the guarded FusedAdam step over all 59 parameters
+    # per Gaussian (train_3dgs.py:74-193 / train_2dgs.py without the densification itself, which runs every 100th iteration)
+    train_its = None
+    if world == 1 and fused_view and side_streams is None and not args.no_secondary and not args.exact_backward:
+        try:
+            from scorp_amd.gaussian_model import OptimizationParams, OptimizationParams2D
+            from scorp_amd.train import training_iteration
+            PairPolicy.mode = "reserve"
+            opt_ = OptimizationParams2D() if surfels else OptimizationParams()
+            opt_.densify_from_iter, opt_.opacity_reset_interval, opt_.random_background = 1 << 30, 1 << 30, False
+            model.optimizer = None
+            model.training_setup(opt_)
+            kw_ = dict(surfels=True) if surfels else {}
+            n_it = max(min(args.steps, 100), 10)
+
+            def it_(i):
+                k_ = i % len(my_cams)
+                training_iteration(model, my_cams[k_], gts[k_], opt_, pipe, bg, i + 1, scene_extent=3.0, fused_view=True, **kw_)
+            for i in range(12):
+                it_(i)
+            PairPolicy.drain()
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0_.record()
+            for i in range(n_it):
+                it_(12 + i)
+            e1_.record()
+            PairPolicy.drain()
+            torch.cuda.synchronize()
+            train_its = round(n_it / (e0_.elapsed_time(e1_) * 1e-3), 1)
+        except Exception as e:   # (an extra: never costs the headline)
+            train_its = f"{type(e).__name__}: {e}"[:200]
+        finally:
+            PairPolicy.mode = "exact"
+            model.optimizer = None
+            for p in params:
+                p.grad = None
     # secondary records (guarded_record: a failure in one of them is reported inside the record, on every rank, and never
     # costs the headline): every N the 128-rotation sweep (the workload north_star's 8-GPU scaling target is set on) and
     # the object-sharded post-refinement; N > 1 the data-parallel training of one scene; N = 1 the 2DGS workload S6
@@ -741,6 +778,7 @@ def main():
             "pairs_per_s": (_sig(value * (P_f + P_b), 4) if work else None),
             "forward_only_views_per_s_per_gpu": round(fwd_only, 1),
             "views_per_s_two_in_flight": None if in_flight2 is None else round(in_flight2, 1),
+            "train_iterations_per_s": train_its,
             "view_hbm": {"algorithmic_bytes_per_view": int(B_view), "achieved_GBs": round(value / world * B_view / 1e9, 1),
                          "frac_of_8TBs": round(value / world * B_view / 8e12, 5)},
         }
