@@ -25,6 +25,28 @@ def run(args, dev, cdev, rank, world):
     cams = ring_cameras(16, args.width, args.height, 2, device=dev)
     gts = render_views_gt(teacher, cams)
     out = {}
+    trace = []
+    if os.environ.get("SCORP_DP_TRACE"):   # per-iteration wall times (synchronised) of rank 0, printed to stderr
+        import scorp_amd.train as T
+        inner = T.training_iteration
+
+        def timed(*a, **k):
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            r = inner(*a, **k)
+            torch.cuda.synchronize(); trace.append(round(1e3 * (time.perf_counter() - t_), 1))
+            return r
+        T.training_iteration = timed
+        for name in ("average_gradients", "average_gradients_sparse", "_shared_overflow"):   # the exchange steps on their own
+            def wrap(fn, name=name):
+                def w(*a, **k):
+                    torch.cuda.synchronize(); t_ = time.perf_counter()
+                    r = fn(*a, **k)
+                    torch.cuda.synchronize(); d_ = 1e3 * (time.perf_counter() - t_)
+                    if d_ > 30.0:
+                        trace.append(f"{name}:{d_:.0f}")
+                    return r
+                return w
+            setattr(T, name, wrap(getattr(T, name)))
     for sparse in ((True, False) if os.environ.get("SCORP_DP_SPARSE_FIRST") else (False, True)):
         m = GaussianModel.from_raw(raw, 3, device=dev)
         m.active_sh_degree = 3
@@ -46,6 +68,8 @@ def run(args, dev, cdev, rank, world):
         out["sparse" if sparse else "dense"] = {"iterations_per_s": round(args.iters / dt, 1), "views_per_s": round(args.iters * world / dt, 1),
                                                 "replicas_identical": bool(torch.equal(lo, hi)), "last_loss": losses[-1]}
     PairPolicy.reset()
+    if trace and rank == 0:
+        print("iteration ms:", trace, file=sys.stderr, flush=True)
     return out
 
 
