@@ -163,6 +163,16 @@ def lib():
     return L
 
 
+def current_stream_ptr():
+    """The current HIP stream of the current device as an integer.  torch.cuda.current_stream() builds a Stream object through
+    three layers of device-index helpers (9 us a call, six calls per training iteration); the raw getter is 0.3 us."""
+    import torch
+    try:
+        return int(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:   # (a torch build without the raw getters)
+        return int(torch.cuda.current_stream().cuda_stream)
+
+
 def prof_enable(on=True, only=None):
     """Start / stop hipEvent bracketing of the library's kernels; `only` = iterable of kernel names to bracket."""
     L = lib()

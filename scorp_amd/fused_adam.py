@@ -39,7 +39,7 @@ class FusedAdam(torch.optim.Adam):
                 st["step"] += 1
                 key = (group["betas"], group["eps"], int(st["step"]))
                 by_cfg.setdefault(key, []).append((p, p.grad.contiguous(), st, float(group["lr"])))
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = ctypes.c_void_p(_C.current_stream_ptr())
         skip, self.skip_flag = self.skip_flag, None
         skip_ptr = None if skip is None else ctypes.c_void_p(skip.data_ptr())
         for (betas, eps, step), items in by_cfg.items():

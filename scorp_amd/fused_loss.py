@@ -16,7 +16,7 @@ def _p(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_C.current_stream_ptr())
 
 
 class _FusedL1SSIM(torch.autograd.Function):

@@ -396,7 +396,7 @@ class GaussianModel:
             arr[k].src, arr[k].dst, arr[k].row_floats, arr[k].zero_if_fresh = src.data_ptr(), dst.data_ptr(), row, z
         if n_out > 0:
             _C.check(L.scorp_gather_rows(arr, len(jobs), ctypes.c_void_p(src_index.data_ptr()), n_out,
-                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "scorp_gather_rows")
+                                         ctypes.c_void_p(_C.current_stream_ptr())), "scorp_gather_rows")
         for group in self.optimizer.param_groups:
             old = group["params"][0]
             state = self.optimizer.state.pop(old, None)
@@ -512,7 +512,7 @@ class GaussianModel:
                 n, vp(r.data_ptr()), vp(f.data_ptr()), vp(g.data_ptr()), g.stride(0),
                 vp(skip_flag.data_ptr()) if skip_flag is not None else None, vp(self.max_radii2D.data_ptr()),
                 vp(self.xyz_gradient_accum.data_ptr()), vp(self.denom.data_ptr()),
-                vp(torch.cuda.current_stream().cuda_stream)), "scorp_densification_stats")
+                vp(_C.current_stream_ptr())), "scorp_densification_stats")
             return
         f = update_filter if skip_flag is None else update_filter & (skip_flag.reshape(-1)[0] == 0)
         self.max_radii2D = torch.where(f, torch.maximum(self.max_radii2D, radii.to(self.max_radii2D.dtype)), self.max_radii2D)

@@ -72,7 +72,7 @@ class PairPolicy:
 
     @classmethod
     def key(cls, N, H, W):
-        return (int(H), int(W), int(torch.cuda.current_stream().cuda_stream))
+        return (int(H), int(W), _C.current_stream_ptr())
 
     @classmethod
     def capacity(cls, N, H, W):
@@ -202,7 +202,7 @@ LAST_NUM_PAIRS_LOG = []   # pair counts of the most recent "exact"-mode forwards
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_C.current_stream_ptr())
 
 
 def _ptr(t):

@@ -102,7 +102,7 @@ def gaussians_transform(g, R=None, T=None, scale=None, fix_center=False, blocks=
     _C.check(L.scorp_gaussians_transform(p(g._xyz.data), p(g._rotation.data) if rotating else None,
                                          p(g._scaling.data) if scaling else None,
                                          p(g._features_rest.data) if (k_rest and rotating) else None, g._xyz.shape[0], k_rest,
-                                         int(g._scaling.shape[1]), p(params), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                         int(g._scaling.shape[1]), p(params), ctypes.c_void_p(_C.current_stream_ptr())),
              "scorp_gaussians_transform")
 
 
