@@ -244,11 +244,17 @@ def secondary_s6(dev, steps=40, warmup=8, cams=4, lead_in=24, parity=False):
     dom = max(kus, key=kus.get)
     K = (deg + 1) ** 2
     alg = kernel_algorithmic_bytes(dom, N, nvis, K, W * H, float(np.mean(Ds)))
+    traffic = None      # PMC bytes per launch of the dominant kernel, if profiles/traffic.json was collected on the loaded sources
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("source_sha") == _C.lib().scorp_source_sha().decode():
+            traffic = tj.get("S6", {}).get(dom)
     rec = {"metric": "fwd+bwd views/sec (S6: 1M surfels 1600x1200 SH3, config #5)", "value": round(steps / dt, 2), "unit": "views/s",
            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4), "pairs_per_view_D": round(float(np.mean(Ds))), "visible": round(nvis),
            "kernels_us": kus,
            "roofline": {"bound": "valu", "kernel": dom, "achieved": round(alg / (kus[dom] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(alg / (kus[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(alg / (kus[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "avg_launch_us": kus[dom], "algorithmic_bytes": int(alg)}}
     if parity:
         rec["parity_full_size"] = s6_full_size_parity(dev)
@@ -285,7 +291,7 @@ def secondary_sweep(dev, cdev, rank, world):
     import copy
     from scorp_amd.align import SweepPlan, render_views, rotation_sweep
     from scorp_amd.gaussian_model import GaussianModel
-    from scorp_amd.parallel import broadcast_tensors
+    from scorp_amd.parallel import all_ok, broadcast_tensors
     from scorp_amd.rasterizer3d import PairPolicy
     from scorp_amd.synthetic import make_gaussians, ring_cameras
     from scorp_amd.transforms import gaussians_rotate
@@ -296,11 +302,17 @@ def secondary_sweep(dev, cdev, rank, world):
     def prepare():
         shapes = dict(xyz=(n_obj, 3), scaling=(n_obj, 3), rotation=(n_obj, 4), opacity=(n_obj, 1), features_dc=(n_obj, 1, 3),
                       features_rest=(n_obj, 0, 3))
-        t = {k: torch.empty(shp, dtype=torch.float32, device=cdev) for k, shp in shapes.items()}
-        if rank == 0:
-            raw = make_gaussians(n_obj, 0, 4, extent=0.8, log_scale_mean=math.log(0.01))
-            raw["xyz"][:, 0] *= 1.6
-            t = {k: torch.tensor(raw[k], device=cdev).reshape(shapes[k]) for k in shapes}
+        t, gen_err = None, None
+        try:      # rank 0 draws the object: rank-local, may raise - agreed on BEFORE anyone enters the broadcast
+            t = {k: torch.empty(shp, dtype=torch.float32, device=cdev) for k, shp in shapes.items()}
+            if rank == 0:
+                raw = make_gaussians(n_obj, 0, 4, extent=0.8, log_scale_mean=math.log(0.01))
+                raw["xyz"][:, 0] *= 1.6
+                t = {k: torch.tensor(raw[k], device=cdev).reshape(shapes[k]) for k in shapes}
+        except Exception as e:   # noqa: BLE001
+            gen_err = e
+        if not all_ok(gen_err is None, cdev):
+            raise RuntimeError(f"object generation failed on some rank: {gen_err}")
         broadcast_tensors(t, src=0)
         obj = GaussianModel.from_raw({k: v.cpu().numpy() for k, v in t.items()}, 0, device=dev)
         cams = ring_cameras(15, 800, 800, 4, radius=3.0, device=dev)
@@ -396,6 +408,22 @@ def secondary_dp_train(dev, cdev, rank, world, backend):
     return guarded_record(prepare, run, cdev)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): start the N ranks as CHILD processes of
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` with the same arguments, relay their output (rank 0
+    prints the JSON line) and return the launcher's exit code.  Runs before this process has made any GPU call (no
+    torch.cuda.*, no _C.lib()); nothing replaces a running process with another."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,13 +451,16 @@ def main():
     ap.add_argument("--exact-backward", action="store_true", help="all-fp32 MFMA reduction in the blend backward (scorp_gs3d_backward_ex) instead of the fp16 two-term split")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))      # bare `python bench.py --gpus N`: this process only starts the N ranks (no GPU call made here)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev_index = 0 if args.single_device else local_rank
     torch.cuda.set_device(dev_index)
@@ -667,6 +698,11 @@ def main():
         gathered = [torch.zeros_like(ll) for _ in range(world)]
         dist.all_gather(gathered, ll)     # gather of per-rank results (scalars)
 
+    # view 0 of the UNTRAINED parameters for the full-size parity figures (the training extra below moves the model)
+    hip_view0 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not surfels:
+        with torch.no_grad():
+            hip_view0 = render(my_cams[0], model, pipe, bg)["render"].cpu().numpy()
     # extra (not part of `value`), N = 1: FULL training iterations on the same model and cameras - the one-call view, the
     # per-view densification statistics (scorp_densification_stats) and the guarded FusedAdam step over all 59 parameters
     # per Gaussian (train_3dgs.py:74-193 / train_2dgs.py without the densification itself, which runs every 100th iteration)
@@ -713,6 +749,7 @@ def main():
         secondary["post_refine_4obj"] = secondary_post_refine_objects(dev, cdev, rank, world)
         if world > 1:
             secondary["dp_train"] = secondary_dp_train(dev, cdev, rank, world, args.backend)
+    parity_failed = False
     if rank == 0:
         views = args.steps * world
         value = views / dt
@@ -786,9 +823,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cpu_rec, orc = cpu_baseline(raw, my_cams[0].to("cpu"), deg, W, H)
             line["parity"] = small_parity(dev)
+            my_cams[0].to(dev)     # (.to() moves in place)
             if not surfels:   # the same full-size view, HIP against the CPU oracle the baseline just rendered
-                with torch.no_grad():
-                    hip = render(my_cams[0].to(dev), model, pipe, bg)["render"].cpu().numpy()   # (.to() moves in place)
+                hip = hip_view0
                 mse = float(((hip - orc.color) ** 2).mean())
                 # ... and the gradients of the oracle's backward pass (same inputs, same upstream gradient), per tensor
                 # relative L1 (north_star's norm; asserted < 1e-4 in tests/test_fullsize_gpu.py) and max-norm, through the
@@ -802,6 +839,10 @@ def main():
                                                    psnr_db=(99.0 if mse == 0 else round(float(10 * math.log10(1.0 / mse)), 1)),
                                                    grad_rel_l1={k: _sig(v[1]) for k, v in errs.items()},
                                                    grad_max_rel_err={k: _sig(v[0]) for k, v in errs.items()})
+                # north_star's tolerance, checked here as well as in tests/test_fullsize_gpu.py: the line says so itself
+                line["parity_ok"] = bool(line["parity"]["full_size"]["l1"] < 1e-4 and all(v[1] < 1e-4 for v in errs.values()))
+                if not line["parity_ok"]:
+                    print("[bench] full-size parity outside 1e-4: " + json.dumps(line["parity"]["full_size"]), file=sys.stderr)
         if world == 1 and args.scene == "S3" and not args.no_secondary and not args.exact_backward:
             try:
                 secondary["S6"] = secondary_s6(dev, parity=not args.no_cpu_baseline)
@@ -820,12 +861,15 @@ def main():
         if cpu_rec is not None:
             line["cpu_baseline"] = cpu_rec
         print(json.dumps(line, separators=(",", ":")), flush=True)
+        parity_failed = line.get("parity_ok") is False
     if world > 1:
         try:
             dist.barrier()
             dist.destroy_process_group()
         except Exception as e:   # noqa: BLE001   (the line is out; a broken group must not turn the run into a failure)
             print(f"[bench] process group teardown: {type(e).__name__}: {e}", file=sys.stderr)
+    if parity_failed:
+        sys.exit(3)     # the line is out (with "parity_ok": false); a run whose renders miss the oracle is not a success
 
 
 if __name__ == "__main__":

@@ -400,6 +400,12 @@ int scorp_adam_step_guarded(const ScorpAdamTensor *tensors, int32_t num_tensors,
 int scorp_densification_stats(int32_t num_gaussians, const int32_t *radii, const uint8_t *visible, const float *grad_means2D,
                               int32_t grad_stride, const uint32_t *skip_if_nonzero, float *max_radii2D,
                               float *xyz_gradient_accum, float *denom, scorp_stream_t stream);
+/* The same with the gradient norm taken over `norm_components` (2 or 3) leading floats of a row: the 2DGS model's
+ * add_densification_stats norms the WHOLE means2D gradient row (gs2dgs/scene/gaussian_model.py:494-495), the 3DGS one
+ * only x, y (gs3dgs/scene/gaussian_model.py:603-605).  scorp_densification_stats is this with norm_components = 2. */
+int scorp_densification_stats_ex(int32_t num_gaussians, const int32_t *radii, const uint8_t *visible, const float *grad_means2D,
+                                 int32_t grad_stride, int32_t norm_components, const uint32_t *skip_if_nonzero,
+                                 float *max_radii2D, float *xyz_gradient_accum, float *denom, scorp_stream_t stream);
 
 /* ---- densify / prune compaction (row f2 of the hot-path scope; gs3dgs/scene/gaussian_model.py:412-601) ----
  * Re-indexes up to SCORP_ROWS_MAX_TENSORS row-major float tensors in one launch: dst row j = src row

@@ -69,7 +69,7 @@ EXPORTS = [
     "scorp_gs3d_render_image",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_backward_ex", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles", "scorp_gs3d_debug_work",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
-    "scorp_knn_dist2", "scorp_gaussians_transform", "scorp_adam_step", "scorp_adam_step_guarded", "scorp_densification_stats", "scorp_gather_rows", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
+    "scorp_knn_dist2", "scorp_gaussians_transform", "scorp_adam_step", "scorp_adam_step_guarded", "scorp_densification_stats", "scorp_densification_stats_ex", "scorp_gather_rows", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
     "scorp_gs3d_pose_score_accumulate",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
     "scorp_gs2d_render_image",
@@ -154,6 +154,7 @@ def lib():
                                           i32, vp, vp]
     L.scorp_gather_rows.argtypes = [ctypes.POINTER(ScorpRowTensor), i32, vp, u64, vp]
     L.scorp_densification_stats.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.scorp_densification_stats_ex.argtypes = [i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.scorp_prof_enable.argtypes = [ctypes.c_int]
     L.scorp_prof_select.argtypes = [u64]
     L.scorp_prof_kernel_name.restype = ctypes.c_char_p

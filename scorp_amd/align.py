@@ -267,17 +267,11 @@ class SweepPlan:
         return out
 
 
-@contextlib.contextmanager
-def _together(dev, what):
-    """The local part of a sharded unit of work, in front of its exchange step: an exception on ANY rank is raised on
-    EVERY rank (parallel.all_ok: one 4-byte all-reduce) instead of leaving the others waiting in the all-gather."""
-    from .parallel import all_ok
-    err = None
-    try:
-        yield
-    except Exception as e:   # noqa: BLE001
-        err = e
-    if not all_ok(err is None, dev):
+def _raise_together(failed_rows, err, what):
+    """A rank whose local part failed sends NaN rows into the exchange it would otherwise have skipped: the all-gather is
+    entered by everyone (nobody waits for a rank that never arrives), the success path has no extra collective and no
+    extra host synchronisation, and the NaNs - checked where the result is read anyway - raise on EVERY rank."""
+    if err is not None or bool(failed_rows):
         raise RuntimeError(f"{what}: the local part failed on " + ("this rank" if err is not None else "another rank")) from err
 
 
@@ -289,13 +283,17 @@ def align_objects(models, rotations, cameras, targets_per_object, bg, render_fn=
     from .parallel import gather_results, shard_indices
     dev = models[0]._xyz.device
     mine = shard_indices(len(models))
-    rows = []
-    with _together(dev, "align_objects"):
+    rows, err = [], None
+    try:
         for j in mine:
             _, fit, best = rotation_sweep(models[j], rotations, cameras, targets_per_object[j], bg, render_fn=render_fn, shard=False)
             rows.append(torch.stack([torch.tensor(float(best), device=fit.device), fit[best, 0].float()]))
+    except Exception as e:   # noqa: BLE001   (raised below, on every rank, behind the exchange)
+        err, rows = e, [torch.full((2,), float("nan"), device=dev) for _ in mine]
     v = torch.stack(rows) if rows else torch.zeros((0, 2), dtype=torch.float32, device=dev)
     _, vals = gather_results(mine, v.to(dev), n_total=len(models))
+    vals = vals.cpu()                   # the one synchronisation of the call: the results are read here
+    _raise_together(torch.isnan(vals).any(), err, "align_objects")
     return [(int(vals[j, 0]), float(vals[j, 1])) for j in range(len(models))]
 
 
@@ -312,11 +310,20 @@ def rotation_sweep(model, rotations, cameras, targets, bg, use_graph=None, plan=
         scores = torch.stack(plan.score(rotations, ids)) if ids else torch.zeros((0, 1), dtype=torch.float32, device=dev)
         return torch.arange(len(ids), device=scores.device), scores, (int(torch.argmax(scores[:, 0])) if ids else -1)
     mine = shard_indices(len(rotations))
-    with _together(dev, "rotation_sweep"):
+    err = None
+    try:
         if plan is None:
             plan = SweepPlan(model, cameras, targets, bg, use_graph=use_graph, render_fn=render_fn)
         vals = plan.score(rotations, mine) if mine else []
+    except Exception as e:   # noqa: BLE001   (raised below, on every rank, behind the exchange)
+        err, vals = e, [torch.full((1,), float("nan"), device=dev) for _ in mine]
     v = torch.stack(vals) if vals else torch.zeros((0, 1), dtype=torch.float32, device=dev)
     ids, scores = gather_results(mine, v.to(dev), n_total=len(rotations))      # ONE fixed-size all-gather, no host sync
-    best = int(ids[torch.argmax(scores[:, 0])]) if ids.numel() else -1
+    if not ids.numel():
+        _raise_together(False, err, "rotation_sweep")
+        return ids, scores, -1
+    # (a failed rank's rows are NaN: one reduction tells, in the same device-to-host read that fetches the arg-max)
+    best, bad = (int(x) for x in torch.stack([ids[torch.argmax(torch.nan_to_num(scores[:, 0], nan=-float("inf")))].long(),
+                                              torch.isnan(scores).any().long()]).tolist())
+    _raise_together(bad, err, "rotation_sweep")
     return ids, scores, best

@@ -264,15 +264,17 @@ namespace {
 // train_3dgs.py:180-181 for one view: the three masked updates as one pass over the Gaussians
 __global__ void __launch_bounds__(256)
 densification_stats_kernel(int N, const int32_t *__restrict__ radii, const uint8_t *__restrict__ visible,
-                           const float *__restrict__ grad, int stride, const uint32_t *__restrict__ skip_if_nonzero,
+                           const float *__restrict__ grad, int stride, int norm3, const uint32_t *__restrict__ skip_if_nonzero,
                            float *__restrict__ max_radii2D, float *__restrict__ accum, float *__restrict__ denom) {
 #pragma clang fp contract(off)
   if (skip_if_nonzero && *skip_if_nonzero) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N || !visible[i]) return;
   const float gx = grad[(size_t)i * stride], gy = grad[(size_t)i * stride + 1];
+  // the 2DGS model takes the norm over the whole row (gs2dgs/scene/gaussian_model.py:494-495), the 3DGS one over x, y
+  const float gz = norm3 ? grad[(size_t)i * stride + 2] : 0.0f;
   max_radii2D[i] = fmaxf(max_radii2D[i], (float)radii[i]);
-  accum[i] += sqrtf(gx * gx + gy * gy);
+  accum[i] += sqrtf(gx * gx + gy * gy + gz * gz);
   denom[i] += 1.0f;
 }
 }  // namespace
@@ -281,14 +283,24 @@ densification_stats_kernel(int N, const int32_t *__restrict__ radii, const uint8
 extern "C" int scorp_densification_stats(int32_t N, const int32_t *radii, const uint8_t *visible, const float *grad_means2D,
                                          int32_t grad_stride, const uint32_t *skip_if_nonzero, float *max_radii2D,
                                          float *xyz_gradient_accum, float *denom, scorp_stream_t stream_) {
-  if (N < 0 || grad_stride < 2) { set_error("scorp_densification_stats: N=%d, grad_stride=%d", N, grad_stride); return SCORP_ERR_INVALID; }
+  return scorp_densification_stats_ex(N, radii, visible, grad_means2D, grad_stride, 2, skip_if_nonzero, max_radii2D,
+                                      xyz_gradient_accum, denom, stream_);
+}
+
+extern "C" int scorp_densification_stats_ex(int32_t N, const int32_t *radii, const uint8_t *visible, const float *grad_means2D,
+                                            int32_t grad_stride, int32_t norm_components, const uint32_t *skip_if_nonzero,
+                                            float *max_radii2D, float *xyz_gradient_accum, float *denom, scorp_stream_t stream_) {
+  if (N < 0 || (norm_components != 2 && norm_components != 3) || grad_stride < norm_components) {
+    set_error("scorp_densification_stats: N=%d, grad_stride=%d, norm_components=%d", N, grad_stride, norm_components);
+    return SCORP_ERR_INVALID;
+  }
   if (N == 0) return SCORP_OK;
   if (!radii || !visible || !grad_means2D || !max_radii2D || !xyz_gradient_accum || !denom) {
     set_error("scorp_densification_stats: NULL pointer"); return SCORP_ERR_INVALID;
   }
   hipStream_t stream = (hipStream_t)stream_;
-  densification_stats_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, radii, visible, grad_means2D, grad_stride, skip_if_nonzero,
-                                                                 max_radii2D, xyz_gradient_accum, denom);
+  densification_stats_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, radii, visible, grad_means2D, grad_stride, norm_components == 3,
+                                                                 skip_if_nonzero, max_radii2D, xyz_gradient_accum, denom);
   SCORP_KERNEL_CHECK("densification_stats", 0, stream);
   return SCORP_OK;
 }

@@ -14,8 +14,18 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
         # Optional 1-element int32 device tensor: the NEXT step() updates nothing if it is non-zero when the kernel runs
         # (scorp_adam_step_guarded).  train() sets it to the overflow word of a view rendered with a reserved pair buffer;
-        # step() consumes it.  (The host-side step counter still advances: one bias-correction step, immaterial.)
+        # step() consumes it.  The host-side step counter advances regardless (the host does not know yet); whoever reads
+        # the overflow words later (train._drain_reservation) takes the skipped steps back with rollback_steps().
         self.skip_flag = None
+        self._stepped = []
+
+    def rollback_steps(self, n=1):
+        """`n` of the steps taken so far were skipped on the device (guarded by a non-zero overflow word): take them out of
+        every parameter's bias-correction counter, so that the next update is scaled as torch.optim.Adam would scale it."""
+        if n <= 0:
+            return
+        for st in self._stepped:       # (the parameters the last step() advanced: frozen leaves keep their counters)
+            st["step"] -= min(float(n), float(st["step"]))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -24,7 +34,7 @@ class FusedAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         L = _C.lib()
-        by_cfg = {}
+        by_cfg, stepped = {}, []
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
@@ -37,8 +47,10 @@ class FusedAdam(torch.optim.Adam):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
+                stepped.append(st)
                 key = (group["betas"], group["eps"], int(st["step"]))
                 by_cfg.setdefault(key, []).append((p, p.grad.contiguous(), st, float(group["lr"])))
+        self._stepped = stepped
         stream = ctypes.c_void_p(_C.current_stream_ptr())
         skip, self.skip_flag = self.skip_flag, None
         skip_ptr = None if skip is None else ctypes.c_void_p(skip.data_ptr())

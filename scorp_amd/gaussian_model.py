@@ -481,6 +481,8 @@ class GaussianModel:
             prune = prune | (self.max_radii2D > max_screen_size) | (self.get_scaling.max(dim=1).values > 0.1 * extent)
         self.prune_points(prune)
 
+    _stats_norm_components = 2     # add_densification_stats below norms grad[:, :2] (gs3dgs/scene/gaussian_model.py:603-605)
+
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         """Accumulates |dL/d(ndc xy)| of the visible splats — this is what pins the scale of the means2D gradient."""
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
@@ -496,6 +498,16 @@ class GaussianModel:
         0.75 ms).  On the GPU this is ONE launch of scorp_densification_stats (no compaction, no synchronisation; nothing
         happens if the device word `skip_flag` is non-zero); elsewhere the same update written with torch.where."""
         grad = viewspace_point_tensor.grad
+        # the fused update restates add_densification_stats: valid only for the class that DEFINES the method in use and
+        # declares, next to it, over how many components of a means2D-gradient row its norm runs
+        owner = next(c for c in type(self).__mro__ if "add_densification_stats" in c.__dict__)
+        nc = owner.__dict__.get("_stats_norm_components")
+        if nc is None:
+            # a subclass with its own add_densification_stats: the reference's sequence, through the override
+            f = update_filter if skip_flag is None else update_filter & (skip_flag.reshape(-1)[0] == 0)
+            self.max_radii2D[f] = torch.max(self.max_radii2D[f], radii[f].to(self.max_radii2D.dtype))
+            self.add_densification_stats(viewspace_point_tensor, f)
+            return
         if self.max_radii2D.is_cuda:
             import ctypes
             from . import _C
@@ -504,18 +516,19 @@ class GaussianModel:
             f = update_filter if update_filter.is_contiguous() else update_filter.contiguous()
             f = f.view(torch.uint8) if f.dtype == torch.bool else f.to(torch.uint8)
             n = self.max_radii2D.shape[0]
-            assert g.shape[0] == n and r.shape[0] == n and f.shape[0] == n and g.shape[1] >= 2
+            assert g.shape[0] == n and r.shape[0] == n and f.shape[0] == n and g.shape[1] >= nc
             assert self.max_radii2D.dtype == torch.float32 and self.max_radii2D.is_contiguous()
             assert self.xyz_gradient_accum.is_contiguous() and self.denom.is_contiguous()
             vp = ctypes.c_void_p
-            _C.check(_C.lib().scorp_densification_stats(
-                n, vp(r.data_ptr()), vp(f.data_ptr()), vp(g.data_ptr()), g.stride(0),
+            _C.check(_C.lib().scorp_densification_stats_ex(
+                n, vp(r.data_ptr()), vp(f.data_ptr()), vp(g.data_ptr()), g.stride(0), nc,
                 vp(skip_flag.data_ptr()) if skip_flag is not None else None, vp(self.max_radii2D.data_ptr()),
                 vp(self.xyz_gradient_accum.data_ptr()), vp(self.denom.data_ptr()),
                 vp(_C.current_stream_ptr())), "scorp_densification_stats")
             return
         f = update_filter if skip_flag is None else update_filter & (skip_flag.reshape(-1)[0] == 0)
         self.max_radii2D = torch.where(f, torch.maximum(self.max_radii2D, radii.to(self.max_radii2D.dtype)), self.max_radii2D)
-        norm = torch.sqrt(grad[:, 0:1] * grad[:, 0:1] + grad[:, 1:2] * grad[:, 1:2])
+        norm = torch.sqrt((grad[:, :nc] * grad[:, :nc]).sum(-1, keepdim=True)) if nc == 3 else \
+            torch.sqrt(grad[:, 0:1] * grad[:, 0:1] + grad[:, 1:2] * grad[:, 1:2])
         self.xyz_gradient_accum += torch.where(f.unsqueeze(-1), norm, torch.zeros_like(norm))
         self.denom += f.unsqueeze(-1).to(self.denom.dtype)

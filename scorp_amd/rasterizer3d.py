@@ -46,6 +46,14 @@ class _Pending:
         return self.header.numel()
 
 
+class PairOverflow(RuntimeError):
+    """Raised by PairPolicy.drain(): `count` pending views had overflowed their reserved pair buffer (each was discarded on
+    the device: no optimizer step, no statistics)."""
+    def __init__(self, msg, count):
+        super().__init__(msg)
+        self.count = int(count)
+
+
 class PairPolicy:
     """How the (tile,splat) pair buffer is sized.
 
@@ -128,7 +136,7 @@ class PairPolicy:
     def drain(cls):
         """Verify every forward issued in "reserve" mode since the last drain (each on its own stream's event)."""
         pend, cls._pending = cls._pending, []
-        worst = 0
+        worst, n_over = 0, 0
         err = None
         if not pend:
             return worst
@@ -157,10 +165,13 @@ class PairPolicy:
                 cls._ctx[p.key] = (max(got, need), p.n if p.n > 0 else n0)   # (re-inserted last: most recently learned)
                 while len(cls._ctx) > cls._MAX_CTX:
                     cls._ctx.pop(next(iter(cls._ctx)))
-            if overflow and err is None:
-                err = f"pair buffer overflow: {n} pairs needed, capacity {capacity}"
+            if overflow:
+                n_over += 1
+                if err is None:
+                    err = f"pair buffer overflow: {n} pairs needed, capacity {capacity}"
         if err:
-            raise RuntimeError(f"pair reservation too small ({err}); the context's reservation has been grown, re-run the view(s)")
+            raise PairOverflow(f"pair reservation too small ({err}; {n_over} of {len(pend)} pending views); the context's "
+                               "reservation has been grown, re-run the view(s)", n_over)
         return worst
 
     @classmethod

@@ -166,6 +166,8 @@ class GaussianModel2D(GaussianModel):
         self._features_rest = P(feats[:, :, 1:].transpose(1, 2))
         self.max_radii2D = torch.zeros(pts.shape[0], device=self.device)
 
+    _stats_norm_components = 3     # the norm below runs over the WHOLE row (gs2dgs/scene/gaussian_model.py:494-495)
+
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter], dim=-1, keepdim=True)
         self.denom[update_filter] += 1

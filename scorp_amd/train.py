@@ -138,7 +138,7 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
                 if fused_view:
                     # the reservation context keeps pairs PER GAUSSIAN, so the resized model starts from a scaled
                     # reservation; drain now so that it is also the freshest figure (one event wait per 100 iterations)
-                    _drain_reservation()
+                    _drain_reservation(optimizer=gaussians.optimizer)
             if iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter):
                 gaussians.reset_opacity()   # train_3dgs.py:187-188
         gaussians.optimizer.step()
@@ -176,16 +176,16 @@ def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, backgr
             # If it overflowed it was discarded on the device and the reservation has grown: the same views run again,
             # instead of a context's default being wrong for every iteration up to the first periodic drain.
             retries += 1
-            first_checked = _drain_reservation(quiet=retries < 3) or data_parallel or retries >= 3   # (data-parallel replicas must not diverge in their camera order)
+            first_checked = _drain_reservation(quiet=retries < 3, optimizer=gaussians.optimizer) or data_parallel or retries >= 3   # (data-parallel replicas must not diverge in their camera order)
             if not first_checked:
                 stack.extend(reversed(ks))
                 continue
         losses.append(loss.detach())
         if kw.get("fused_view") and it % 32 == 0:
-            _drain_reservation()
+            _drain_reservation(optimizer=gaussians.optimizer)
         it += 1
     if kw.get("fused_view"):
-        _drain_reservation()
+        _drain_reservation(optimizer=gaussians.optimizer)
     return _to_floats(losses)
 
 
@@ -197,15 +197,21 @@ def _to_floats(losses):
     return torch.stack([l.reshape(()) for l in losses]).tolist()
 
 
-def _drain_reservation(quiet=False):
+def _drain_reservation(quiet=False, optimizer=None):
     """Fused views reserve their pair buffer instead of asking for the count.  A view that overflowed its reservation was
     blended from truncated tile lists (nothing is written out of bounds) and was DISCARDED on the device: its optimizer
     step was skipped and it did not enter the densification statistics (training_iteration).  drain() has grown the
-    reservation; training goes on, the user is told how that happened.  Returns False if a view had overflowed."""
+    reservation; training goes on, the user is told how that happened.  Returns False if a view had overflowed.
+
+    `optimizer`: FusedAdam counted a bias-correction step on the host for every view, the discarded ones included; they
+    are taken back here (rollback_steps), so that the updates after a retry are scaled as those of a run that never
+    overflowed (a first-view overflow is an expected event: the default reservation is four pairs per Gaussian)."""
     try:
         PairPolicy.drain()
         return True
     except RuntimeError as e:
+        if optimizer is not None and hasattr(optimizer, "rollback_steps"):
+            optimizer.rollback_steps(getattr(e, "count", 1))
         if not quiet:
             import warnings
             warnings.warn(f"train(fused_view=True): {e}; the overflowed views were skipped (no optimizer step, no statistics)")
@@ -256,16 +262,16 @@ def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, p
             # the first one-call view sizes the pair reservation (see train()): checked at once, run again if it overflowed
             # (objects that fill the screen need more than the default four pairs per Gaussian)
             retries += 1
-            sized = _drain_reservation(quiet=retries < 3) or retries >= 3
+            sized = _drain_reservation(quiet=retries < 3, optimizer=gaussians.optimizer) or retries >= 3
             if not sized:
                 stack.append(k)
                 continue
         losses.append(loss.detach())
         if fused_view and it % 32 == 0:
-            _drain_reservation()
+            _drain_reservation(optimizer=gaussians.optimizer)
         it += 1
     if fused_view:
-        _drain_reservation()
+        _drain_reservation(optimizer=gaussians.optimizer)
     return _to_floats(losses)
 
 

@@ -401,3 +401,45 @@ def test_view_statistics_kernel_equals_the_masked_indexing(dev):
     assert torch.equal(ours.max_radii2D, ref_max) and torch.equal(ours.denom, ref_den)
     torch.testing.assert_close(ours.xyz_gradient_accum, ref_acc, rtol=1e-6, atol=0)
     assert float(ref_den.max()) == 2.0 and float(ref_den.min()) == 0.0
+
+
+def test_view_statistics_of_the_surfel_model_norm_the_whole_row(dev):
+    """The 2DGS model's add_densification_stats takes the norm over all three components of a means2D-gradient row
+    (gs2dgs/scene/gaussian_model.py:494-495); the fused update (scorp_densification_stats_ex, norm_components = 3) must
+    do the same, and a subclass that overrides add_densification_stats must be served by ITS method."""
+    from scorp_amd.gaussian_model import OptimizationParams2D
+    from scorp_amd.renderer2d import GaussianModel2D
+    from scorp_amd.synthetic import make_gaussians
+    n = 5003
+    g = torch.Generator(device="cpu").manual_seed(8)
+
+    class VS:
+        pass
+
+    class Custom(GaussianModel2D):
+        def add_densification_stats(self, viewspace_point_tensor, update_filter):     # anything else: here the L1 norm
+            self.xyz_gradient_accum[update_filter] += viewspace_point_tensor.grad[update_filter].abs().sum(-1, keepdim=True)
+            self.denom[update_filter] += 1
+
+    raw = make_gaussians(n, 1, 3, scale_dims=2)
+    ours, custom = GaussianModel2D.from_raw(raw, 1, device=dev), Custom.from_raw(raw, 1, device=dev)
+    for m in (ours, custom):
+        m.training_setup(OptimizationParams2D())
+    ref_max, ref_acc, ref_den = ours.max_radii2D.clone(), ours.xyz_gradient_accum.clone(), ours.denom.clone()
+    ref_l1 = ref_acc.clone()
+    for view in range(2):
+        vs = VS()
+        vs.grad = torch.randn(n, 3, generator=g).to(dev) * 1e-3      # a z component that is NOT zero
+        radii = torch.randint(0, 40, (n,), generator=g, dtype=torch.int32).to(dev)
+        vis = (radii > 0) & (torch.rand(n, generator=g).to(dev) > 0.3)
+        ours.accumulate_view_stats(vs, vis, radii)
+        custom.accumulate_view_stats(vs, vis, radii)
+        ref_max[vis] = torch.max(ref_max[vis], radii[vis].float())
+        ref_acc[vis] += torch.norm(vs.grad[vis], dim=-1, keepdim=True)
+        ref_l1[vis] += vs.grad[vis].abs().sum(-1, keepdim=True)
+        ref_den[vis] += 1
+    torch.cuda.synchronize()
+    for m in (ours, custom):
+        assert torch.equal(m.max_radii2D, ref_max) and torch.equal(m.denom, ref_den)
+    torch.testing.assert_close(ours.xyz_gradient_accum, ref_acc, rtol=1e-6, atol=0)
+    torch.testing.assert_close(custom.xyz_gradient_accum, ref_l1, rtol=1e-6, atol=0)

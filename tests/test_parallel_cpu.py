@@ -294,6 +294,41 @@ def test_rotation_sweep_itself_on_two_gloo_ranks():
         assert r[4] == best1 == 7
 
 
+def _failing_sweep_worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from scorp_amd.align import rotation_sweep
+        obj, rots, cams, targets = _sweep_setup()
+
+        def render_fn(cam, pc, pipe, bg, **kw):
+            if rank == 1:
+                raise ValueError("rank 1 cannot render")
+            return _standin_render(cam, pc, pipe, bg, **kw)
+        try:
+            rotation_sweep(obj, rots, cams, targets, torch.zeros(3), use_graph=False, render_fn=render_fn)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_raises_on_every_rank_of_the_sweep():
+    """A rank whose local scoring fails still enters the sweep's one all-gather (with NaN rows), so nobody waits for it,
+    and the failure is raised on BOTH ranks - with no agreement collective and no host synchronisation on the success path."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_sweep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert "another rank" in res[0] and "this rank" in res[1], res
+
+
 def test_sh_rotation_blocks_match_the_independent_wigner_table():
     """scorp_amd.transforms.sh_rotation_blocks (a least-squares fit on sampled directions) against tests/golden/wigner_d.npz,
     generated by tests/golden/make_wigner_golden.py from the Ivanic-Ruedenberg recurrence AND by quadrature (the two agree

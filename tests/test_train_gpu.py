@@ -229,6 +229,45 @@ def test_overflowed_fused_view_is_discarded_on_the_device(dev):
         PairPolicy.reset()
 
 
+def test_first_view_overflow_retry_equals_a_presized_run(dev):
+    """train() / post_refine() verify the first fused view at once and run it again when it overflowed its reservation.
+    The discarded attempt must leave nothing behind - FusedAdam's bias-correction counter included (it advances on the
+    host even when the device skipped the update): under the deterministic backward the parameters after a run that
+    starts with an overflow are the SAME BITS as those of a run whose reservation was large enough from the start."""
+    import warnings
+    from scorp_amd import rasterizer3d as R
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams, train
+    raw = make_gaussians(3000, 1, 4, log_scale_mean=math.log(0.05))
+    cams = ring_cameras(3, 128, 96, 2, radius=3.0, device=dev)
+    gts = [torch.rand(3, 96, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(k)) for k in range(3)]
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    res = []
+    try:
+        with R.backward_precision("deterministic"):
+            for too_small in (False, True):
+                PairPolicy.reset()
+                PairPolicy.mode = "reserve"
+                m = GaussianModel.from_raw(raw, 1, device=dev)
+                m.active_sh_degree = 1
+                opt = OptimizationParams()
+                opt.random_background, opt.densify_from_iter = False, 1 << 30
+                m.training_setup(opt)
+                PairPolicy.set_context(3000, 96, 128, 64 if too_small else 1 << 20)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    train(m, cams, gts, opt, PipelineParams(), iterations=5, background=torch.zeros(3, device=dev), fused_view=True)
+                steps = {float(st["step"]) for st in m.optimizer.state.values()}
+                assert steps == {5.0}, steps
+                res.append([getattr(m, n).detach().clone() for n in names])
+    finally:
+        PairPolicy.reset()
+    for n, a, b in zip(names, *res):
+        assert torch.equal(a, b), n
+
+
 def test_reserve_mode_pends_headers_not_states_and_train_view_checks_its_buffers(dev):
     """What a reserve-mode view leaves pending until drain() is a copy of the 64-byte state header (a whole forward state
     per pending view pinned ~110 MB each at 1 M Gaussians); and scorp_gs3d_train_view refuses bad buffers with a message
