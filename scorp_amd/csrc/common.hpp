@@ -21,6 +21,11 @@ constexpr float kAlphaMax = 0.99f;
 constexpr float kLog2AlphaMax = -0.014499569695115089f;   // log2(kAlphaMax): only a splat with log2(opacity) above it can reach the clamp
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTMin = 0.0001f;
+// `alpha >= 1/255` decided from the exponent: v_exp_f32 is non-decreasing across the threshold - scripts/mb_exp_threshold.hip
+// evaluates EVERY float in [-126, 0] and finds ONE step, at this value (profiles/r05_mb_exp_threshold.txt) - so
+//     __builtin_amdgcn_exp2f(e) >= kAlphaMin   <=>   e >= kExp2AlphaMin        for every float e (NaN: false on both sides),
+// the same bits, and the blend kernels know which pixels a hit is live on before (and without) taking the v_exp.
+constexpr uint32_t kExp2AlphaMinBits = 0xC0FFD1BEu;   // -7.99435329
 constexpr float kWEps = 0.0000001f;
 constexpr float kDet2Eps = 0.0000001f;
 

@@ -690,7 +690,7 @@ __device__ unsigned long long g_fwd_trace[3 * 40000];
 #ifdef SCORP_FWD_STATS
 // diagnostic build only (scripts/dev/stats_forward.py): how full the 64 lanes are per blended hit, and how many
 // iterations a wave would run if its hits were listed per 8x4 half / per 4x4 quadrant / per pixel instead of per block
-__device__ unsigned long long g_fwd_stats[9];
+__device__ unsigned long long g_fwd_stats[12];
 #endif
 template <bool kForBackward>
 __global__ void __launch_bounds__(64, SCORP_FWD_WAVES)
@@ -750,6 +750,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   uint32_t hot_end = 0;      // hits [0, hot_end) may hold a splat with opacity > 0.99 (wave-uniform; see blend_group)
 #ifdef SCORP_FWD_STATS
   uint32_t st_hits = 0, st_live = 0, st_any = 0, st_q[4] = {0, 0, 0, 0}, st_h[2] = {0, 0}, st_lane = 0, st_pairs = 0;
+  uint32_t st_g16 = 0, st_g64 = 0, st_g8 = 0, st_gq[4] = {0, 0, 0, 0}, st_cq[4] = {0, 0, 0, 0}, st_hq[4] = {0, 0, 0, 0}, st_cn = 0;
   uint64_t st_prev = 0;
   bool st_have = false;
 #endif
@@ -857,6 +858,17 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
             st_q[2] += (m & 0x0F0F0F0F00000000ull) != 0; st_q[3] += (m & 0xF0F0F0F000000000ull) != 0;
             st_h[0] += (m & 0x00000000FFFFFFFFull) != 0; st_h[1] += (m & 0xFFFFFFFF00000000ull) != 0;
             st_lane += (ok & live) ? 1u : 0u;
+            // lock-step cost of per-quadrant lists when the four lists are synchronised every 8 / 16 / 64 block hits
+            // (the backward's matrix pass holds a fixed number of slots): sum over such windows of the largest quadrant count
+            if (m != 0) {
+              const uint32_t qb[4] = {(m & 0x000000000F0F0F0Full) != 0, (m & 0x00000000F0F0F0F0ull) != 0,
+                                      (m & 0x0F0F0F0F00000000ull) != 0, (m & 0xF0F0F0F000000000ull) != 0};
+              for (int q_ = 0; q_ < 4; q_++) { st_gq[q_] += qb[q_]; st_cq[q_] += qb[q_]; st_hq[q_] += qb[q_]; }
+              st_cn += 1;
+              if ((st_cn & 7) == 0) { st_g8 += max(max(st_hq[0], st_hq[1]), max(st_hq[2], st_hq[3])); st_hq[0] = st_hq[1] = st_hq[2] = st_hq[3] = 0; }
+              if ((st_cn & 15) == 0) { st_g16 += max(max(st_gq[0], st_gq[1]), max(st_gq[2], st_gq[3])); st_gq[0] = st_gq[1] = st_gq[2] = st_gq[3] = 0; }
+              if ((st_cn & 63) == 0) { st_g64 += max(max(st_cq[0], st_cq[1]), max(st_cq[2], st_cq[3])); st_cq[0] = st_cq[1] = st_cq[2] = st_cq[3] = 0; }
+            }
             // greedy pairing of ADJACENT hits whose live lanes are disjoint (no pixel sees both: they could share an iteration)
             if (st_have && (st_prev & m) == 0) { st_pairs += 1; st_have = false; }
             else { st_prev = m; st_have = true; }
@@ -927,6 +939,9 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       atomicAdd(&g_fwd_stats[6], (unsigned long long)max(st_h[0], st_h[1]));
       atomicAdd(&g_fwd_stats[7], (unsigned long long)lm);
       atomicAdd(&g_fwd_stats[8], (unsigned long long)st_pairs);
+      atomicAdd(&g_fwd_stats[9], (unsigned long long)(st_g8 + max(max(st_hq[0], st_hq[1]), max(st_hq[2], st_hq[3]))));
+      atomicAdd(&g_fwd_stats[10], (unsigned long long)(st_g16 + max(max(st_gq[0], st_gq[1]), max(st_gq[2], st_gq[3]))));
+      atomicAdd(&g_fwd_stats[11], (unsigned long long)(st_g64 + max(max(st_cq[0], st_cq[1]), max(st_cq[2], st_cq[3]))));
     }
   }
 #endif
@@ -1248,9 +1263,9 @@ extern "C" int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint
 
 #ifdef SCORP_FWD_STATS
 extern "C" int scorp_debug_fwd_stats(unsigned long long *out, int reset) {
-  static const unsigned long long zero[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scorp::g_fwd_stats), 72) != hipSuccess) return -2;
-  return reset && hipMemcpyToSymbol(HIP_SYMBOL(scorp::g_fwd_stats), zero, 72) != hipSuccess ? -2 : 0;
+  static const unsigned long long zero[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(scorp::g_fwd_stats), 96) != hipSuccess) return -2;
+  return reset && hipMemcpyToSymbol(HIP_SYMBOL(scorp::g_fwd_stats), zero, 96) != hipSuccess ? -2 : 0;
 }
 #endif
 #ifdef SCORP_FWD_TRACE
