@@ -448,7 +448,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary record (the 2DGS workload S6) of the default N=1 run")
     ap.add_argument("--lead-in", type=int, default=40, help="untimed views enqueued in front of the warm-up of every timed run (see timed_run)")
     ap.add_argument("--no-twins", action="store_true", help="skip the two extra timed runs (all-fp32 backward, deterministic backward): profiling passes")
-    ap.add_argument("--exact-backward", action="store_true", help="all-fp32 MFMA reduction in the blend backward (scorp_gs3d_backward_ex) instead of the fp16 two-term split")
+    ap.add_argument("--exact-backward", action="store_true", help="(kept for old command lines: the all-fp32 backward IS the headline now) also skips the secondary records")
+    ap.add_argument("--split-backward", action="store_true",
+                    help="headline = the library's default backward (two-term fp16 split of the pixel->splat reduction, 22 mantissa bits) "
+                         "instead of the all-fp32 one")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -540,7 +543,12 @@ def main():
     # form of training, or multi-view evaluation); the default, 1, is the reference's one-view-at-a-time loop
     side_streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
 
-    if args.exact_backward:
+    # `value` is measured with the blend backward's pixel->splat reduction on fp32 MFMAs throughout (SCORP_BACKWARD_EXACT_FP32):
+    # every operand at fp32, as in the reference's arithmetic.  The library's DEFAULT form carries the two operands of that
+    # reduction as two fp16 terms each (22 mantissa bits, exact products, fp32 accumulation; parity-tested against the exact
+    # form and the oracle): faster, reported as `value_split22`, and the headline only with --split-backward.
+    headline_exact = fused_view and not args.split_backward
+    if headline_exact or args.exact_backward:
         R._tls.backward_flags = _C.BACKWARD_EXACT_FP32     # every forward (and one-call view) from here on asks for the all-fp32 backward
 
     def step(i):
@@ -623,19 +631,22 @@ def main():
     dt, dt_host, t_host, loss = timed_run(args.warmup, args.steps, dom_mask)
     kern = {} if args.no_kernel_events else _C.prof_collect()
     _C.prof_enable(False)
-    # the same step with the blend backward's pixel->splat reduction on fp32 MFMAs throughout (SCORP_BACKWARD_EXACT_FP32),
-    # same protocol: the headline next to its all-fp32 twin
-    dt_exact = dt_det = None
-    if fused_view and side_streams is None and not args.exact_backward and not args.no_twins:
+    # the same step with the OTHER form of the blend backward's pixel->splat reduction (the two-term fp16 split if the headline
+    # is all-fp32, and the other way round), same protocol: the headline next to its twin
+    dt_twin = dt_det = None
+    if fused_view and side_streams is None and not args.no_twins:
         prev_flags = getattr(R._tls, "backward_flags", 0)
-        R._tls.backward_flags = _C.BACKWARD_EXACT_FP32
+        R._tls.backward_flags = 0 if (prev_flags & _C.BACKWARD_EXACT_FP32) else _C.BACKWARD_EXACT_FP32
         try:
-            dt_exact = timed_run(min(args.warmup, 10), args.steps)[0]
+            dt_twin = timed_run(min(args.warmup, 10), args.steps)[0]
             # ... and with SCORP_BACKWARD_DETERMINISTIC: no float atomics, plain partial rows + an ordered per-Gaussian sum
             R._tls.backward_flags = _C.BACKWARD_DETERMINISTIC
             dt_det = timed_run(min(args.warmup, 5), args.steps)[0]
         finally:
             R._tls.backward_flags = prev_flags
+    exact_is_headline = bool(getattr(R._tls, "backward_flags", 0) & _C.BACKWARD_EXACT_FP32)
+    dt_exact, dt_split = (None, dt_twin) if exact_is_headline else (dt_twin, None)
+    R._tls.backward_flags = 0     # the extras and the secondary records below run the library's defaults
     # extra (not part of `value`): forward-only render rate, the unit of the alignment sweep / test-view rendering
     nf = max(args.steps // 2, 1)
     torch.cuda.synchronize()
@@ -689,11 +700,12 @@ def main():
         R.LAST_FORWARD = None
         work = {"forward_block_splat_iterations": int(o3[0]), "backward_block_splat_iterations": int(o3[1]), "blocks_8x8": int(o3[2])}
     if world > 1:
-        tt = torch.tensor([dt, dt_host, dt_exact or 0.0, dt_det or 0.0], device=cdev, dtype=torch.float64)
+        tt = torch.tensor([dt, dt_host, dt_exact or 0.0, dt_det or 0.0, dt_split or 0.0], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, dt_host = float(tt[0]), float(tt[1])
         dt_exact = float(tt[2]) if dt_exact is not None else None
         dt_det = float(tt[3]) if dt_det is not None else None
+        dt_split = float(tt[4]) if dt_split is not None else None
         ll = torch.tensor([float(loss.detach())], device=cdev)
         gathered = [torch.zeros_like(ll) for _ in range(world)]
         dist.all_gather(gathered, ll)     # gather of per-rank results (scalars)
@@ -810,7 +822,10 @@ def main():
                        "pixel_splat_pairs_P": P_f, "pixel_splat_pairs_P_backward": P_b, "parallelism": f"view-sharded replicas x{world}"},
             "timing": {"clock": "hipEvents", "probe_views": max(3, min(args.warmup, 8)), "lead_in_views": args.lead_in,
                        "host_clock_ms_per_step": round(dt_host / args.steps * 1e3, 4), "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 4)},
-            "precision": "f32; backward pixel->splat reduction: " + ("fp32 MFMA" if args.exact_backward else "2-term fp16 split MFMA (22 bits), fp32 accumulate"),
+            "precision": "f32 throughout (blend backward's pixel->splat reduction on fp32 MFMAs)" if exact_is_headline
+                         else "f32; backward pixel->splat reduction: 2-term fp16 split MFMA (22 bits), fp32 accumulate",
+            "library_default_backward": "2-term fp16 split (value_split22); the headline asks for SCORP_BACKWARD_EXACT_FP32 per view",
+
             "kernels_us_GBs": kernels,
             "pairs_per_s": (_sig(value * (P_f + P_b), 4) if work else None),
             "forward_only_views_per_s_per_gpu": round(fwd_only, 1),
@@ -853,8 +868,10 @@ def main():
         # the figures the record is read for come LAST (a log tail keeps the end of the line)
         line["ms_per_step"] = round(dt / args.steps * 1e3, 4)
         line["value"] = round(value, 3)
-        line["value_exact_fp32"] = None if dt_exact is None else round(views / dt_exact, 3)
-        line["ms_per_step_exact_fp32"] = None if dt_exact is None else round(dt_exact / args.steps * 1e3, 4)
+        line["value_exact_fp32"] = round(value, 3) if exact_is_headline else (None if dt_exact is None else round(views / dt_exact, 3))
+        line["ms_per_step_exact_fp32"] = line["ms_per_step"] if exact_is_headline else (None if dt_exact is None else round(dt_exact / args.steps * 1e3, 4))
+        line["value_split22"] = (None if dt_split is None else round(views / dt_split, 3)) if exact_is_headline else round(value, 3)
+        line["ms_per_step_split22"] = (None if dt_split is None else round(dt_split / args.steps * 1e3, 4)) if exact_is_headline else line["ms_per_step"]
         line["value_deterministic_backward"] = None if dt_det is None else round(views / dt_det, 3)
         line["ms_per_step_deterministic_backward"] = None if dt_det is None else round(dt_det / args.steps * 1e3, 4)
         line["roofline"] = roof

@@ -129,6 +129,19 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // Tile mask convention: bit (ty - y0) * 8 + (tx - x0) for rectangles of at most 8 x 8 tiles; ~0 = whole rectangle.
 constexpr uint64_t kMaskAll = ~0ull;
 template <typename F>
+__device__ __forceinline__ void for_each_tile_xy(int x0, int y0, int x1, int y1, uint64_t mask, F f) {   // f(tile x, tile y)
+  if (mask == kMaskAll) {
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) f(x, y);
+  } else {
+    while (mask) {
+      const int b = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      f(x0 + (b & 7), y0 + (b >> 3));
+    }
+  }
+}
+template <typename F>
 __device__ __forceinline__ void for_each_tile(int x0, int y0, int x1, int y1, uint64_t mask, int tiles_x, F f) {
   if (mask == kMaskAll) {
     for (int y = y0; y < y1; y++)
@@ -162,9 +175,25 @@ inline int bin_blocks(int N, int tiles) {
   return b < 1 ? 1 : (b > kBinBlocksMax ? kBinBlocksMax : b);
 }
 
+// Two-level binning (round 5).  The (tile, splat) pairs of a view are bucketed FIRST by cell - kCellTiles x kCellTiles tiles,
+// 64 x 64 pixels - and only then, one workgroup per cell, by tile: a bin block's pairs for one cell are a run of ~20
+// consecutive 8-byte keys (they were 1.4 scattered keys per (block, tile): the scatter wrote 110 MB for 35 MB, section 8 of
+// DESIGN.md), the block x bin histogram matrix shrinks sixteenfold, and the second level's stores stay inside one cell's
+// ~40 KB.  A level-one key carries the tile's index inside its cell in bits 28..31 of its low word, which is why the path
+// takes fewer than 2^28 (virtual) Gaussians; the tile lists then lie in memory in CELL-major order, so every tile has its
+// own (start, end) pair: tile_start[2 t], tile_start[2 t + 1] (both paths write that form).
+constexpr int kCellTiles = 4;
+constexpr int kCellShift = 28;          // level-one keys: tile-in-cell index in bits 28..31 of the low word
+constexpr int kMaxCells = 8192;         // the scatter's prologue scans this many bin totals (8 per thread)
+#ifndef SCORP_TWO_LEVEL_MIN_N
+#define SCORP_TWO_LEVEL_MIN_N 0
+#endif
+
 struct StateLayout {
-  size_t header, rec, bin, tile_mask, tile_count, tile_start, final_T, n_contrib, block_hits, block_hist, total;
+  size_t header, rec, bin, tile_mask, tile_count, tile_start, cell_start, final_T, n_contrib, block_hits, block_hist, total;
   int tiles_x, tiles_y, tiles, nb;
+  int cells_x, cells_y, cells;
+  bool two_level;      // bins of the count / scan / scatter kernels are cells; expand_cells_kernel makes the tile buckets
   int views, view_n;   // stacked views (ScorpGs3dInputs.num_views): binning pass v owns view v's Gaussians AND tiles
   bool lds_binning;
   int bin_passes() const { return views > 1 ? views : (tiles + kMaxLdsTiles - 1) / kMaxLdsTiles; }
@@ -172,7 +201,7 @@ struct StateLayout {
   int bin_n() const { return views > 1 ? view_n : -1; }   // Gaussians a pass looks at (-1: all of them)
   // up to 8192 tiles (one pass, 8 counts per thread) every scatter workgroup scans the tile totals itself while it sets
   // up its LDS cursors, and the one-workgroup scan launch between the count and the scatter is dropped
-  bool scan_in_scatter() const { return lds_binning && tiles <= 8192 && views <= 1; }
+  bool scan_in_scatter() const { return lds_binning && (two_level || tiles <= 8192) && views <= 1; }
   // views_ > 1: N and H are the TOTALS of views_ stacked views (N / views_ Gaussians, H / views_ rows each).  View v's
   // Gaussians only reach the tiles of band v, so the binning runs as views_ passes, pass v over view v's Gaussians with a
   // histogram of view v's tiles only: nb blocks PER VIEW and a block-histogram matrix of nb x tiles counters instead of
@@ -190,8 +219,12 @@ struct StateLayout {
     rec = off; off = align_up(off + n * (mode2d ? (size_t)96 : sizeof(SplatRec)), 256);
     bin = off; off = align_up(off + n * sizeof(BinRec), 256);
     tile_mask = off; off = align_up(off + n * 8, 256);   // per splat: which tiles of its (<= 8x8) rectangle it can reach
+    cells_x = (tiles_x + kCellTiles - 1) / kCellTiles;
+    cells_y = (tiles_y + kCellTiles - 1) / kCellTiles;
+    cells = cells_x * cells_y;
     tile_count = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
-    tile_start = off; off = align_up(off + ((size_t)tiles + 1) * 4, 256);
+    tile_start = off; off = align_up(off + ((size_t)tiles + 1) * 8, 256);   // (start, end) per tile
+    cell_start = off; off = align_up(off + ((size_t)cells + 1) * 4, 256);
     final_T = off; off = align_up(off + hw * 4 * (mode2d ? 3 : 1), 256);     // 2DGS also keeps M1, M2 per pixel
     n_contrib = off; off = align_up(off + hw * 4 * (mode2d ? 2 : 1), 256);   // ... and the median contributor
     block_hits = off; off = align_up(off + (size_t)tiles * 4 * 4, 256);      // per 8x8 block: hits the blend forward replayed
@@ -203,6 +236,7 @@ struct StateLayout {
       nb = per_view < cap ? per_view : cap;
     }
     lds_binning = tiles <= 64 * kMaxLdsTiles;   // (beyond: the global-atomic fallback; 150 M pixels)
+    two_level = lds_binning && views <= 1 && N < (1 << kCellShift) && N >= SCORP_TWO_LEVEL_MIN_N && cells <= kMaxCells;
     block_hist = off; off = align_up(off + (lds_binning ? (size_t)nb * tiles * 4 : 0), 256);
     total = off;
   }
@@ -214,10 +248,11 @@ struct StateLayout {
 // ellipse-vs-block test, in list order, compacted; 16 bytes per pair, so the region is twice the keys), 2DGS one
 // verdict byte per (quad, entry).
 struct PairLayout {
-  size_t keys, hits, list, total;
+  size_t keys, keys2, hits, list, total;   // keys2: the tile buckets of the two-level binning (keys: its cell buckets)
   explicit PairLayout(uint64_t capacity) {
     size_t c = capacity > 0 ? (size_t)capacity : 1;
     keys = 0;
+    keys2 = c * 8;
     hits = 0;
     list = align_up(c * 16, 256);
     total = align_up(list + c * 4, 256);
@@ -269,6 +304,8 @@ void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L,
                                 const ScorpGs3dGrads *grads, hipStream_t stream);
 
 // ---- binning shared by the 3DGS and 2DGS paths (gs3d_forward.hip) ----
+int copy_tile_lists_raster(const StateLayout &L, const PairLayout &P, const void *state, const void *pairs, uint64_t capacity,
+                           uint32_t num_pairs, uint32_t *tile_start, uint32_t *point_list, hipStream_t stream);
 int bin_count_and_scan(const StateLayout &L, char *state_base, int N, int debug, hipStream_t stream);
 int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *state_base, char *pairs_base, int N,
                          uint32_t capacity, int debug, hipStream_t stream, uint32_t *header_copy = nullptr);

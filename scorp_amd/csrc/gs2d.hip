@@ -383,7 +383,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
   const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)by, by1 = (float)(by + 7);
   const float bxc = (float)bx + 3.5f, byc = (float)by + 3.5f;                    // the linear form's expansion point (surfel_lin)
   const float qxb = (float)(lane & 7) - 3.5f, qyb = (float)(lane >> 3) - 3.5f;   // this pixel about it
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t beg = min(tile_start[2 * tile], capacity), end = min(tile_start[2 * tile + 1], capacity);   // (start, end) per tile
   const uint32_t n = end - beg;
   const float fn = kFarZ / (kFarZ - kNearZ);
   float T = inside ? 1.0f : -1.0f, C0 = 0, C1 = 0, C2 = 0, N0 = 0, N1 = 0, N2 = 0, Dp = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
@@ -597,7 +597,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   const float pxf = (float)px, pyf = (float)py;
   const float bxc = (float)bx + 3.5f, byc = (float)by + 3.5f;                    // the linear form's expansion point (surfel_lin)
   const float qxb = (float)(lane & 7) - 3.5f, qyb = (float)(lane >> 3) - 3.5f;   // this pixel about it
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t beg = min(tile_start[2 * tile], capacity), end = min(tile_start[2 * tile + 1], capacity);   // (start, end) per tile
   if (end == beg) return;
   const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
   // all of the pixel's loads are issued together; pixels nothing was blended into drop their upstream gradient
@@ -1241,11 +1241,5 @@ extern "C" int scorp_gs2d_debug_tiles(const void *state, const void *pairs, uint
   StateHeader h;
   SCORP_HIP_CHECK(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, stream));
   SCORP_HIP_CHECK(hipStreamSynchronize(stream));
-  if (tile_start)
-    SCORP_HIP_CHECK(hipMemcpyAsync(tile_start, (const char *)state + L.tile_start, ((size_t)L.tiles + 1) * 4, hipMemcpyDeviceToHost, stream));
-  const size_t n = h.num_pairs < capacity ? h.num_pairs : (size_t)capacity;
-  if (point_list && n)
-    SCORP_HIP_CHECK(hipMemcpyAsync(point_list, (const char *)pairs + P.list, n * 4, hipMemcpyDeviceToHost, stream));
-  SCORP_HIP_CHECK(hipStreamSynchronize(stream));
-  return SCORP_OK;
+  return copy_tile_lists_raster(L, P, state, pairs, capacity, h.num_pairs, tile_start, point_list, stream);
 }

@@ -152,7 +152,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   const bool a_on = a_operand_active(lane);
   const int a_slot = a_operand_slot(lane);
   if (lane < 3) *reinterpret_cast<uint4 *>(&xm[(13 + lane) * kXStride + 64]) = make_uint4(0u, 0u, 0u, 0u);
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t beg = min(tile_start[2 * tile], capacity), end = min(tile_start[2 * tile + 1], capacity);   // (start, end) per tile
   // deterministic mode: the sums leave as plain rows partial[4 * pair + quad], pair = the (Gaussian, tile) pair's ordinal
   // in GAUSSIAN-major order (pair_base[id] + the tile's rank in the Gaussian's tile mask), with a flag byte per row
   constexpr bool det = kDet;

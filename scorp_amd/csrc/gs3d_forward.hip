@@ -62,20 +62,21 @@ scan_tiles_kernel(const uint32_t *__restrict__ tile_count, uint32_t *__restrict_
   incl += wave > 0 ? s_wave[wave - 1] : 0u;
   const uint32_t total = s_wave[15];
   uint32_t run = incl - sum;
+  uint2 *range = reinterpret_cast<uint2 *>(tile_start);   // (start, end) per tile
   if (per <= 8) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      if (lo + j < hi) tile_start[lo + j] = run;
+      if (lo + j < hi) range[lo + j] = make_uint2(run, run + cnt[j]);
       run += cnt[j];
     }
   } else {
     for (int k = lo; k < hi; k++) {
-      tile_start[k] = run;
-      run += tile_count[k];
+      const uint32_t c = tile_count[k];
+      range[k] = make_uint2(run, run + c);
+      run += c;
     }
   }
   if (t == 1023) {
-    tile_start[tiles] = total;
     header->num_pairs = total;
     header->overflow = 0;
   }
@@ -116,15 +117,13 @@ scan_tiles_lds_kernel(const uint32_t *__restrict__ tile_count, uint32_t *__restr
   __syncthreads();
   uint32_t run = incl - sum + (wave > 0 ? s_wave[wave - 1] : 0u);
   const uint32_t total = s_wave[15];
+  uint2 *range = reinterpret_cast<uint2 *>(tile_start);   // (start, end) per tile
   for (int k = lo; k < hi; k++) {
     const uint32_t v = s_all[k];
-    s_all[k] = run;
+    range[k] = make_uint2(run, run + v);
     run += v;
   }
-  __syncthreads();
-  for (int k = t; k < tiles; k += 1024) tile_start[k] = s_all[k];
   if (t == 0) {
-    tile_start[tiles] = total;
     header->num_pairs = total;
     header->overflow = 0;
   }
@@ -153,7 +152,7 @@ scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__re
   if ((br.radius & kRadiusMask) == 0) return;
   const uint64_t key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
   for_each_tile(br.x0, br.y0, br.x1, br.y1, tile_mask[i], tiles_x, [&](int t) {
-    const uint32_t slot = tile_start[t] + atomicSub(&tile_count[t], 1u) - 1u;
+    const uint32_t slot = tile_start[2 * t] + atomicSub(&tile_count[t], 1u) - 1u;
     if (slot < capacity) keys[slot] = key;
   });
 }
@@ -168,10 +167,14 @@ scatter_pairs_kernel(int N, const BinRec *__restrict__ bin, const uint64_t *__re
 //   scatter: the block reloads its row (+ tile_start) as LDS cursors and ranks its pairs with returning LDS atomics.
 // Slot order inside a tile is arbitrary but deterministic; the per-tile depth sort fixes the final order.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kBinAhead = 4;         // Gaussians whose records one thread loads together
 constexpr int kBinThreads = 1024;   // few Gaussians per thread: the count / scatter loops are latency chains (load -> LDS atomic -> store)
 
 // Images with more tiles than one LDS histogram holds are binned in passes: workgroup (pass, block) owns the tile range
 // [pass * tpp, (pass + 1) * tpp) of bin block `block` (blockIdx.x = pass * nb + block).
+// kCells: the bins are cells of kCellTiles x kCellTiles tiles (`tiles` = number of cells, `tiles_x` = cells per row): the
+// first level of the two-level binning
+template <bool kCells>
 __global__ void __launch_bounds__(kBinThreads)
 count_tiles_lds_kernel(int N, int per_block, int nb, int tpp, int view_n, const BinRec *__restrict__ bin,
                        const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x, uint32_t *__restrict__ block_hist,
@@ -185,15 +188,34 @@ count_tiles_lds_kernel(int N, int per_block, int nb, int tpp, int view_n, const 
   // (stacked views: pass v looks at view v's Gaussians only, [v * view_n, (v + 1) * view_n))
   const int g0 = view_n >= 0 ? pass * view_n : 0, g1 = view_n >= 0 ? g0 + view_n : N;
   const int lo = g0 + blk * per_block, hi = min(g1, lo + per_block);
-  for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
-    const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
-    const uint64_t mask = tile_mask[i];   // issued with the record, not after the visibility test
-    const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
-    if ((br.radius & kRadiusMask) == 0) continue;
-    for_each_tile(br.x0, br.y0, br.x1, br.y1, mask, tiles_x, [&](int t) {
-      const uint32_t r = (uint32_t)(t - t_lo);
-      if (r < (uint32_t)nt) atomicAdd(&s_hist[r], 1u);
-    });
+  // (the loads of kBinAhead Gaussians are issued together: one thread walks 2 - 4 of them, and with a load per iteration that
+  // was as many dependent round trips to memory)
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += kBinAhead * kBinThreads) {
+    uint4 raws[kBinAhead];
+    uint64_t masks[kBinAhead];
+#pragma unroll
+    for (int u = 0; u < kBinAhead; u++) {
+      const int i = min(i0 + u * kBinThreads, hi - 1);
+      raws[u] = reinterpret_cast<const uint4 *>(bin)[i];
+      masks[u] = tile_mask[i];
+    }
+#pragma unroll
+    for (int u = 0; u < kBinAhead; u++) {
+      if (i0 + u * kBinThreads >= hi) break;
+      const BinRec br = *reinterpret_cast<const BinRec *>(&raws[u]);
+      const uint64_t mask = masks[u];
+      if ((br.radius & kRadiusMask) == 0) continue;
+      if constexpr (kCells) {
+        for_each_tile_xy(br.x0, br.y0, br.x1, br.y1, mask, [&](int x, int y) {
+          atomicAdd(&s_hist[(y / kCellTiles) * tiles_x + x / kCellTiles], 1u);
+        });
+      } else {
+        for_each_tile(br.x0, br.y0, br.x1, br.y1, mask, tiles_x, [&](int t) {
+          const uint32_t r = (uint32_t)(t - t_lo);
+          if (r < (uint32_t)nt) atomicAdd(&s_hist[r], 1u);
+        });
+      }
+    }
   }
   __syncthreads();
   uint32_t *row = block_hist + (size_t)blk * tiles + t_lo;
@@ -246,6 +268,9 @@ scan_block_hist_kernel(int nb, int tiles, uint32_t *__restrict__ block_hist, uin
   }
 }
 
+// kCells: bins are cells (see count_tiles_lds_kernel); `tile_start` is then the plain prefix cell_start[cells + 1] and a key
+// carries its tile's index inside the cell in bits kCellShift.. of its low word (expand_cells_kernel strips it again)
+template <bool kCells>
 __global__ void __launch_bounds__(kBinThreads)
 scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, int view_n, const BinRec *__restrict__ bin,
                          const uint64_t *__restrict__ tile_mask, int tiles, int tiles_x,
@@ -300,30 +325,103 @@ scatter_pairs_lds_kernel(int N, int per_block, int nb, int tpp, int view_n, cons
     for (int j = 0; j < 8; j++) {
       if (8 * t + j < tiles) {
         s_cur[8 * t + j] = run + rw[j];
-        if (blockIdx.x == 0) tile_start[8 * t + j] = run;
+        if (blockIdx.x == 0) {
+          if constexpr (kCells) tile_start[8 * t + j] = run;
+          else reinterpret_cast<uint2 *>(tile_start)[8 * t + j] = make_uint2(run, run + cnt[j]);
+        }
       }
       run += cnt[j];
     }
-    if (blockIdx.x == 0 && t == kBinThreads - 1) tile_start[tiles] = run;
+    if (kCells && blockIdx.x == 0 && t == kBinThreads - 1) tile_start[tiles] = run;
   } else {
-    for (int t = threadIdx.x; t < nt; t += kBinThreads) s_cur[t] = tile_start[t_lo + t] + row[t];
+    for (int t = threadIdx.x; t < nt; t += kBinThreads) s_cur[t] = tile_start[2 * (t_lo + t)] + row[t];
   }
   __syncthreads();
   const int g0 = view_n >= 0 ? pass * view_n : 0, g1 = view_n >= 0 ? g0 + view_n : N;
   const int lo = g0 + blk * per_block, hi = min(g1, lo + per_block);
-  for (int i = lo + threadIdx.x; i < hi; i += kBinThreads) {
-    const uint4 raw = reinterpret_cast<const uint4 *>(bin)[i];
-    const uint64_t mask = tile_mask[i];
-    const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += kBinAhead * kBinThreads) {
+    uint4 raws[kBinAhead];
+    uint64_t masks[kBinAhead];
+#pragma unroll
+    for (int u = 0; u < kBinAhead; u++) {
+      const int i = min(i0 + u * kBinThreads, hi - 1);
+      raws[u] = reinterpret_cast<const uint4 *>(bin)[i];
+      masks[u] = tile_mask[i];
+    }
+#pragma unroll
+    for (int u = 0; u < kBinAhead; u++) {
+    const int i = i0 + u * kBinThreads;
+    if (i >= hi) break;
+    const BinRec br = *reinterpret_cast<const BinRec *>(&raws[u]);
+    const uint64_t mask = masks[u];
     if ((br.radius & kRadiusMask) == 0) continue;
     const uint64_t key = ((uint64_t)br.depth_bits << 32) | (uint32_t)i;
-    for_each_tile(br.x0, br.y0, br.x1, br.y1, mask, tiles_x, [&](int t) {
-      const uint32_t r = (uint32_t)(t - t_lo);
-      if (r < (uint32_t)nt) {
-        const uint32_t slot = atomicAdd(&s_cur[r], 1u);
-        if (slot < capacity) keys[slot] = key;
-      }
-    });
+    if constexpr (kCells) {
+      for_each_tile_xy(br.x0, br.y0, br.x1, br.y1, mask, [&](int x, int y) {
+        const uint32_t slot = atomicAdd(&s_cur[(y / kCellTiles) * tiles_x + x / kCellTiles], 1u);
+        if (slot < capacity) keys[slot] = key | (uint64_t)((uint32_t)((y % kCellTiles) * kCellTiles + x % kCellTiles) << kCellShift);
+      });
+    } else {
+      for_each_tile(br.x0, br.y0, br.x1, br.y1, mask, tiles_x, [&](int t) {
+        const uint32_t r = (uint32_t)(t - t_lo);
+        if (r < (uint32_t)nt) {
+          const uint32_t slot = atomicAdd(&s_cur[r], 1u);
+          if (slot < capacity) keys[slot] = key;
+        }
+      });
+    }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Second level of the two-level binning: ONE WORKGROUP PER CELL.  The cell's keys (contiguous, in arbitrary order) are
+// counted per tile (sixteen LDS counters), the sixteen tile buckets are laid out one after the other inside the cell's own
+// range of the second key buffer, every tile's (start, end) is written, and the keys go to their buckets with the tile
+// index stripped - so that what the per-tile sort reads is exactly what the one-level scatter produces.  Up to
+// kExpandKeep keys per thread stay in registers between the two passes (a cell of S3 holds ~5 100 pairs); longer cells read
+// the rest again.  A view that overflowed its reservation is clamped to `capacity` as everywhere else.
+// (Staging the buckets in LDS and copying them out linearly - a wave's 64 stores consecutive instead of scattered over the
+// cell's 40 KB - was built and is SLOWER, 19.1 against 16.2 us: with 64 KB of LDS two workgroups share a CU, and the kernel
+// is a chain of round trips, not a stream of stores.)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kExpandThreads = 512, kExpandKeep = 12;
+__global__ void __launch_bounds__(kExpandThreads)
+expand_cells_kernel(const uint32_t *__restrict__ cell_start, const uint64_t *__restrict__ keys_in, uint64_t *__restrict__ keys_out,
+                    uint32_t *__restrict__ tile_range, uint32_t capacity, int cells_x, int tiles_x, int tiles_y) {
+  constexpr int kBins = kCellTiles * kCellTiles;
+  __shared__ uint32_t s_cnt[kBins], s_cur[kBins];
+  const int cell = blockIdx.x, tid = threadIdx.x;
+  const uint32_t beg = min(cell_start[cell], capacity), end = min(cell_start[cell + 1], capacity);
+  if (tid < kBins) s_cnt[tid] = 0;
+  __syncthreads();
+  uint64_t kk[kExpandKeep];
+#pragma unroll
+  for (int j = 0; j < kExpandKeep; j++) {
+    const uint32_t i = beg + tid + j * kExpandThreads;
+    kk[j] = i < end ? keys_in[i] : ~0ull;
+  }
+  auto bin_of = [](uint64_t k) { return (uint32_t)(k >> kCellShift) & (uint32_t)(kBins - 1); };
+#pragma unroll
+  for (int j = 0; j < kExpandKeep; j++)
+    if (beg + tid + j * kExpandThreads < end) atomicAdd(&s_cnt[bin_of(kk[j])], 1u);
+  for (uint32_t i = beg + tid + kExpandKeep * kExpandThreads; i < end; i += kExpandThreads) atomicAdd(&s_cnt[bin_of(keys_in[i])], 1u);
+  __syncthreads();
+  if (tid < kBins) {
+    uint32_t run = beg;
+    for (int b = 0; b < tid; b++) run += s_cnt[b];
+    s_cur[tid] = run;
+    const int tx = (cell % cells_x) * kCellTiles + tid % kCellTiles, ty = (cell / cells_x) * kCellTiles + tid / kCellTiles;
+    if (tx < tiles_x && ty < tiles_y) reinterpret_cast<uint2 *>(tile_range)[ty * tiles_x + tx] = make_uint2(run, run + s_cnt[tid]);
+  }
+  __syncthreads();
+  constexpr uint64_t kStrip = ~((uint64_t)(kBins - 1) << kCellShift);
+#pragma unroll
+  for (int j = 0; j < kExpandKeep; j++)
+    if (beg + tid + j * kExpandThreads < end) keys_out[atomicAdd(&s_cur[bin_of(kk[j])], 1u)] = kk[j] & kStrip;
+  for (uint32_t i = beg + tid + kExpandKeep * kExpandThreads; i < end; i += kExpandThreads) {
+    const uint64_t k = keys_in[i];
+    keys_out[atomicAdd(&s_cur[bin_of(k)], 1u)] = k & kStrip;
   }
 }
 
@@ -501,7 +599,7 @@ sort_tiles_reg_kernel(const uint32_t *__restrict__ tile_start, const uint64_t *_
                       StateHeader *__restrict__ header) {
   __shared__ __attribute__((aligned(16))) uint64_t s_x[1024];
   const int tile = blockIdx.x;
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t beg = min(tile_start[2 * tile], capacity), end = min(tile_start[2 * tile + 1], capacity);   // (start, end) per tile
   const uint32_t n = end - beg;
   if (n > 1024) {   // sort_tiles_long_kernel's: it walks the list of such tiles (usually empty) instead of every tile
     if (threadIdx.x == 0) long_list[atomicAdd(&header->long_tiles, 1u)] = (uint32_t)tile;
@@ -558,7 +656,7 @@ __device__ __forceinline__ void clean_chunk_1024(uint64_t (&k)[4], uint64_t *s_x
 __device__ __forceinline__ void sort_long_tile(int tile, const uint32_t *__restrict__ tile_start, uint64_t *__restrict__ keys,
                                                uint32_t *__restrict__ point_list, uint32_t capacity, uint64_t *s_keys, uint64_t *s_x) {
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t beg = min(tile_start[2 * tile], capacity), end = min(tile_start[2 * tile + 1], capacity);   // (start, end) per tile
   const uint32_t n = end - beg;
   if (n <= 1024) return;   // sort_tiles_reg_kernel's
   uint32_t P = 2048;
@@ -733,7 +831,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
   const int byl = band_h > 0 ? by % band_h : by;
   const float bx0 = (float)bx, bx1 = (float)(bx + 7), by0 = (float)byl, by1 = (float)(byl + 7);
   const float cx = (float)bx + 3.5f, cy = (float)byl + 3.5f;
-  const uint32_t beg = min(tile_start[tile], capacity), end = min(tile_start[tile + 1], capacity);
+  const uint32_t beg = min(tile_start[2 * tile], capacity), end = min(tile_start[2 * tile + 1], capacity);   // (start, end) per tile
   const uint32_t n = end - beg;
   uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
   if (lane < 3) q_k[lane][kFRing] = make_uint4(0u, 0u, 0u, 0u);
@@ -1009,6 +1107,21 @@ int validate(const ScorpGs3dInputs *in) {
 namespace scorp {
 int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipStream_t stream) {
   uint32_t *tile_count = (uint32_t *)(base + L.tile_count);
+  if (L.two_level) {
+    // first level: the bins are cells (one pass, the histogram matrix is nb x cells); the totals land in tile_count[0 .. cells)
+    const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
+    uint32_t *block_hist = (uint32_t *)(base + L.block_hist);
+    {
+      ProfScope prof(kKCountTiles, stream);
+      count_tiles_lds_kernel<true><<<L.nb, kBinThreads, (size_t)L.cells * 4, stream>>>(
+          N, per_block, L.nb, L.cells, -1, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.cells, L.cells_x,
+          block_hist, (StateHeader *)(base + L.header));
+      scan_block_hist_kernel<<<(L.cells + kScanTiles - 1) / kScanTiles, kScanTiles * kScanSegs, 0, stream>>>(
+          L.nb, L.cells, block_hist, tile_count, (StateHeader *)(base + L.header));
+    }
+    SCORP_KERNEL_CHECK("count_cells", debug, stream);
+    return SCORP_OK;
+  }
   if (L.lds_binning) {
     const int per_block = (max(L.bin_n() >= 0 ? L.bin_n() : N, 1) + L.nb - 1) / L.nb;
     uint32_t *block_hist = (uint32_t *)(base + L.block_hist);
@@ -1019,10 +1132,10 @@ int bin_count_and_scan(const StateLayout &L, char *base, int N, int debug, hipSt
       // drives a second GPU must set it there too), so it is set whenever such a launch is about to happen - two cheap
       // host calls, no process-global flag, no data race between threads - and its result is checked.
       if ((size_t)tpp * 4 > 64 * 1024) {
-        SCORP_HIP_CHECK(hipFuncSetAttribute((const void *)count_tiles_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4));
-        SCORP_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_pairs_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4));
+        SCORP_HIP_CHECK(hipFuncSetAttribute((const void *)count_tiles_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4));
+        SCORP_HIP_CHECK(hipFuncSetAttribute((const void *)scatter_pairs_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsTiles * 4));
       }
-      count_tiles_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
+      count_tiles_lds_kernel<false><<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
           N, per_block, L.nb, tpp, L.bin_n(), (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
           block_hist, L.scan_in_scatter() ? (StateHeader *)(base + L.header) : nullptr);
       scan_block_hist_kernel<<<(L.tiles + kScanTiles - 1) / kScanTiles, kScanTiles * kScanSegs, 0, stream>>>(
@@ -1052,12 +1165,33 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
   uint64_t *keys = (uint64_t *)(pb + P.keys);
   uint32_t *point_list = (uint32_t *)(pb + P.list);
   StateHeader *header = (StateHeader *)(base + L.header);
+  if (L.two_level) {
+    // pairs -> cell buckets (first key buffer) -> tile buckets (second key buffer), then the per-tile sort reads the second
+    uint32_t *cell_start = (uint32_t *)(base + L.cell_start);
+    uint64_t *keys2 = (uint64_t *)(pb + P.keys2);
+    {
+      ProfScope prof(kKScatterPairs, stream);
+      const int per_block = (max(N, 1) + L.nb - 1) / L.nb;
+      scatter_pairs_lds_kernel<true><<<L.nb, kBinThreads, (size_t)L.cells * 4, stream>>>(
+          N, per_block, L.nb, L.cells, -1, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.cells, L.cells_x,
+          (const uint32_t *)(base + L.block_hist), cell_start, tile_count, keys, capacity, header, header_copy);
+      expand_cells_kernel<<<L.cells, kExpandThreads, 0, stream>>>(cell_start, keys, keys2, tile_start, capacity, L.cells_x, L.tiles_x, L.tiles_y);
+    }
+    SCORP_KERNEL_CHECK("scatter_cells", debug, stream);
+    {
+      ProfScope prof(kKSortTiles, stream);
+      sort_tiles_reg_kernel<<<L.tiles, 256, 0, stream>>>(tile_start, keys2, point_list, capacity, tile_count, header);
+      sort_tiles_long_kernel<<<L.tiles < 512 ? L.tiles : 512, 256, 0, stream>>>(tile_start, keys2, point_list, capacity, tile_count, header);
+    }
+    SCORP_KERNEL_CHECK("sort_tiles", debug, stream);
+    return SCORP_OK;
+  }
   {
     ProfScope prof(kKScatterPairs, stream);
     if (L.lds_binning) {
       const int per_block = (max(L.bin_n() >= 0 ? L.bin_n() : N, 1) + L.nb - 1) / L.nb;
       const int tpp = L.tiles_per_pass();
-      scatter_pairs_lds_kernel<<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
+      scatter_pairs_lds_kernel<false><<<L.nb * L.bin_passes(), kBinThreads, (size_t)tpp * 4, stream>>>(
           N, per_block, L.nb, tpp, L.bin_n(), (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), L.tiles, L.tiles_x,
           (const uint32_t *)(base + L.block_hist), tile_start, L.scan_in_scatter() ? tile_count : nullptr, keys, capacity,
           header, header_copy);
@@ -1078,6 +1212,29 @@ int bin_scatter_and_sort(const StateLayout &L, const PairLayout &P, char *base, 
   return SCORP_OK;
 }
 }  // namespace scorp
+
+// The debug entry points' view of the tile lists: tile_start[tiles + 1] in RASTER tile order with the lists concatenated in
+// that order - whatever order they have in the pair buffer (cell-major under the two-level binning).
+int scorp::copy_tile_lists_raster(const StateLayout &L, const PairLayout &P, const void *state, const void *pairs, uint64_t capacity,
+                                  uint32_t num_pairs, uint32_t *tile_start, uint32_t *point_list, hipStream_t stream) {
+  const size_t n = num_pairs < capacity ? num_pairs : (size_t)capacity;
+  uint32_t *range = (uint32_t *)malloc(((size_t)L.tiles + 1) * 8), *list = (uint32_t *)malloc((n ? n : 1) * 4);
+  if (!range || !list) { free(range); free(list); set_error("out of host memory"); return SCORP_ERR_INVALID; }
+  hipError_t e = hipMemcpyAsync(range, (const char *)state + L.tile_start, (size_t)L.tiles * 8, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(list, (const char *)pairs + P.list, n * 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) { free(range); free(list); set_error("copy of the tile lists failed: %s", hipGetErrorString(e)); return SCORP_ERR_HIP; }
+  uint32_t run = 0;
+  for (int t = 0; t < L.tiles; t++) {
+    const uint32_t b = range[2 * t] < n ? range[2 * t] : (uint32_t)n, en = range[2 * t + 1] < n ? range[2 * t + 1] : (uint32_t)n;
+    if (tile_start) tile_start[t] = run;
+    if (point_list && en > b) memcpy(point_list + run, list + b, (size_t)(en - b) * 4);
+    run += en > b ? en - b : 0;
+  }
+  if (tile_start) tile_start[L.tiles] = run;
+  free(range); free(list);
+  return SCORP_OK;
+}
 
 using namespace scorp;
 
@@ -1252,13 +1409,7 @@ extern "C" int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint
   StateHeader h;
   SCORP_HIP_CHECK(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, stream));
   SCORP_HIP_CHECK(hipStreamSynchronize(stream));
-  if (tile_start)
-    SCORP_HIP_CHECK(hipMemcpyAsync(tile_start, (const char *)state + L.tile_start, ((size_t)L.tiles + 1) * 4, hipMemcpyDeviceToHost, stream));
-  const size_t n = h.num_pairs < capacity ? h.num_pairs : (size_t)capacity;
-  if (point_list && n)
-    SCORP_HIP_CHECK(hipMemcpyAsync(point_list, (const char *)pairs + P.list, n * 4, hipMemcpyDeviceToHost, stream));
-  SCORP_HIP_CHECK(hipStreamSynchronize(stream));
-  return SCORP_OK;
+  return copy_tile_lists_raster(L, P, state, pairs, capacity, h.num_pairs, tile_start, point_list, stream);
 }
 
 #ifdef SCORP_FWD_STATS
