@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "scorp_gs.h"
@@ -189,6 +190,13 @@ constexpr int kMaxCells = 8192;         // the scatter's prologue scans this man
 #define SCORP_TWO_LEVEL_MIN_N 0
 #endif
 
+// SCORP_ONE_LEVEL_BINNING=1 in the environment (read once per process): every view takes the one-level binning - what stacked
+// views and images beyond kMaxCells cells take anyway - so that the tests can hold that path against the oracle as well.
+inline bool one_level_binning_forced() {
+  static const bool forced = [] { const char *e = getenv("SCORP_ONE_LEVEL_BINNING"); return e && e[0] == '1'; }();
+  return forced;
+}
+
 struct StateLayout {
   size_t header, rec, bin, tile_mask, tile_count, tile_start, cell_start, final_T, n_contrib, block_hits, block_hist, total;
   int tiles_x, tiles_y, tiles, nb;
@@ -236,7 +244,8 @@ struct StateLayout {
       nb = per_view < cap ? per_view : cap;
     }
     lds_binning = tiles <= 64 * kMaxLdsTiles;   // (beyond: the global-atomic fallback; 150 M pixels)
-    two_level = lds_binning && views <= 1 && N < (1 << kCellShift) && N >= SCORP_TWO_LEVEL_MIN_N && cells <= kMaxCells;
+    two_level = lds_binning && views <= 1 && N < (1 << kCellShift) && N >= SCORP_TWO_LEVEL_MIN_N && cells <= kMaxCells &&
+                !one_level_binning_forced();
     block_hist = off; off = align_up(off + (lds_binning ? (size_t)nb * tiles * 4 : 0), 256);
     total = off;
   }

@@ -14,6 +14,9 @@
 
 #include "common.hpp"
 #include "exp_mfma.hpp"
+#if defined(SCORP_FWD_MERGE) && SCORP_FWD_MERGE
+#include "blend_group_asm.hpp"   // generated: python scripts/dev/gen_blend_group_asm.py (a parked experiment, off by default)
+#endif
 
 namespace scorp {
 namespace {
@@ -771,6 +774,10 @@ sort_tiles_long_kernel(const uint32_t *__restrict__ tile_start, uint64_t *__rest
 #ifndef SCORP_FWD_RING
 #define SCORP_FWD_RING 80
 #endif
+#ifndef SCORP_FWD_MERGE
+#define SCORP_FWD_MERGE 0     // 1: clamp-free full groups let adjacent hits with disjoint live pixels share an iteration (the parked
+                              // experiment scripts/dev/gen_blend_group_asm.py: correct, fewer vector instructions, not faster)
+#endif
 constexpr int kFRing = SCORP_FWD_RING, kFChunk = 64, kFGroup = 16;   // ring: at most 15 left-over hits + 64 new ones
 
 // __launch_bounds__(64, 6): six waves per SIMD = at most 80 registers.  The kernel needs 84 - 86 left to itself since it
@@ -992,6 +999,30 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
       consumed += (uint32_t)nslots;
       return all_done;
     };
+#if SCORP_FWD_MERGE
+    // full clamp-free groups: adjacent hits whose live pixels are disjoint share an iteration (blend_group_asm.hpp: the
+    // sixteen slots as one hand-allocated assembly block; section 4.2a of DESIGN.md)
+    auto blend_group_merged = [&](const f32x16 &e) -> bool {
+      const uint32_t gcb = (uint32_t)(size_t)(const void *)(q_col + head);   // LDS byte address of the group's first slot
+      bool all_done;
+      if constexpr (kForBackward) {
+        uint32_t lastg = 0, kept16 = 0;
+        all_done = blend_group_merged_asm_fb(e, gcb, T, C0, C1, C2, Dp, lastg, kept16);
+        int hv = head;
+        asm volatile("" : "+v"(hv));
+        if (lastg) last = kept_n + (uint32_t)__builtin_popcount(kept16 & ((1u << lastg) - 1u));
+        if (lane < kFGroup && ((kept16 >> lane) & 1u)) my_hits[kept_n + __builtin_amdgcn_mbcnt_lo(kept16, 0u)] = q_id[hv + lane];
+        kept_n += (uint32_t)__builtin_popcount(kept16);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        all_done = blend_group_merged_asm_img(e, gcb, T, C0, C1, C2, Dp);
+      }
+      head = head + kFGroup == kFRing ? 0 : head + kFGroup;
+      count -= kFGroup;
+      consumed += (uint32_t)kFGroup;
+      return all_done;
+    };
+#endif
     bool all_done = false;   // every pixel saturated: checked twice per group, not only once per 64 list entries
 #if SCORP_FWD_DB
     // The exponents of the NEXT group are issued to the matrix cores before the current group is blended: the three
@@ -1012,8 +1043,12 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
 #else
     while (count >= kFGroup) {
       const f32x16 e = exponents(head);
+#if SCORP_FWD_MERGE
+      const bool gd = consumed < hot_end ? blend_group(std::true_type{}, std::true_type{}, kFGroup, e) : blend_group_merged(e);
+#else
       const bool gd = consumed < hot_end ? blend_group(std::true_type{}, std::true_type{}, kFGroup, e)
                                          : blend_group(std::true_type{}, std::false_type{}, kFGroup, e);
+#endif
       if (gd || __ballot(T > 0.0f) == 0) { all_done = true; break; }
     }
 #endif

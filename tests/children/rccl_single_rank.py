@@ -109,6 +109,22 @@ def main():
     ids, fit, best = rotation_sweep(obj, rots, cams3, targets, bg)
     assert ids.tolist() == list(range(8)) and fit.shape == (8, 1) and 0 <= best < 8
     PairPolicy.reset()
+    # ... in the form bench.py's 8-GPU record takes: a plan built beforehand (stacked views, RESERVED pair buffers: no host
+    # synchronisation per render), the sharded sweep through the group's all-gather, against this rank scoring everything
+    # itself without the group's help
+    from scorp_amd.align import SweepPlan
+    plan = SweepPlan(obj, cams3, targets, bg)
+    assert plan.stacked is not None
+    ids2, fit2, best2 = rotation_sweep(obj, rots, cams3, targets, bg, plan=plan)
+    P.SINGLE_RANK_COLLECTIVES = False
+    try:
+        ids3, fit3, best3 = rotation_sweep(obj, rots, cams3, targets, bg, plan=plan, shard=False)
+    finally:
+        P.SINGLE_RANK_COLLECTIVES = True
+    assert ids2.tolist() == ids3.tolist() and best2 == best3 == best
+    assert float((fit2.to(fit3.device) - fit3).abs().max()) < 1e-6      # (the score is a float-atomic sum: not bit-stable)
+    assert float((fit2.to(fit.device) - fit).abs().max()) < 1e-6
+    PairPolicy.reset()
     objs = [GaussianModel.from_raw(make_gaussians(3_000, 0, 60 + k, extent=0.5, log_scale_mean=math.log(0.03)), 0, device=dev) for k in range(2)]
     cams4 = ring_cameras(2, 160, 128, 9, device=dev)
     with torch.no_grad():

@@ -111,6 +111,10 @@ CASES = {
     "long_lists": dict(N=2500, W=64, H=64, deg=1, seed=11, log_scale=math.log(0.6)),     # 1024 < n <= 4096: second sort launch, in LDS
     "many_tiles": dict(N=3000, W=2320, H=1800, deg=1, seed=10, log_scale=math.log(0.03)),  # 16385 tiles: a 64 KiB+ LDS histogram
     "two_pass_tiles": dict(N=2000, W=3104, H=3328, deg=0, seed=12, log_scale=math.log(0.03)),  # 40352 tiles > kMaxLdsTiles: binned in two tile-range passes
+                                                                                              # (one-level binning; two-level: 2 523 cells)
+    # the align loop's largest render, 1600x1200 scaled by 1.5 three times (align_3dgs_clpe_9dof.py:157-169): 85 852 tiles =
+    # three tile-range passes of the one-level binning, 5 440 cells of the two-level one
+    "three_pass_tiles": dict(N=1500, W=5400, H=4050, deg=0, seed=13, log_scale=math.log(0.03)),
 }
 
 
@@ -239,7 +243,7 @@ def _raw_forward(kw, dev, capacity=None):
                 alpha=alpha, keep=(keep, ten), stream=stream, N=N, W=W, H=H)
 
 
-@pytest.mark.parametrize("name", ["sh3_bg_mod", "sh2_ragged", "inside_cloud", "huge_splats", "long_lists", "many_tiles", "two_pass_tiles"])
+@pytest.mark.parametrize("name", ["sh3_bg_mod", "sh2_ragged", "inside_cloud", "huge_splats", "long_lists", "many_tiles", "two_pass_tiles", "three_pass_tiles"])
 def test_stage_parity_geom_and_tile_lists(name, dev):
     """Projection records match the oracle to float rounding; tile rectangles, pair count, per-tile ranges and the
     depth-sorted splat lists match exactly (integer work: bit-exact)."""
@@ -648,3 +652,19 @@ def test_indefinite_conic_is_skipped_where_power_is_positive(precision, dev):
     ((color * torch.tensor(wc, device=dev)).sum() + (depth * torch.tensor(wd, device=dev)).sum()
      + (alpha * torch.tensor(wa, device=dev)).sum()).backward()
     compare_grads(t, o.backward(wc, wd, wa), g64_fn=oracle64_grads(kw, wc, wd, wa))
+
+
+def test_one_level_binning_path_in_a_child_process():
+    """Single views take the two-level binning (cells, then tiles).  The one-level path - what stacked views and images beyond
+    8 192 cells take - is held against the oracle too: a child process with SCORP_ONE_LEVEL_BINNING=1 (the switch is read once
+    per process) runs the stage-parity and forward / backward parity tests of the cases that exercise its branches: ragged
+    sizes, LDS histograms above 64 KiB, two and three tile-range passes, long lists."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SCORP_ONE_LEVEL_BINNING="1")
+    sel = "sh2_ragged or many_tiles or two_pass_tiles or three_pass_tiles or long_lists or huge_splats"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        f"(test_forward_backward_parity or test_stage_parity_geom_and_tile_lists) and ({sel})"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
