@@ -59,9 +59,9 @@ def kernel_algorithmic_bytes(name, N, Nvis, K, HW, D):
     per_g_in = 12 + 4 + 12 + 16                      # xyz, opacity, scale, quaternion
     return {
         "preprocess": N * (per_g_in + 16 + 4) + Nvis * (K * 12 + 48),
-        "count_tiles": N * 16,
+        "count_tiles": N * 24,                       # the 16-byte bin record + the 8-byte tile mask
         "scan_tiles": 0,
-        "scatter_pairs": N * 16 + D * 8,
+        "scatter_pairs": N * 24 + D * (8 + 16),      # two-level binning: cell keys written, then read and written again as tile buckets
         "sort_tiles": D * (8 + 4),
         "blend_forward": 4 * D * 4 + Nvis * 48 + HW * (20 + 8),      # each of a tile's 4 waves walks the tile's list
         "blend_backward": 4 * D * 4 + Nvis * 48 + HW * (20 + 8) + Nvis * 40,

@@ -530,8 +530,13 @@ typedef _Float16 f16x8_2d __attribute__((ext_vector_type(8)));
 union Frag2 { f16x8_2d v; uint4 q; uint32_t d[4]; };
 constexpr int k2XStride = 68;                // dwords per row of the [16][64] value matrix (16-byte aligned rows, conflict-free row writes)
 constexpr int k2DStride = 17;                // floats per row of the 16 x 16 result tile (odd: the read-out lanes hit distinct banks)
-constexpr int k2TargetExp = 2;               // the block's largest |upstream gradient| is scaled into [2^2, 2^3): the values carry
-                                             // factors of depth (<= 100), 1 / p.z scaled to <= 4 and the cutoff radius 3 on top
+constexpr int k2TargetExp = 0;               // the block's largest |upstream gradient| is scaled into [1, 2): the values carry
+                                             // factors of depth (<= kFarZ = 100), 1 / p.z scaled to <= 4 and the cutoff radius 3
+                                             // squared on top - 3.6e3 x the gradient, 7.2e3 at most: a factor of nine below the
+                                             // fp16 maximum, where a saturating conversion would make a gradient quietly wrong
+                                             // (it was [4, 8): 2.9e4 .. 5.8e4, no headroom for a depth-loss-dominated block at
+                                             // the far plane; tests/test_gs2d_gpu.py "far_depth").  The two-term split keeps its
+                                             // 22 bits either way: fp16 stays normal down to 6e-5
 constexpr float k2WScale = 1024.0f;
 __device__ __forceinline__ uint32_t pack_rtz16_2d(float lo, float hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
 __device__ __forceinline__ float half_lo_2d(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p & 0xFFFFu)); }

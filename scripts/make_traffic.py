@@ -14,7 +14,7 @@ from collections import defaultdict
 
 SHORT = {  # kernel symbol -> the name bench.py uses
     "preprocess_kernel": "preprocess", "count_tiles_lds_kernel": "count_tiles", "scan_tiles_kernel": "scan_tiles",
-    "scan_block_hist_kernel": "scan_block_hist", "scatter_pairs_lds_kernel": "scatter_pairs", "sort_tiles_reg_kernel": "sort_tiles", "sort_tiles_kernel": "sort_tiles_long",
+    "scan_block_hist_kernel": "scan_block_hist", "scatter_pairs_lds_kernel": "scatter_pairs", "expand_cells_kernel": "expand_cells", "sort_tiles_reg_kernel": "sort_tiles", "sort_tiles_kernel": "sort_tiles_long",
     "blend_forward_wave_kernel": "blend_forward", "blend_backward_wave_kernel": "blend_backward",
     "preprocess_backward_kernel": "preprocess_backward", "ssim_l1_forward_kernel": "ssim_l1_forward", "ssim_l1_forward_strip_kernel": "ssim_l1_forward",
     "ssim_l1_backward_kernel": "ssim_l1_backward", "preprocess2d_kernel": "preprocess_2d",

@@ -46,6 +46,9 @@ CASES = {
     "inside_cloud": dict(N=5000, W=80, H=80, deg=3, seed=7, radius=1.5),
     "tiny_surfels": dict(N=20000, W=256, H=192, deg=1, seed=5, log_scale=math.log(0.006)),   # low-pass branch
     "scale_mod": dict(N=2000, W=96, H=96, deg=1, seed=8, scale_modifier=1.4),
+    # large surfels near the far plane (depth ~70 of kFarZ = 100) under depth / alpha / normal upstream gradients: the products
+    # depth x 1 / p.z x r^2 of the backward's fp16-split values are at their largest here (gs2d.hip, k2TargetExp)
+    "far_depth": dict(N=1500, W=160, H=120, deg=1, seed=21, radius=70.0, log_scale=math.log(2.0)),
 }
 
 
