@@ -181,7 +181,8 @@ int scorp_gs3d_debug_geom(const void *state, int32_t num_gaussians, int32_t imag
  * to its deepest last contributor), out3[2] = number of blocks. */
 int scorp_gs3d_debug_work(const void *state, int32_t num_gaussians, int32_t image_width, int32_t image_height,
                           uint64_t *out3, scorp_stream_t stream);
-/* tile_start[tiles+1] (uint32) and the sorted splat list point_list[num_pairs] (uint32). */
+/* tile_start[tiles+1] (uint32) and the sorted splat list point_list[num_pairs] (uint32), both in RASTER tile order
+ * (whatever order the lists have in the pair buffer: cell-major under the two-level binning). */
 int scorp_gs3d_debug_tiles(const void *state, const void *pairs, uint64_t capacity, int32_t num_gaussians,
                            int32_t image_width, int32_t image_height, uint32_t *tile_start, uint32_t *point_list,
                            scorp_stream_t stream);

@@ -347,6 +347,9 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
           float4 av[4];
 #pragma unroll
           for (int t4 = 0; t4 < 4; t4++) av[t4] = *reinterpret_cast<const float4 *>(&xm[abase + 4 * t4]);
+#ifdef SCORP_BWD_PROBE_HALF_MFMA
+          if (h == 0)     // diagnostic build (wrong gradients): what halving the fp32 matrix work would buy
+#endif
 #pragma unroll
           for (int t4 = 0; t4 < 4; t4++) {
             d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4].x, bb[4 * t4], d, 0, 0, 0);
