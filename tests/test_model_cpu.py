@@ -29,3 +29,24 @@ def test_view_statistics_without_mask_indexing_equal_the_reference_form():
             ref_den[vis] += 1
     assert torch.equal(m.max_radii2D, ref_max) and torch.equal(m.denom, ref_den)
     torch.testing.assert_close(m.xyz_gradient_accum, ref_acc, rtol=1e-6, atol=0)
+
+
+def test_fused_adam_rollback_takes_discarded_steps_back():
+    """FusedAdam counts a bias-correction step on the host for every view, the ones the device discarded included (a fused view
+    that overflowed its pair reservation); rollback_steps(n) takes them out again - for the parameters the last step() advanced
+    only, and never below zero.  (Host bookkeeping: no GPU involved; the GPU side is
+    tests/test_train_gpu.py::test_first_view_overflow_retry_equals_a_presized_run.)"""
+    import torch
+    from scorp_amd.fused_adam import FusedAdam
+    from scorp_amd.rasterizer3d import PairOverflow
+    a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))
+    opt = FusedAdam([{"params": [a]}, {"params": [b]}], lr=1e-3)
+    opt.state[a]["step"], opt.state[b]["step"] = torch.tensor(5.0), torch.tensor(7.0)
+    opt._stepped = [opt.state[a]]                 # the last step() advanced `a` only (`b` frozen: no gradient)
+    opt.rollback_steps(2)
+    assert float(opt.state[a]["step"]) == 3.0 and float(opt.state[b]["step"]) == 7.0
+    opt.rollback_steps(9)
+    assert float(opt.state[a]["step"]) == 0.0
+    opt.rollback_steps(0)
+    e = PairOverflow("pair reservation too small", 3)
+    assert isinstance(e, RuntimeError) and e.count == 3
