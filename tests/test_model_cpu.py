@@ -50,3 +50,27 @@ def test_fused_adam_rollback_takes_discarded_steps_back():
     opt.rollback_steps(0)
     e = PairOverflow("pair reservation too small", 3)
     assert isinstance(e, RuntimeError) and e.count == 3
+
+
+def test_bench_self_launcher_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` from a bare shell starts its ranks as CHILD processes of torch.distributed.run (never an exec,
+    never a GPU call in the parent) with the same arguments and relays the return code."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    assert bench.launch_ranks(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    assert cmd[-7].endswith("bench.py")
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
