@@ -115,16 +115,18 @@ __device__ __forceinline__ float dpp_add(float v) {
 }
 
 // Wave-wide maximum of a u32 (also of non-negative floats, through their bits), uniform result: four DPP steps inside
-// each row of 16 lanes (xor 1, xor 2, half-mirror, mirror), then the four rows through v_readlane.  No LDS round trips
+// each row of 16 lanes (xor 1, xor 2, half-mirror, mirror), two row broadcasts, one v_readlane.  No LDS round trips
 // (the __shfl_xor form is six dependent ds_bpermute).
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
-  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
-  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
-  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
-  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
-                 c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-  return max(max(a, b), max(c, d));
+  // old = 0 (the identity of an unsigned maximum) lets the compiler fold each move into v_max_u32_dpp; the rows are joined
+  // by the two row broadcasts and one v_readlane (it was four v_readlane and three s_max behind unfolded v_mov_dpp pairs)
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror: every lane holds its row's
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast15 into rows 1, 3
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast31 into rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // Tile mask convention: bit (ty - y0) * 8 + (tx - x0) for rectangles of at most 8 x 8 tiles; ~0 = whole rectangle.

@@ -519,34 +519,39 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
 // are (hit of the pair, kind), its K dimension (pixel, term); B holds each basis value twice (once per term: the MFMA
 // adds the two terms by itself) - columns 0 = 1, 1 = x, 2 = y, 3..8 = the first fp16 term of the six upstream gradients,
 // 9..14 = their remainder.  Two hits per pass, four v_mfma_f32_16x16x32_f16 per pass.
-// Range: the upstream gradients are pre-scaled by a power of two chosen per wave from the block's largest |dL/dpixel|
-// (everything the recurrence produces is linear in them, so t, dL/dz come out scaled, exactly); the blend weight is
-// carried as w * 2^10; and the four values that contain 1 / p.z (p.z ~ surfel extent^2 in pixels: anything from 1e-3 to
-// 1e3) are scaled per hit by the power of two below |p.z| at the block centre.  The conversion saturates (round toward
-// zero) instead of overflowing.  The sums are unscaled by exact powers of two when they are read out.
+// Range: block floating point, three exact powers of two.  The upstream gradients are pre-scaled per wave from the
+// block's largest |dL/dpixel| (everything the recurrence produces is linear in them: the B operand's gradient columns
+// sit high in the fp16 range); the four values that contain 1 / p.z (p.z ~ surfel extent^2 in pixels: anything from 1e-3
+// to 1e3) are scaled per hit by the power of two below |p.z| at the block centre; and the three per-pixel roots of a
+// hit - all eight values are linear in them - by the power of two that brings the largest of them over the hit's pixels
+// into [2^4, 2^5) (one wave maximum per hit), so that the pair's 22 bits hold down to 2^-17 of the hit's largest value
+// whatever T, alpha and the depth scale are.  The blend weight is carried as w * 2^10.  The conversion saturates
+// (round toward zero) instead of overflowing.  The sums are unscaled by exact powers of two when they are read out.
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x4_2d __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_2d __attribute__((ext_vector_type(8)));
 union Frag2 { f16x8_2d v; uint4 q; uint32_t d[4]; };
 constexpr int k2XStride = 68;                // dwords per row of the [16][64] value matrix (16-byte aligned rows, conflict-free row writes)
 constexpr int k2DStride = 17;                // floats per row of the 16 x 16 result tile (odd: the read-out lanes hit distinct banks)
-constexpr int k2TargetExp = 0;               // the block's largest |upstream gradient| is scaled into [1, 2): the values carry
-                                             // factors of depth (<= kFarZ = 100), 1 / p.z scaled to <= 4 and the cutoff radius 3
-                                             // squared on top - 3.6e3 x the gradient, 7.2e3 at most: a factor of nine below the
-                                             // fp16 maximum, where a saturating conversion would make a gradient quietly wrong
-                                             // (it was [4, 8): 2.9e4 .. 5.8e4, no headroom for a depth-loss-dominated block at
-                                             // the far plane; tests/test_gs2d_gpu.py "far_depth").  The two-term split keeps its
-                                             // 22 bits either way: fp16 stays normal down to 6e-5
+#ifndef SCORP_2D_TARGET_EXP
+#define SCORP_2D_TARGET_EXP 12
+#endif
+constexpr int k2TargetExp = SCORP_2D_TARGET_EXP;   // the block's largest |upstream gradient| is scaled into [2^12, 2^13): the B operand's
+                                             // gradient columns (two fp16 terms) keep 22 bits for a pixel whose gradient is down to 2^-14 of the
+                                             // block's largest.  The A side does not depend on it any more: every hit's values are brought to a
+                                             // fixed range by the hit's own power of two (`sg` in the kernel; until round 5 they rode on this
+                                             // scale alone, [1, 2) with a factor of nine of head room for a depth-loss-dominated block at the
+                                             // far plane - tests/test_gs2d_gpu.py "far_depth" - and an absolute floor of 2^-24 under them)
 constexpr float k2WScale = 1024.0f;
 __device__ __forceinline__ uint32_t pack_rtz16_2d(float lo, float hi) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
 __device__ __forceinline__ float half_lo_2d(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p & 0xFFFFu)); }
-__device__ __forceinline__ float half_hi_2d(uint32_t p) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(p >> 16)); }
-// (a, b) -> da = (h1(a) | h2(a) << 16), db = (h1(b) | h2(b) << 16)
-__device__ __forceinline__ void split_two(float a, float b, uint32_t &da, uint32_t &db) {
-  const uint32_t p1 = pack_rtz16_2d(a, b);
-  const uint32_t p2 = pack_rtz16_2d(__builtin_fmaf(half_lo_2d(p1), -1.0f, a), __builtin_fmaf(half_hi_2d(p1), -1.0f, b));
-  da = __builtin_amdgcn_perm(p2, p1, 0x05040100u);
-  db = __builtin_amdgcn_perm(p2, p1, 0x07060302u);
+// x -> (h1(x) | h2(x) << 16), h1 = rtz16(x), h2 = rtz16(x - h1).  h1 as an fp32 value is x with the low thirteen mantissa
+// bits cleared (fp16 carries ten), so the remainder needs no conversion back and ONE v_cvt_pkrtz makes the whole dword:
+// three instructions per value (it was nine per two: two packs, two conversions back, two fma, two v_perm).  Below the
+// fp16 normal range (2^-14; the hit's largest value sits at 2^4 .. 2^14, see `sg`) the pair ends at the same 2^-24.
+__device__ __forceinline__ uint32_t split_one(float x) {
+  const float h1 = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
+  return pack_rtz16_2d(h1, x - h1);
 }
 // What lane `o` (0..19 of either half of the wave) reads out of the result tile: out = alpha * D[row][c1] + beta * D[row][c2],
 // beta one of {0, 1, ox, oy, kF * offx, kF * offy} by `bsel`; `cls`: which unscaling applies (0: 1 / (sv Sh), 1: 1 / sv, 2: 1 / (sv 2^10))
@@ -677,6 +682,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   const int abase = (lane & 15) * k2XStride + 4 * (lane >> 4);
   // Two hits per pass over the matrix pipe: `pend` halves of the matrix are filled (slots pend_s[0], pend_s[1] of the chunk)
   int pend = 0, pend_s0 = 0, pend_s1 = 0;
+  float pend_iw0 = 1.0f, pend_iw1 = 1.0f;   // 1 / (the hit's block-floating-point scale, see `sg` below)
   auto flush_pair = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -704,7 +710,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       beta = ro.bsel == 4 ? kFilterInvSq * (a2.z - bxc) : beta;
       beta = ro.bsel == 5 ? kFilterInvSq * (a2.w - byc) : beta;
       const float *row = dbuf + (ro.row + 8 * hh) * k2DStride;
-      const float v = (ro.alpha * row[ro.c1] + beta * row[ro.c2]) * (ro.cls == 0 ? ro_unscale * sh.y : ro_unscale);
+      const float v = (ro.alpha * row[ro.c1] + beta * row[ro.c2]) * (ro.cls == 0 ? ro_unscale * sh.y : ro_unscale) * (hh ? pend_iw1 : pend_iw0);
       atomicAdd(acc + (size_t)q_id[sl] * kAcc2Stride + (lane & 31), v);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -712,6 +718,15 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
     pend = 0;
   };
   float T = T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f, last_dL_dT = 0.0f;
+  // Block floating point per hit.  The fp16 pair x = h1 + h2 has an ABSOLUTE floor (2^-24, the last denormal): against the
+  // block's largest upstream gradient scaled into [1, 2) a hit at the rim of a faint surfel (alpha ~ 0.004, T ~ 0.3: values
+  // ~ 1e-3) was left with 14 bits, a hit deep in a list with fewer - invisible in a tensor's max norm, percent-level in
+  // the row of a surfel that only such pixels see (2-D fuzz, seeds 63 / 64: tests/test_gs2d_gpu.py).  All eight values
+  // are linear in the three per-pixel roots (t, dL/dz, w); the largest |root| over the hit's pixels (one wave maximum)
+  // gives the power of two `sg` that brings it into [2^4, 2^5) - wave-uniform, exact, undone at the read-out - so the
+  // pair keeps its 22 bits down to 2^-17 of the hit's largest value, whatever T, alpha or the depth scale are.
+  // Range: |dp| <= 12 |t| (|1 / p.z| Sh <= 4, |s| <= 3), |dp2| <= 36 |t| + 400 |dL/dz| (depth <= kFarZ): 1.4e4 at most;
+  // w * 2^10 <= 2^15.
   // gathers software-pipelined two chunks deep over the block's hit list (left by the forward), back to front: lane l of
   // the chunk that starts dn hits from the end takes the hit at 0-based position todo - 1 - dn - l
   const uint32_t *my_hits = hits + (size_t)quad * capacity + beg;
@@ -803,6 +818,14 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         dL_dal -= T_final * rinv * bg_dot;
         t = -h.Go * dL_dal;          // dL/dG * (-G), G = Go / opacity
       }
+      float inv_sg;
+      {   // the hit's power-of-two scale (see above); a hit whose roots are all zero or denormal keeps 1
+        const uint32_t eb = wave_max_u32(__float_as_uint(fmaxf(fmaxf(fabsf(t), fabsf(dL_dz)), w))) >> 23;
+        const uint32_t sb = eb == 0u ? 127u : min(258u - eb, 250u);   // 2^(4 - (eb - 127)), biased
+        const float sg = __uint_as_float(sb << 23);
+        inv_sg = __uint_as_float((254u - sb) << 23);
+        t *= sg; dL_dz *= sg; w *= sg;
+      }
       // The eight per-pixel values of this hit (zero on the lanes it does not touch), as two fp16 terms each, into the
       // matrix half `pend`; the products with the bases and the sums over the block's pixels are the matrix cores' work.
       {
@@ -821,13 +844,12 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         const float zr = dL_dz * rzs;                                       // depth = D / pz
         const float dp2 = -(dp0 * s0 + dp1 * s1) - zr * dep;
         uint32_t *rowp = xm2 + (8 * pend) * k2XStride + lane;
-        uint32_t da, db;
-        split_two(dp0, dp1, da, db); rowp[0] = da; rowp[k2XStride] = db;
-        split_two(dp2, zr, da, db); rowp[2 * k2XStride] = da; rowp[3 * k2XStride] = db;
-        split_two(z2, t2, da, db); rowp[4 * k2XStride] = da; rowp[5 * k2XStride] = db;
-        split_two(t, w * k2WScale, da, db); rowp[6 * k2XStride] = da; rowp[7 * k2XStride] = db;
+        rowp[0] = split_one(dp0); rowp[k2XStride] = split_one(dp1);
+        rowp[2 * k2XStride] = split_one(dp2); rowp[3 * k2XStride] = split_one(zr);
+        rowp[4 * k2XStride] = split_one(z2); rowp[5 * k2XStride] = split_one(t2);
+        rowp[6 * k2XStride] = split_one(t); rowp[7 * k2XStride] = split_one(w * k2WScale);
       }
-      if (pend == 0) pend_s0 = s_; else pend_s1 = s_;
+      if (pend == 0) { pend_s0 = s_; pend_iw0 = inv_sg; } else { pend_s1 = s_; pend_iw1 = inv_sg; }
       pend++;
       if (pend == 2) flush_pair();
     }

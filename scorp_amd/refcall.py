@@ -36,9 +36,9 @@ def render3d_reference_call(kw, dev, requires_grad=True, debug=False):
 def render2d_reference_call(kw, dev, requires_grad=True):
     """-> ((color, radii, allmap), leaves) through diff_surfel_rasterization.GaussianRasterizer."""
     from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    T, t, means2D = _leaves(kw, dev, requires_grad, ("means3D", "shs", "colors_precomp", "scales", "rotations"))
+    T, t, means2D = _leaves(kw, dev, requires_grad, ("means3D", "shs", "colors_precomp", "scales", "rotations", "transmat_precomp"))
     out = GaussianRasterizer(raster_settings=_settings(GaussianRasterizationSettings, kw, T, False))(
         means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["shs"], colors_precomp=t["colors_precomp"],
-        scales=t["scales"], rotations=t["rotations"], cov3D_precomp=None)
+        scales=t["scales"], rotations=t["rotations"], cov3D_precomp=t["transmat_precomp"])   # (the reference's name for the [N, 9] transforms)
     t["means2D"] = means2D
     return out, t

@@ -26,7 +26,7 @@ for k in [int(v) for v in os.environ.get("DIAG_CASES", "16,2,7").split(",")]:
     wa[5] *= 0.1
     ((color * torch.tensor(wc, device=dev)).sum() + (allmap * torch.tensor(wa, device=dev)).sum()).backward()
     g = o.backward(wc, wa); g64 = o64.backward(wc, wa)
-    for nm in ("means3D", "rotations", "scales", "opacities"):
+    for nm in ("means3D", "means2D", "rotations", "scales", "opacities"):
         got = t[nm].grad.detach().cpu().numpy().reshape(g[nm].shape)
         err = np.abs(got - g[nm]).reshape(got.shape[0], -1).max(1)
         e64 = np.abs(g[nm] - g64[nm]).reshape(got.shape[0], -1).max(1)

@@ -130,9 +130,9 @@ FUZZ_2D = fuzz_cases("2d", int(os.environ.get("SCORP_FUZZ_N", "32")), _FUZZ_SEED
 # No named exceptions any more.  Round 1's linear form of the ray-surfel intersection, expanded about the image
 # origin, needed two here (surfel 1322 of case 2 seen almost edge-on, surfel 3836 of case 7 far out on its long axis:
 # scripts/dev/diag2d_single.py) and missed the tolerance in 7 of 300 differently seeded draws; expanded about the block
-# centre, with the gradients gathered about the surfel's own centre (gs2d.hip, surfel_lin), all 32 pass as they are and
-# 1-2 of 300 remain (SCORP_FUZZ_N=300 SCORP_FUZZ_SEED=1|2|777): single pixels where alpha sits on the 1/255 threshold
-# to the last digit and the two implementations' roundings fall on different sides (scripts/dev/diag2d.py).
+# centre, with the gradients gathered about the surfel's own centre (gs2d.hip, surfel_lin), all 32 pass as they are.  Of
+# 1 120 differently seeded draws (SCORP_FUZZ_N=160, SCORP_FUZZ_SEED = 1, 2, 61 .. 64, 777) five miss, by one surfel each, and
+# in each it is the fp32 ORACLE that is off: CONDITIONING_PICKS and the test below them.
 FUZZ_2D_EXCEPTIONS = {}
 
 
@@ -140,6 +140,104 @@ FUZZ_2D_EXCEPTIONS = {}
 def test_fuzz_parity_2d(k, dev):
     """Randomised surfel cases (seeded), forward + backward against the 2-D oracle, same assertions as above."""
     _parity_2d(FUZZ_2D[k], dev, outlier_gaussians=FUZZ_2D_EXCEPTIONS.get(k, 0) if _FUZZ_SEED == 20261004 else 0)
+
+
+@pytest.mark.parametrize("seed,k", [(63, 122), (64, 140)])
+def test_faint_hits_keep_their_bits(seed, k, dev):
+    """Two fuzz scenes whose means2D gradient is carried by a few low-pass pixels of faint or deeply covered surfels
+    (alpha ~ 0.01, T down to 1e-4): the largest row of the tensor was 1e-3 / 1e-2 off while the backward's fp16 pairs rode on
+    one power of two per wave, under their absolute floor of 2^-24; with the hit's own power of two (gs2d.hip, `sg`) it is
+    within 1e-5 (scripts/dev/diag2d_rows.py prints the rows)."""
+    _parity_2d(fuzz_cases("2d", 160, seed)[k], dev)
+
+
+def _given_T(kw, rows=None):
+    """The scene with its transforms GIVEN (transmat_precomp = the fp32 oracle's T, the reference's `cov3D_precomp` argument of
+    the surfel rasterizer) - every implementation then starts from bit-identical T and the float64 build of the oracle is the
+    exact answer for them.  `rows`: keep only these surfels."""
+    from oracle.gs_oracle import OracleRender2D
+    q = dict(kw)
+    if rows is not None:
+        for key in ("means3D", "opacities", "shs", "colors_precomp", "scales", "rotations"):
+            if q.get(key) is not None:
+                q[key] = np.ascontiguousarray(q[key][rows])
+    T32 = OracleRender2D(np.float32, **q).geom()["T"].astype(np.float32)
+    q["scales"] = None; q["rotations"] = None; q["transmat_precomp"] = T32
+    return q
+
+
+def _weights(seed, c, am):
+    rng = np.random.default_rng(seed + 99)
+    wc = rng.normal(0, 1, c.shape).astype(np.float32)
+    wa = rng.normal(0, 1, am.shape).astype(np.float32)
+    wa[5] *= 0.1
+    return wc, wa
+
+
+# The surfels on which seven differently seeded draws of 160 cases (SCORP_FUZZ_SEED = 1, 2, 61 .. 64, 777: 1 120 cases) left
+# the HIP path outside the tolerance against the fp32 oracle - one surfel each, 5 cases of 1 120.  (seed, case, surfel):
+# 82 / 115 / 159: ill-conditioned intersections (the centre column of T cancels against x Tw to 1e-4 of its terms);
+# 68: a pixel whose alpha is 1.000015 / 255.
+CONDITIONING_PICKS = [(62, 82, 250), (1, 115, 5145), (64, 159, 418), (63, 68, 66)]
+
+
+@pytest.mark.parametrize("pick", CONDITIONING_PICKS, ids=lambda p: "seed%d_case%d_surfel%d" % p)
+def test_fuzz_outliers_are_the_fp32_oracles_rounding_not_the_hip_paths(pick, dev):
+    """Each of those surfels alone, its transform given: against the EXACT answer for the same fp32 T (the float64 build) the
+    HIP path's alpha map and gradients are closer than the fp32 oracle's - the reference's own order of operations in fp32
+    (k = x Tw - Tu, p = k x l) loses 1e-4 .. 3e-2 there, the block-centred linear form (gs2d.hip, surfel_lin) 1e-6 .. 1e-4."""
+    from oracle.gs_oracle import OracleRender2D
+    seed, k, gid = pick
+    case = fuzz_cases("2d", 160, seed)[k]
+    kw, _ = make_case2d(**case)
+    given = _given_T(kw, rows=slice(gid, gid + 1))
+    o32, o64 = OracleRender2D(np.float32, **given), OracleRender2D(np.float64, **given)
+    (color, radii, allmap), t = hip_render2d(given, dev)
+    assert int(radii[0]) == int(o32.radii[0]) > 0
+    am = allmap.detach().cpu().numpy()
+    e_hip, e_o32 = np.abs(am[1] - o64.allmap[1]).max(), np.abs(o32.allmap[1] - o64.allmap[1]).max()
+    assert e_hip <= max(1e-5, e_o32), f"alpha: HIP {e_hip:.3e} from exact, fp32 oracle {e_o32:.3e}"
+    wc, wa = _weights(case["seed"], color.detach().cpu().numpy(), am)
+    ((color * torch.tensor(wc, device=dev)).sum() + (allmap * torch.tensor(wa, device=dev)).sum()).backward()
+    g32, g64 = o32.backward(wc, wa), o64.backward(wc, wa)
+    for nm, key in (("transmat", "transmat_precomp"), ("opacities", "opacities")):
+        got = t[key].grad.detach().cpu().numpy().reshape(-1).astype(np.float64)
+        r32, r64 = np.asarray(g32[nm], np.float64).reshape(-1), np.asarray(g64[nm], np.float64).reshape(-1)
+        sc = np.abs(r64).max()
+        e_hip, e_o32 = np.abs(got - r64).max() / sc, np.abs(r32 - r64).max() / sc
+        assert e_hip <= max(2e-4, e_o32), f"grad {nm}: HIP {e_hip:.3e} from exact, fp32 oracle {e_o32:.3e}"
+
+
+def given_T_check(kw, seed, dev, report=None):
+    """The scene with its transforms given: per gradient tensor the HIP path's relative L1 distance to the exact answer (the
+    float64 build on the same fp32 T) is at most max(1e-4, 1.25 x the fp32 oracle's own) - tests.util.assert_no_further_from_f64;
+    `report[name]` = (relL1(HIP, exact), relL1(oracle32, exact), max-norm(HIP, exact), max-norm(oracle32, exact))."""
+    from oracle.gs_oracle import OracleRender2D
+    from tests.util import assert_no_further_from_f64, grad_errors
+    given = _given_T(kw)
+    o32, o64 = OracleRender2D(np.float32, **given), OracleRender2D(np.float64, **given)
+    (color, radii, allmap), t = hip_render2d(given, dev)
+    assert_radii_match(radii.cpu().numpy(), o32.radii)
+    c, am = color.detach().cpu().numpy(), allmap.detach().cpu().numpy()
+    assert np.abs(c - o64.color).mean() <= max(IMG_L1_TOL, 1.25 * np.abs(o32.color - o64.color).mean())
+    wc, wa = _weights(seed, c, am)
+    ((color * torch.tensor(wc, device=dev)).sum() + (allmap * torch.tensor(wa, device=dev)).sum()).backward()
+    g32, g64 = o32.backward(wc, wa), o64.backward(wc, wa)
+    names = [("transmat", "transmat_precomp"), ("opacities", "opacities"), ("means3D", "means3D")]
+    names.append(("shs", "shs") if t["shs"] is not None else ("colors_precomp", "colors_precomp"))
+    for nm, key in names:
+        got = t[key].grad.detach().cpu().numpy()
+        e = assert_no_further_from_f64(nm, got, g32[nm], g64[nm])
+        if report is not None:
+            report[nm] = e + (grad_errors(got, g64[nm])[0], grad_errors(g32[nm], g64[nm])[0])
+
+
+@pytest.mark.parametrize("k", list(range(8)) + [26])
+def test_given_transforms_hip_is_no_further_from_exact_than_the_fp32_oracle(k, dev):
+    """Whole fuzz scenes (2 and 26 are the two of the 32 whose gradients pass against the fp32 oracle only through its
+    indecision band) with the transforms given."""
+    case = FUZZ_2D[k]
+    given_T_check(make_case2d(**case)[0], case["seed"], dev)
 
 
 def test_edge_on_surfel_sliver_is_not_culled(dev):
