@@ -192,8 +192,8 @@ constexpr int kMaxCells = 8192;         // the scatter's prologue scans this man
 #define SCORP_TWO_LEVEL_MIN_N 0
 #endif
 
-// SCORP_ONE_LEVEL_BINNING=1 in the environment (read once per process): every view takes the one-level binning - what stacked
-// views and images beyond kMaxCells cells take anyway - so that the tests can hold that path against the oracle as well.
+// SCORP_ONE_LEVEL_BINNING=1 in the environment (read once per process): every view takes the one-level binning - what images
+// beyond kMaxCells cells or 2^28 (virtual) Gaussians take anyway - so that the tests can hold that path against the oracle as well.
 inline bool one_level_binning_forced() {
   static const bool forced = [] { const char *e = getenv("SCORP_ONE_LEVEL_BINNING"); return e && e[0] == '1'; }();
   return forced;
@@ -206,12 +206,13 @@ struct StateLayout {
   bool two_level;      // bins of the count / scan / scatter kernels are cells; expand_cells_kernel makes the tile buckets
   int views, view_n;   // stacked views (ScorpGs3dInputs.num_views): binning pass v owns view v's Gaussians AND tiles
   bool lds_binning;
+  // (the three below describe the ONE-level binning; the two-level one is a single pass over everything)
   int bin_passes() const { return views > 1 ? views : (tiles + kMaxLdsTiles - 1) / kMaxLdsTiles; }
   int tiles_per_pass() const { return views > 1 ? tiles / views : (tiles < kMaxLdsTiles ? tiles : kMaxLdsTiles); }
   int bin_n() const { return views > 1 ? view_n : -1; }   // Gaussians a pass looks at (-1: all of them)
   // up to 8192 tiles (one pass, 8 counts per thread) every scatter workgroup scans the tile totals itself while it sets
   // up its LDS cursors, and the one-workgroup scan launch between the count and the scatter is dropped
-  bool scan_in_scatter() const { return lds_binning && (two_level || tiles <= 8192) && views <= 1; }
+  bool scan_in_scatter() const { return lds_binning && (two_level || (tiles <= 8192 && views <= 1)); }
   // views_ > 1: N and H are the TOTALS of views_ stacked views (N / views_ Gaussians, H / views_ rows each).  View v's
   // Gaussians only reach the tiles of band v, so the binning runs as views_ passes, pass v over view v's Gaussians with a
   // histogram of view v's tiles only: nb blocks PER VIEW and a block-histogram matrix of nb x tiles counters instead of
@@ -239,15 +240,17 @@ struct StateLayout {
     n_contrib = off; off = align_up(off + hw * 4 * (mode2d ? 2 : 1), 256);   // ... and the median contributor
     block_hits = off; off = align_up(off + (size_t)tiles * 4 * 4, 256);      // per 8x8 block: hits the blend forward replayed
     nb = bin_blocks(N, tiles);
-    if (views > 1) {
+    lds_binning = tiles <= 64 * kMaxLdsTiles;   // (beyond: the global-atomic fallback; 150 M pixels)
+    // (stacked views too: the V x N virtual Gaussians of the stacked image are binned in ONE pass - a cell that straddles two
+    // views' bands is only a bucket - instead of V passes with a tile histogram each and a one-workgroup scan of all tiles)
+    two_level = lds_binning && N < (1 << kCellShift) && N >= SCORP_TWO_LEVEL_MIN_N && cells <= kMaxCells &&
+                !one_level_binning_forced();
+    if (views > 1 && !two_level) {
       // (a view's blocks write only the view's segment of their histogram row, so nb is the number of blocks PER VIEW; more
       // than ~16 bought nothing at 15 views: the scatter is bound by its 8-byte pair stores, 64 blocks measured 69 vs 68 us)
       const int per_view = bin_blocks(view_n, tiles / views), cap = kBinBlocksMax / views > 16 ? kBinBlocksMax / views : 16;
       nb = per_view < cap ? per_view : cap;
     }
-    lds_binning = tiles <= 64 * kMaxLdsTiles;   // (beyond: the global-atomic fallback; 150 M pixels)
-    two_level = lds_binning && views <= 1 && N < (1 << kCellShift) && N >= SCORP_TWO_LEVEL_MIN_N && cells <= kMaxCells &&
-                !one_level_binning_forced();
     block_hist = off; off = align_up(off + (lds_binning ? (size_t)nb * tiles * 4 : 0), 256);
     total = off;
   }

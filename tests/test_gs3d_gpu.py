@@ -655,10 +655,11 @@ def test_indefinite_conic_is_skipped_where_power_is_positive(precision, dev):
 
 
 def test_one_level_binning_path_in_a_child_process():
-    """Single views take the two-level binning (cells, then tiles).  The one-level path - what stacked views and images beyond
-    8 192 cells take - is held against the oracle too: a child process with SCORP_ONE_LEVEL_BINNING=1 (the switch is read once
-    per process) runs the stage-parity and forward / backward parity tests of the cases that exercise its branches: ragged
-    sizes, LDS histograms above 64 KiB, two and three tile-range passes, long lists."""
+    """Views take the two-level binning (cells, then tiles).  The one-level path - what images beyond 8 192 cells or 2^28
+    (virtual) Gaussians take - is held against the oracle too: a child process with SCORP_ONE_LEVEL_BINNING=1 (the switch is read
+    once per process) runs the stage-parity and forward / backward parity tests of the cases that exercise its branches: ragged
+    sizes, LDS histograms above 64 KiB, two and three tile-range passes, long lists - and the stacked views (one binning pass
+    per view there) against the single renders."""
     import subprocess
     import sys
     env = dict(os.environ, SCORP_ONE_LEVEL_BINNING="1")
@@ -668,3 +669,7 @@ def test_one_level_binning_path_in_a_child_process():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+    aux = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_aux_gpu.py")
+    r = subprocess.run([sys.executable, "-m", "pytest", aux, "-q", "-x", "-m", "gpu", "-k", "test_stacked_views_equal_single_views"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
