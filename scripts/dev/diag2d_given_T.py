@@ -12,6 +12,13 @@ dev = torch.device('cuda:0')
 for seed, nn, k, gid in [tuple(int(v) for v in p.split(":")) for p in os.environ["DIAG_PICKS"].split(",")]:
     case = fuzz_cases("2d", nn, seed)[k]
     kw, _ = make_case2d(**case)
+    if gid < 0:   # the surfel whose means3D gradient is furthest from the fp32 oracle's in the whole scene
+        (c0, _, a0), t0 = hip_render2d(kw, dev)
+        rng0 = np.random.default_rng(case["seed"] + 99)
+        wc0 = rng0.normal(0, 1, tuple(c0.shape)).astype(np.float32); wa0 = rng0.normal(0, 1, tuple(a0.shape)).astype(np.float32); wa0[5] *= 0.1
+        ((c0 * torch.tensor(wc0, device=dev)).sum() + (a0 * torch.tensor(wa0, device=dev)).sum()).backward()
+        gs = OracleRender2D(np.float32, **kw).backward(wc0, wa0)
+        gid = int(np.abs(t0["means3D"].grad.detach().cpu().numpy() - gs["means3D"]).max(1).argmax())
     one = dict(kw)
     for key in ("means3D", "opacities", "shs", "scales", "rotations"):
         if one.get(key) is not None:

@@ -79,6 +79,10 @@ for seed, nn, k, gid, px, py in picks:
                 if a[0] >= 1 / 255 and abs(a[1] - a[2]) < 2e-3 * max(a[2], 1e-9):
                     print(f"   tie at ({xx},{yy}): exact rho3d {a[1]:.7f} rho2d {a[2]:.7f} | reference fp32 order rho3d {b[1]:.7f} rho2d {b[2]:.7f} alpha {a[0]:.5f}")
         continue
+    print("   centre hip", repr(xy[0]), "f32", repr(g["xy"][0]), "f64", repr(g64["xy"][0]))
+    for nm, c in (("hip", xy[0]), ("f32", g["xy"][0])):
+        r2 = np.float32(2.0) * (np.float32(c[0] - np.float32(px)) ** 2 + np.float32(c[1] - np.float32(py)) ** 2)
+        print(f"   rho2d in fp32 from the {nm} centre: {float(r2):.9f}")
     print("   T hip   ", Tm[0]); print("   T f32   ", g["T"][0]); print("   T f64   ", g64["T"][0])
     print("   rel |T hip - T f64| / |T f64| per entry", np.abs(Tm[0] - g64["T"][0]) / np.maximum(np.abs(g64["T"][0]), 1e-30))
     print("   rel |T f32 - T f64| / |T f64| per entry", np.abs(g["T"][0] - g64["T"][0]) / np.maximum(np.abs(g64["T"][0]), 1e-30))
