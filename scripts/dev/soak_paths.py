@@ -39,7 +39,14 @@ for it in range(40):
         pa = render(cam, a, pipe, bg)
         la = fused_l1_ssim_loss(pa["render"], gt, 0.2, mask); la.backward()
         pb = train_view(cam, b, pipe, bg, gt, 0.2, mask=mask)
-        PairPolicy.drain()
+        try:
+            PairPolicy.drain()
+        except RuntimeError as e:   # PairOverflow: the one-call view was discarded and the reservation grown - the contract is "run it again"
+            if "re-run" not in str(e):
+                raise
+            b = GaussianModel.from_raw(raw, 3, device=dev); b.active_sh_degree = deg
+            pb = train_view(cam, b, pipe, bg, gt, 0.2, mask=mask)
+            PairPolicy.drain()
         ok = torch.equal(pa["render"], pb["render"]) and torch.equal(pa["radii"], pb["radii"]) and abs(float(la) - float(pb["loss"])) < 1e-7
         ok = ok and all(close(getattr(a, n).grad, getattr(b, n).grad) for n in names)
         # deterministic: twice the same bits, and close to the atomic form
