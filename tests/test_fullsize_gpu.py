@@ -147,18 +147,19 @@ def test_full_size_parity_vs_oracle_2d(cam, dev, parallel_oracle):
         print("  elements beyond the max-norm tolerance after the band: " + ", ".join(f"{n} {c}" for n, c in BAND_TALLY.get("beyond", [])[-6:]))
 
 
-def test_full_size_given_transforms_2d(dev, parallel_oracle):
-    """S6 view 0 with the surfels' transforms given (transmat_precomp = the fp32 oracle's T): HIP path, fp32 oracle and the
+@pytest.mark.parametrize("cam", _VIEWS)
+def test_full_size_given_transforms_2d(cam, dev, parallel_oracle):
+    """S6 (view 0 unless SCORP_FULLSIZE_VIEWS names others) with the surfels' transforms given (transmat_precomp = the fp32 oracle's T): HIP path, fp32 oracle and the
     exact answer (float64 build) start from bit-identical T, so the ill-conditioned intersections stop being a question of
     whose rounding of T one believes.  Asserted per gradient tensor: relL1(HIP, exact) <= max(1e-4, 1.25 x relL1(oracle32, exact))."""
     from tests.test_gs2d_gpu import given_T_check
-    kw = _scene_kw("S6", _VIEWS[0])
+    kw = _scene_kw("S6", cam)
     kw["scale_modifier"] = 1.0
     report = {}
     try:
         given_T_check(kw, 6, dev, report=report)
     finally:
-        print("\nS6 full size, transforms given:  relL1 HIP vs exact | oracle32 vs exact || max-norm HIP vs exact | oracle32 vs exact")
+        print(f"\nS6 full size, view {cam}, transforms given:  relL1 HIP vs exact | oracle32 vs exact || max-norm HIP vs exact | oracle32 vs exact")
         for k, (eh, eo, mh, mo) in report.items():
             print(f"  {k:10s} {eh:.2e} | {eo:.2e} || {mh:.2e} | {mo:.2e}")
 
