@@ -456,6 +456,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))      # bare `python bench.py --gpus N`: this process only starts the N ranks (no GPU call made here)
+    # ONE line on stdout: whatever else writes to file descriptor 1 from here on - gloo's connection banner, a library's
+    # printf, a stray print() - goes to stderr; the JSON line leaves through a private duplicate of the original descriptor.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -877,7 +882,8 @@ def main():
         line["roofline"] = roof
         if cpu_rec is not None:
             line["cpu_baseline"] = cpu_rec
-        print(json.dumps(line, separators=(",", ":")), flush=True)
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(line, separators=(",", ":")) + "\n").encode())
         parity_failed = line.get("parity_ok") is False
     if world > 1:
         try:
