@@ -206,6 +206,20 @@ int scorp_gs2d_render_image(const ScorpGs3dInputs *in, void *state, void *pairs,
 int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
                         const float *dL_dcolor, const float *dL_dallmap, const ScorpGs3dGrads *grads, void *scratch,
                         size_t scratch_bytes, scorp_stream_t stream);
+/* The same with the `flags` of scorp_gs3d_backward_ex.  The surfel backward reduces eight per-pixel values of a hit over
+ * the block's pixels on the matrix cores; by default they travel as two fp16 terms each under a per-hit power of two (22
+ * bits, exact products, fp32 accumulation).  SCORP_BACKWARD_EXACT_FP32: the values and the upstream gradients stay fp32
+ * and the reduction runs on fp32 MFMAs - no operand narrower than the reference's fp32 arithmetic
+ * (gs2dgs/gaussian_renderer/__init__.py:111-120 under train_2dgs.py:142-150).  SCORP_BACKWARD_DETERMINISTIC: no float
+ * atomics - one plain 80-byte row per (8x8 block, hit) and an ordered per-surfel sum, as in 3-D; two runs give the same bits
+ * (utils/mask.py:52-124 votes on signs of repeated backward passes).  SCORP_BACKWARD_SCRATCH_ZEROED is ignored.
+ * scratch: scorp_gs2d_backward_scratch_bytes_ex(flags) (num_gaussians * 80 bytes, plus for the deterministic form
+ * num_gaussians + 1 pair ordinals, 4 * capacity flag bytes and 4 * capacity rows of 80 bytes). */
+size_t scorp_gs2d_backward_scratch_bytes_ex(int32_t num_gaussians, int32_t image_width, int32_t image_height, uint64_t capacity,
+                                            uint32_t flags);
+int scorp_gs2d_backward_ex(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
+                           const float *dL_dcolor, const float *dL_dallmap, const ScorpGs3dGrads *grads, void *scratch,
+                           size_t scratch_bytes, uint32_t flags, scorp_stream_t stream);
 /* T[N,9], xy[N,2], depth[N], normal_opacity[N,4], rgb[N,3], rect[N,4]; any may be NULL (stage-level parity tests). */
 int scorp_gs2d_debug_geom(const void *state, int32_t num_gaussians, int32_t image_width, int32_t image_height, float *T,
                           float *xy, float *depth, float *normal_opacity, float *rgb, int32_t *rect,
@@ -347,8 +361,9 @@ typedef struct ScorpGs2dTrainView {
   float *grad_color;             /* [3,H,W] scratch */
   float *grad_allmap;            /* [7,H,W] scratch */
   const ScorpGs3dGrads *grads;
-  void *backward_scratch;        /* scorp_gs2d_backward_scratch_bytes(N) */
+  void *backward_scratch;        /* scorp_gs2d_backward_scratch_bytes(N) (scorp_gs2d_backward_scratch_bytes_ex with backward_flags) */
   size_t backward_scratch_bytes;
+  uint32_t backward_flags;       /* flags of scorp_gs2d_backward_ex for the view's backward; 0 = default */
 } ScorpGs2dTrainView;
 int scorp_gs2d_train_view(const ScorpGs2dTrainView *view, scorp_stream_t stream);
 

@@ -51,7 +51,8 @@ class ScorpGs2dTrainView(ctypes.Structure):
                 ("loss_workspace", ctypes.c_void_p), ("loss_workspace_bytes", ctypes.c_size_t),
                 ("reg_workspace", ctypes.c_void_p), ("reg_workspace_bytes", ctypes.c_size_t),
                 ("grad_color", ctypes.c_void_p), ("grad_allmap", ctypes.c_void_p), ("grads", ctypes.c_void_p),
-                ("backward_scratch", ctypes.c_void_p), ("backward_scratch_bytes", ctypes.c_size_t)]
+                ("backward_scratch", ctypes.c_void_p), ("backward_scratch_bytes", ctypes.c_size_t),
+                ("backward_flags", ctypes.c_uint32)]
 
 
 class ScorpRowTensor(ctypes.Structure):
@@ -73,7 +74,7 @@ EXPORTS = [
     "scorp_gs3d_pose_score_accumulate",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
     "scorp_gs2d_render_image",
-    "scorp_gs2d_backward", "scorp_gs2d_debug_geom", "scorp_gs2d_debug_tiles", "scorp_gs2d_maps_forward",
+    "scorp_gs2d_backward", "scorp_gs2d_backward_ex", "scorp_gs2d_backward_scratch_bytes_ex", "scorp_gs2d_debug_geom", "scorp_gs2d_debug_tiles", "scorp_gs2d_maps_forward",
     "scorp_gs2d_maps_backward", "scorp_gs2d_regularizers_workspace_bytes", "scorp_gs2d_regularizers_forward",
     "scorp_gs2d_regularizers_backward", "scorp_gs3d_train_view", "scorp_gs2d_train_view",
     "scorp_prof_enable", "scorp_prof_select", "scorp_prof_num_kernels", "scorp_prof_kernel_name", "scorp_prof_collect",
@@ -137,6 +138,10 @@ def lib():
     L.scorp_gs2d_render.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp]
     L.scorp_gs2d_render_image.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp]
     L.scorp_gs2d_backward.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, ctypes.POINTER(ScorpGs3dGrads), vp, sz, vp]
+    L.scorp_gs2d_backward_ex.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, ctypes.POINTER(ScorpGs3dGrads), vp, sz,
+                                         ctypes.c_uint32, vp]
+    L.scorp_gs2d_backward_scratch_bytes_ex.restype = sz
+    L.scorp_gs2d_backward_scratch_bytes_ex.argtypes = [i32, i32, i32, u64, ctypes.c_uint32]
     L.scorp_gs2d_debug_geom.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.scorp_gs2d_debug_tiles.argtypes = [vp, vp, u64, i32, i32, i32, vp, vp, vp]
     L.scorp_gs2d_maps_forward.argtypes = [i32, i32, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, vp, vp, vp]

@@ -273,6 +273,27 @@ struct PairLayout {
   }
 };
 
+// Scratch of the deterministic backward (SCORP_BACKWARD_DETERMINISTIC), 3-D and 2-D:
+// [accumulator rows][pair_base N + 1][block sums of the scan][one flag byte per row][4 x capacity rows of row_floats floats]
+constexpr int kPairScanBlock = 1024;   // Gaussians per workgroup of the pair-count scan (gs3d_backward.hip)
+struct DetLayout {
+  size_t acc, pair_base, block_sums, flags, partial, total;
+  int scan_blocks;
+  DetLayout(int N, uint64_t capacity, int row_floats) {
+    const size_t n = N > 0 ? (size_t)N : 1, c = capacity > 0 ? (size_t)capacity : 1;
+    scan_blocks = (int)((n + kPairScanBlock - 1) / kPairScanBlock);
+    size_t off = 0;
+    acc = off; off = align_up(off + n * row_floats * sizeof(float), 256);
+    pair_base = off; off = align_up(off + (n + 1) * sizeof(uint32_t), 256);
+    block_sums = off; off = align_up(off + (size_t)scan_blocks * sizeof(uint32_t), 256);
+    flags = off; off = align_up(off + c * 4, 256);
+    partial = off; off = align_up(off + c * 4 * row_floats * sizeof(float), 256);
+    total = off;
+  }
+};
+int launch_pair_base(int N, const BinRec *bin, const uint64_t *tile_mask, uint32_t *block_sums, uint32_t *pair_base,
+                     hipStream_t stream);
+
 // ---- in-library kernel timing (api.hip) ----
 enum KernelId {
   kKPreprocess = 0, kKCountTiles, kKScanTiles, kKScatterPairs, kKSortTiles, kKBlendForward, kKBlendBackward, kKPreprocessBackward,

@@ -531,8 +531,21 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
 typedef float f32x4_2d __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_2d __attribute__((ext_vector_type(8)));
 union Frag2 { f16x8_2d v; uint4 q; uint32_t d[4]; };
-constexpr int k2XStride = 68;                // dwords per row of the [16][64] value matrix (16-byte aligned rows, conflict-free row writes)
-constexpr int k2DStride = 17;                // floats per row of the 16 x 16 result tile (odd: the read-out lanes hit distinct banks)
+// Row strides chosen by the LDS banking rules (MI355X_MICROARCH.md, section LDS; scripts/dev/lds_conflicts.py does the arithmetic):
+// a ds_read_b128 is served in four 16-lane groups that each hold all sixteen matrix rows, eight from one K group of the MFMA
+// operand and eight from the next (+ 4 dwords).  With 68 dwords per row the sixteen 16-byte slots of a group collided pairwise
+// (8 LDS cycles per read instead of 4); with 72 a row starts two slots after the previous one, the rows of one K group take the
+// even slots and those of the other the odd ones.  The result tile's rows are 20 floats apart so that the four rows a
+// ds_write_b32 touches per 32-lane group start 16 banks apart (17: 4 cycles per write instead of 2).  Round 5's counters had
+// 43.8 M conflict cycles per launch on S6 (44 % of the LDS-active cycles): 16 per pair from the reads, 8 from the writes.
+#ifndef SCORP_2D_XSTRIDE
+#define SCORP_2D_XSTRIDE 72
+#endif
+#ifndef SCORP_2D_DSTRIDE
+#define SCORP_2D_DSTRIDE 20
+#endif
+constexpr int k2XStride = SCORP_2D_XSTRIDE;  // dwords per row of the [16][64] value matrix (16-byte aligned rows, conflict-free row writes)
+constexpr int k2DStride = SCORP_2D_DSTRIDE;  // floats per row of the 16 x 16 result tile
 #ifndef SCORP_2D_TARGET_EXP
 #define SCORP_2D_TARGET_EXP 12
 #endif
@@ -582,21 +595,33 @@ constexpr int k2BChunk = SCORP_2D_BCHUNK;   // hits staged per chunk: 32 (the st
 #ifndef SCORP_2D_BWAVES
 #define SCORP_2D_BWAVES 3
 #endif
-template <bool kHasMap>
+// Three forms, as for the 3-D kernel (scorp_gs2d_backward_ex, include/scorp_gs.h):
+//   * SPLIT (default): the description above.
+//   * kExact (SCORP_BACKWARD_EXACT_FP32): the eight values of a hit stay fp32 in the matrix, the B operand holds the basis and
+//     the six upstream gradients in fp32 (nine columns), the reduction is 16 v_mfma_f32_16x16x4_f32 per pair of hits.  No
+//     fp16 terms, so none of the three power-of-two scales either (wave, hit, 1 / p.z): every operand is the fp32 number the
+//     reference's arithmetic would carry.  The fp32 MFMA runs at the vector rate (34 cycles each): this
+//     form pays 8 of them per hit where the split form pays 2 fp16 ones, and saves the split's ~40 instructions.
+//   * kDet (SCORP_BACKWARD_DETERMINISTIC): the twenty sums of a (block, hit) leave as one plain row
+//     partial[4 * pair + block] (pair = the (surfel, tile) pair's ordinal in surfel-major order, gs3d_backward.hip) with a
+//     flag byte; reduce_pair_rows2d_kernel adds a surfel's rows in a fixed order.  No float atomics.
+template <bool kHasMap, bool kExact = false, bool kDet = false>
 __global__ void __launch_bounds__(64, SCORP_2D_BWAVES)
 blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                              const Surfel *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                              const float *__restrict__ bg, const float *__restrict__ final_T,
                              const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dcolor,
                              const float *__restrict__ dL_dallmap, float *__restrict__ acc,
-                             const uint32_t *__restrict__ hits) {
+                             const uint32_t *__restrict__ hits, float *__restrict__ partial, uint8_t *__restrict__ row_flags,
+                             const uint32_t *__restrict__ pair_base, const BinRec *__restrict__ bin,
+                             const uint64_t *__restrict__ tile_mask) {
   __shared__ float4 q0[k2BChunk], q1[k2BChunk], q2[k2BChunk], q3[k2BChunk], q4[k2BChunk], q5[k2BChunk];
   __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];   // q0..q3: SurfelLin, q4: (normal, r), q5: (g, b, ox, oy)
   __shared__ float2 q6[k2BChunk];                        // (Sh, 1 / Sh): the hit's power-of-two scale for the 1 / p.z values
   // [row = hit of the pair x kind][pixel] matrix of (h1 | h2 << 16) dwords; the 16 x 16 result tile reuses its first rows
   __shared__ __attribute__((aligned(16))) uint32_t xm2[16 * k2XStride];
   float *dbuf = reinterpret_cast<float *>(xm2);
-  static_assert(16 * k2DStride <= 4 * k2XStride && 64 * 6 <= 16 * k2XStride, "the result tile and the prologue scratch fit the matrix");
+  static_assert(16 * k2DStride <= 16 * k2XStride && 64 * 6 <= 16 * k2XStride, "the result tile and the prologue scratch fit the matrix");
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
@@ -635,8 +660,8 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   for (int off = 32; off >= 1; off >>= 1) todo = max(todo, (uint32_t)__shfl_xor((int)todo, off, 64));
   todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);   // wave-uniform: keeps the chunk loop's counters in SGPRs
   // one power-of-two scale per wave from the block's largest upstream gradient (exact; everything below is linear in them)
-  float sv, inv_sv;
-  {
+  float sv = 1.0f, inv_sv = 1.0f;
+  if constexpr (!kExact) {
     float amax = fmaxf(fmaxf(fabsf(dpix0), fabsf(dpix1)), fabsf(dpix2));
     if (kHasMap) amax = fmaxf(fmaxf(fmaxf(amax, fabsf(ddep)), fmaxf(fabsf(dacc), fabsf(dmed))),
                               fmaxf(fmaxf(fabsf(dn0), fabsf(dn1)), fmaxf(fabsf(dn2), fabsf(dreg))));
@@ -649,7 +674,8 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   const float bg_dot = bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2;   // (of the SCALED gradients, like everything below)
   // B operand.  A lane supplies ONE column bn of the basis for the pixels 16 m + 4 bk + j (MFMA m, j = 0..3), each value twice
   // (once per fp16 term of the A side).  The six gradient columns come from the other lanes through LDS (the matrix is idle).
-  Frag2 bh[4];
+  Frag2 bh[kExact ? 1 : 4];
+  float bb[kExact ? 16 : 1];   // exact form: fp32 MFMA 4 m + j covers the pixels 16 m + 4 bk + j (one per K slot bk)
   {
     float *xs = reinterpret_cast<float *>(xm2);
     xs[lane * 6 + 0] = dn0; xs[lane * 6 + 1] = dn1; xs[lane * 6 + 2] = dn2;
@@ -666,19 +692,25 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         b = bn == 0 ? 1.0f : b;
         b = bn == 1 ? (float)(q & 7) - 3.5f : b;
         b = bn == 2 ? (float)(q >> 3) - 3.5f : b;
-        if (bn >= 3 && bn <= 14) {
-          const float g = xs[q * 6 + (bn - 3) % 6];
-          const float g1 = half_lo_2d(pack_rtz16_2d(g, 0.0f));
-          b = bn <= 8 ? g1 : g - g1;                       // columns 3..8: first fp16 term, 9..14: the remainder
+        if constexpr (kExact) {
+          if (bn >= 3 && bn <= 8) b = xs[q * 6 + (bn - 3)];   // columns 3..8: the six upstream gradients, whole; 9..15: zero
+          bb[4 * m + j] = b;
+        } else {
+          if (bn >= 3 && bn <= 14) {
+            const float g = xs[q * 6 + (bn - 3) % 6];
+            const float g1 = half_lo_2d(pack_rtz16_2d(g, 0.0f));
+            b = bn <= 8 ? g1 : g - g1;                       // columns 3..8: first fp16 term, 9..14: the remainder
+          }
+          const uint32_t hb = pack_rtz16_2d(b, 0.0f) & 0xFFFFu;
+          bh[m].d[j] = hb | (hb << 16);
         }
-        const uint32_t hb = pack_rtz16_2d(b, 0.0f) & 0xFFFFu;
-        bh[m].d[j] = hb | (hb << 16);
       }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
   const ReadOut ro = read_out_of(lane & 31);
-  const float ro_unscale = ro.cls == 2 ? inv_sv * (1.0f / k2WScale) : inv_sv;
+  constexpr float kWCarry = kExact ? 1.0f : k2WScale;   // the blend weight travels as w * 2^10 in the split form only
+  const float ro_unscale = ro.cls == 2 ? inv_sv * (1.0f / kWCarry) : inv_sv;
   const int abase = (lane & 15) * k2XStride + 4 * (lane >> 4);
   // Two hits per pass over the matrix pipe: `pend` halves of the matrix are filled (slots pend_s[0], pend_s[1] of the chunk)
   int pend = 0, pend_s0 = 0, pend_s1 = 0;
@@ -686,12 +718,25 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
   auto flush_pair = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    Frag2 af[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) af[m].q = *reinterpret_cast<const uint4 *>(&xm2[abase + 16 * m]);
     f32x4_2d d = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (kExact) {
+      float4 av[4];
 #pragma unroll
-    for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m].v, bh[m].v, d, 0, 0, 0);
+      for (int m = 0; m < 4; m++) av[m] = *reinterpret_cast<const float4 *>(&xm2[abase + 16 * m]);
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].x, bb[4 * m], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].y, bb[4 * m + 1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].z, bb[4 * m + 2], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].w, bb[4 * m + 3], d, 0, 0, 0);
+      }
+    } else {
+      Frag2 af[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) af[m].q = *reinterpret_cast<const uint4 *>(&xm2[abase + 16 * m]);
+#pragma unroll
+      for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m].v, bh[m].v, d, 0, 0, 0);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();   // every lane has its A operands: the result tile may overwrite the matrix
 #pragma unroll
@@ -703,15 +748,26 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       const int sl = hh ? pend_s1 : pend_s0;
       const float4 gb = q5[sl];
       const float4 a2 = q2[sl];
-      const float2 sh = q6[sl];
+      float2 sh = make_float2(1.0f, 1.0f);
+      if constexpr (!kExact) sh = q6[sl];
       float beta = ro.bsel == 1 ? 1.0f : 0.0f;
       beta = ro.bsel == 2 ? gb.z : beta;
       beta = ro.bsel == 3 ? gb.w : beta;
       beta = ro.bsel == 4 ? kFilterInvSq * (a2.z - bxc) : beta;
       beta = ro.bsel == 5 ? kFilterInvSq * (a2.w - byc) : beta;
       const float *row = dbuf + (ro.row + 8 * hh) * k2DStride;
-      const float v = (ro.alpha * row[ro.c1] + beta * row[ro.c2]) * (ro.cls == 0 ? ro_unscale * sh.y : ro_unscale) * (hh ? pend_iw1 : pend_iw0);
-      atomicAdd(acc + (size_t)q_id[sl] * kAcc2Stride + (lane & 31), v);
+      float v = ro.alpha * row[ro.c1] + beta * row[ro.c2];
+      if constexpr (!kExact) v = v * (ro.cls == 0 ? ro_unscale * sh.y : ro_unscale) * (hh ? pend_iw1 : pend_iw0);
+      if constexpr (kDet) {   // (q_id holds the pair's ordinal; one beyond the reservation: an overflowed view, discarded anyway)
+        const uint32_t pair = q_id[sl];
+        if (pair < capacity) {
+          const size_t r = (size_t)pair * 4u + (uint32_t)quad;
+          partial[r * kAcc2Stride + (lane & 31)] = v;   // whole rows, zeros included: nothing was cleared beforehand
+          if ((lane & 31) == 0) row_flags[r] = 1;
+        }
+      } else {
+        atomicAdd(acc + (size_t)q_id[sl] * kAcc2Stride + (lane & 31), v);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the next hits' rows overwrite the result tile
@@ -760,18 +816,33 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       q0[qi] = L.e0; q1[qi] = L.e1; q2[qi] = L.e2; q3[qi] = L.e3; q4[qi] = r3;
       // (ox, oy) = block centre - the surfel's accumulation point (its centre clamped into the image)
       q5[qi] = make_float4(r4.x, r4.y, bxc - fminf(fmaxf(r2.y, 0.0f), (float)(W - 1)), byc - fminf(fmaxf(r2.z, 0.0f), (float)(H - 1)));
-      q_id[qi] = id; q_pos[qi] = top - (uint32_t)lane + 1u;
+      if constexpr (kDet) {
+        // the (surfel, tile) pair's ordinal, surfel-major: pair_base[id] + the rank of this tile among the tiles the surfel
+        // reaches (for_each_tile's order: the set bits of its mask, or its whole rectangle row by row)
+        const uint4 raw = reinterpret_cast<const uint4 *>(bin)[id];
+        const BinRec br = *reinterpret_cast<const BinRec *>(&raw);
+        const uint64_t mk = tile_mask[id];
+        const int tx = tile % tiles_x, ty = tile / tiles_x;
+        const uint32_t rank = mk == kMaskAll ? (uint32_t)((ty - br.y0) * (br.x1 - br.x0) + (tx - br.x0))
+                                             : (uint32_t)__builtin_popcountll(mk & ((1ull << ((ty - br.y0) * 8 + (tx - br.x0))) - 1ull));
+        q_id[qi] = pair_base[id] + rank;
+      } else {
+        q_id[qi] = id;
+      }
+      q_pos[qi] = top - (uint32_t)lane + 1u;
       // The power of two below |p.z| at the block centre (L.e2.x): 1 / p.z times it stays within [1/3, 4] over the block as
       // long as p.z = e2.x + e0.z qx + e1.y qy (|qx|, |qy| <= 3.5) stays within half of its centre value.  Where it does not - a
       // large surfel whose horizon passes near the block - the centre says nothing about the pixels that count, and the
       // scale is taken from the hit's largest |1 / p.z| over its valid pixels when the hit is replayed (Sh = 0 asks for it).
-      const float pzc = fabsf(L.e2.x);
 #ifndef SCORP_2D_STEADY_FRAC
 #define SCORP_2D_STEADY_FRAC 0.5f
 #endif
-      const bool steady = 3.5f * (fabsf(L.e0.z) + fabsf(L.e1.y)) <= SCORP_2D_STEADY_FRAC * pzc;
-      const uint32_t eb = min(max(__float_as_uint(pzc) & 0x7F800000u, 0x10000000u), 0x6F000000u);
-      q6[qi] = steady ? make_float2(__uint_as_float(eb), __uint_as_float(0x7F000000u - eb)) : make_float2(0.0f, 0.0f);
+      if constexpr (!kExact) {
+        const float pzc = fabsf(L.e2.x);
+        const bool steady = 3.5f * (fabsf(L.e0.z) + fabsf(L.e1.y)) <= SCORP_2D_STEADY_FRAC * pzc;
+        const uint32_t eb = min(max(__float_as_uint(pzc) & 0x7F800000u, 0x10000000u), 0x6F000000u);
+        q6[qi] = steady ? make_float2(__uint_as_float(eb), __uint_as_float(0x7F000000u - eb)) : make_float2(0.0f, 0.0f);
+      }
     }
     const int cnt = (int)min(todo - done_n, (uint32_t)k2BChunk);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -818,8 +889,8 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         dL_dal -= T_final * rinv * bg_dot;
         t = -h.Go * dL_dal;          // dL/dG * (-G), G = Go / opacity
       }
-      float inv_sg;
-      {   // the hit's power-of-two scale (see above); a hit whose roots are all zero or denormal keeps 1
+      float inv_sg = 1.0f;
+      if constexpr (!kExact) {   // the hit's power-of-two scale (see above); a hit whose roots are all zero or denormal keeps 1
         const uint32_t eb = wave_max_u32(__float_as_uint(fmaxf(fmaxf(fabsf(t), fabsf(dL_dz)), w))) >> 23;
         const uint32_t sb = eb == 0u ? 127u : min(258u - eb, 250u);   // 2^(4 - (eb - 127)), biased
         const float sg = __uint_as_float(sb << 23);
@@ -831,8 +902,9 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       {
         const bool u3 = valid & h.use3d;
         const float s0 = u3 ? h.s0 : 0.0f, s1 = u3 ? h.s1 : 0.0f, dep = u3 ? h.depth : 0.0f;
-        float Sh = q6[s].x;                                                 // (wave-uniform: one LDS broadcast)
-        if (Sh == 0.0f) {   // no steady scale for this hit (see the staging): 2^-e of its largest |1 / p.z| over the valid 3-D pixels
+        float Sh = 1.0f;
+        if constexpr (!kExact) Sh = q6[s].x;                                // (wave-uniform: one LDS broadcast)
+        if (!kExact && Sh == 0.0f) {   // no steady scale for this hit (see the staging): 2^-e of its largest |1 / p.z| over the valid 3-D pixels
           const uint32_t em = min(max(wave_max_u32(u3 ? (__float_as_uint(h.rz) & 0x7F800000u) : 0u), 0x10000000u), 0x6F000000u);
           Sh = __uint_as_float(0x7F000000u - em);
           if (lane == 0) q6[s_] = make_float2(Sh, __uint_as_float(em));       // the read-out unscales with it
@@ -844,10 +916,11 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         const float zr = dL_dz * rzs;                                       // depth = D / pz
         const float dp2 = -(dp0 * s0 + dp1 * s1) - zr * dep;
         uint32_t *rowp = xm2 + (8 * pend) * k2XStride + lane;
-        rowp[0] = split_one(dp0); rowp[k2XStride] = split_one(dp1);
-        rowp[2 * k2XStride] = split_one(dp2); rowp[3 * k2XStride] = split_one(zr);
-        rowp[4 * k2XStride] = split_one(z2); rowp[5 * k2XStride] = split_one(t2);
-        rowp[6 * k2XStride] = split_one(t); rowp[7 * k2XStride] = split_one(w * k2WScale);
+        auto term = [](float x) { return kExact ? __float_as_uint(x) : split_one(x); };
+        rowp[0] = term(dp0); rowp[k2XStride] = term(dp1);
+        rowp[2 * k2XStride] = term(dp2); rowp[3 * k2XStride] = term(zr);
+        rowp[4 * k2XStride] = term(z2); rowp[5 * k2XStride] = term(t2);
+        rowp[6 * k2XStride] = term(t); rowp[7 * k2XStride] = term(w * kWCarry);
       }
       if (pend == 0) { pend_s0 = s_; pend_iw0 = inv_sg; } else { pend_s1 = s_; pend_iw1 = inv_sg; }
       pend++;
@@ -1086,6 +1159,32 @@ preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const Bi
   preprocess2d_backward_body<DEG, SPLIT, false>(a, s_sh, rec, bin, acc, g);
 }
 
+// Deterministic mode: the rows of one surfel are contiguous - partial[4 * pair_base[i] ... 4 * pair_base[i + 1]) - so the
+// ordered per-surfel sum is a streaming read (gs3d_backward.hip has the 3-D twin).  Thirty-two lanes per surfel (lane = float
+// of a row, twenty used) add the flagged rows in the fixed order pair, block - sixteen rows in flight per step.
+__global__ void __launch_bounds__(256)
+reduce_pair_rows2d_kernel(int N, const uint32_t *__restrict__ pair_base, uint32_t capacity, const uint8_t *__restrict__ row_flags,
+                          const float *__restrict__ partial, float *__restrict__ acc) {
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5), col = threadIdx.x & 31;
+  if (i >= N || col >= kAcc2Stride) return;
+  const uint32_t r0 = min(pair_base[i], capacity) * 4u, r1 = min(pair_base[i + 1], capacity) * 4u;
+  float sum = 0.0f;
+  for (uint32_t r = r0; r < r1; r += 16) {
+    uint32_t f[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) f[p] = r + 4 * p < r1 ? *reinterpret_cast<const uint32_t *>(row_flags + r + 4 * p) : 0u;
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const bool on = (f[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+      v[k] = on ? partial[(size_t)(r + k) * kAcc2Stride + col] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) sum += v[k];   // (an absent row adds an exact zero)
+  }
+  acc[(size_t)i * kAcc2Stride + col] = sum;
+}
+
 Pg2Args make_args2(const ScorpGs3dInputs *in, const StateLayout &L) {
   Pg2Args a;
   a.N = in->num_gaussians; a.K = in->sh_coeffs; a.W = in->image_width; a.H = in->image_height;
@@ -1124,6 +1223,11 @@ using namespace scorp;
 extern "C" size_t scorp_gs2d_state_bytes(int32_t N, int32_t W, int32_t H) { return StateLayout(N, W, H, true).total; }
 extern "C" size_t scorp_gs2d_backward_scratch_bytes(int32_t N) {
   return align_up((size_t)(N > 0 ? N : 1) * kAcc2Stride * sizeof(float), 256);
+}
+extern "C" size_t scorp_gs2d_backward_scratch_bytes_ex(int32_t N, int32_t W, int32_t H, uint64_t capacity, uint32_t flags) {
+  (void)W; (void)H;
+  if (flags & SCORP_BACKWARD_DETERMINISTIC) return DetLayout(N, capacity, kAcc2Stride).total;
+  return scorp_gs2d_backward_scratch_bytes(N);
 }
 
 extern "C" int scorp_gs2d_preprocess(const ScorpGs3dInputs *in, int32_t *out_radii, void *state, size_t state_bytes,
@@ -1190,28 +1294,62 @@ extern "C" int scorp_gs2d_render_image(const ScorpGs3dInputs *in, void *state, v
 extern "C" int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
                                    const float *dL_dcolor, const float *dL_dallmap, const ScorpGs3dGrads *grads,
                                    void *scratch, size_t scratch_bytes, scorp_stream_t stream_) {
+  return scorp_gs2d_backward_ex(in, state, pairs, capacity, dL_dcolor, dL_dallmap, grads, scratch, scratch_bytes, 0u, stream_);
+}
+
+extern "C" int scorp_gs2d_backward_ex(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
+                                      const float *dL_dcolor, const float *dL_dallmap, const ScorpGs3dGrads *grads,
+                                      void *scratch, size_t scratch_bytes, uint32_t flags, scorp_stream_t stream_) {
   if (!in || !state || !pairs || !grads || !scratch || !dL_dcolor) { set_error("NULL argument to scorp_gs2d_backward"); return SCORP_ERR_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
   if (N <= 0) return SCORP_OK;
   const StateLayout L(N, W, H, true);
   const PairLayout P(capacity);
-  if (scratch_bytes < scorp_gs2d_backward_scratch_bytes(N) || ((uintptr_t)scratch & 15)) { set_error("2D backward scratch too small or misaligned"); return SCORP_ERR_INVALID; }
+  const bool det = (flags & SCORP_BACKWARD_DETERMINISTIC) != 0, exact = (flags & SCORP_BACKWARD_EXACT_FP32) != 0;
+  const size_t need = scorp_gs2d_backward_scratch_bytes_ex(N, W, H, capacity, flags);
+  if (scratch_bytes < need || ((uintptr_t)scratch & 15)) {
+    set_error("2D backward scratch too small or misaligned (%zu < %zu)", scratch_bytes, need);
+    return SCORP_ERR_INVALID;
+  }
+  if (det && capacity * 4 > 0xFFFFFFFFull) { set_error("capacity too large for the deterministic backward"); return SCORP_ERR_INVALID; }
   const char *base = (const char *)state, *pb = (const char *)pairs;
   float *acc = (float *)scratch;
-  SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAcc2Stride * sizeof(float), stream));
+  float *partial = nullptr;
+  uint8_t *row_flags = nullptr;
+  uint32_t *pair_base = nullptr;
+  const BinRec *bin_arr = (const BinRec *)(base + L.bin);
+  const uint64_t *mask_arr = (const uint64_t *)(base + L.tile_mask);
+  if (det) {
+    const DetLayout DL(N, capacity, kAcc2Stride);
+    char *p = (char *)scratch;
+    partial = (float *)(p + DL.partial);
+    row_flags = (uint8_t *)(p + DL.flags);
+    pair_base = (uint32_t *)(p + DL.pair_base);
+    SCORP_HIP_CHECK(hipMemsetAsync(row_flags, 0, (size_t)(capacity > 0 ? capacity : 1) * 4, stream));
+    launch_pair_base(N, bin_arr, mask_arr, (uint32_t *)(p + DL.block_sums), pair_base, stream);
+    SCORP_KERNEL_CHECK("pair_base", in->debug, stream);
+  } else {
+    SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAcc2Stride * sizeof(float), stream));
+  }
   {
     ProfScope prof(kKBlendBackward2d, stream);
-#define SCORP_BW2(HASMAP)                                                                                         \
-  blend2d_backward_wave_kernel<HASMAP><<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(                                \
-      (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),    \
-      (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),                     \
-      (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc, (const uint32_t *)(pb + P.hits))
-    if (dL_dallmap) SCORP_BW2(true);
-    else SCORP_BW2(false);
-#undef SCORP_BW2
+    const bool map = dL_dallmap != nullptr;
+    auto wk = det ? (exact ? (map ? blend2d_backward_wave_kernel<true, true, true> : blend2d_backward_wave_kernel<false, true, true>)
+                           : (map ? blend2d_backward_wave_kernel<true, false, true> : blend2d_backward_wave_kernel<false, false, true>))
+                  : (exact ? (map ? blend2d_backward_wave_kernel<true, true, false> : blend2d_backward_wave_kernel<false, true, false>)
+                           : (map ? blend2d_backward_wave_kernel<true, false, false> : blend2d_backward_wave_kernel<false, false, false>));
+    wk<<<(L.tiles + 7) / 8 * 32, 64, 0, stream>>>(
+        (const uint32_t *)(base + L.tile_start), (const uint32_t *)(pb + P.list), (const Surfel *)(base + L.rec),
+        (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg, (const float *)(base + L.final_T),
+        (const uint32_t *)(base + L.n_contrib), dL_dcolor, dL_dallmap, acc, (const uint32_t *)(pb + P.hits), partial, row_flags,
+        pair_base, bin_arr, mask_arr);
   }
   SCORP_KERNEL_CHECK("blend_backward_2d", in->debug, stream);
+  if (det) {
+    reduce_pair_rows2d_kernel<<<(N + 7) / 8, 256, 0, stream>>>(N, pair_base, (uint32_t)capacity, row_flags, partial, acc);
+    SCORP_KERNEL_CHECK("reduce_pair_rows_2d", in->debug, stream);
+  }
   {
     ProfScope prof(kKPreprocessBackward2d, stream);
     const Pg2Args a = make_args2(in, L);

@@ -533,7 +533,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
 //   reduce_pair_rows_kernel              : sixteen lanes per Gaussian (lane = float of a row) add the flagged rows in the
 //                                          fixed order tiles of the mask x blocks 0..3
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kScanBlock = 1024;   // Gaussians per workgroup of the pair-count scan
+constexpr int kScanBlock = kPairScanBlock;   // Gaussians per workgroup of the pair-count scan
 __device__ __forceinline__ uint32_t pairs_of(const BinRec &br, uint64_t mask) {
   if ((br.radius & kRadiusMask) == 0) return 0u;
   return mask == kMaskAll ? (uint32_t)((br.x1 - br.x0) * (br.y1 - br.y0)) : (uint32_t)__builtin_popcountll(mask);
@@ -619,28 +619,22 @@ reduce_pair_rows_kernel(int N, const uint32_t *__restrict__ pair_base, uint32_t 
 }  // namespace
 }  // namespace scorp
 
-using namespace scorp;
+// pair_base[i] = the number of (Gaussian, tile) pairs of the Gaussians before i (pair_base[N] = all of them), from the tile
+// rectangles / masks the binning used; shared by the 3-D and the 2-D deterministic backward (the 2-D state holds the same
+// BinRec / tile-mask arrays)
+int scorp::launch_pair_base(int N, const BinRec *bin, const uint64_t *tile_mask, uint32_t *block_sums, uint32_t *pair_base,
+                            hipStream_t stream) {
+  const int blocks = (N + kScanBlock - 1) / kScanBlock;
+  pair_count_kernel<<<blocks, 256, 0, stream>>>(N, bin, tile_mask, block_sums);
+  pair_base_kernel<<<blocks, 256, 0, stream>>>(N, bin, tile_mask, block_sums, pair_base);
+  return SCORP_OK;
+}
 
-// deterministic scratch: [accumulator rows][pair_base N + 1][block sums of the scan][one flag byte per row][4 x capacity rows]
-struct DetLayout {
-  size_t acc, pair_base, block_sums, flags, partial, total;
-  int scan_blocks;
-  DetLayout(int N, uint64_t capacity) {
-    const size_t n = N > 0 ? (size_t)N : 1, c = capacity > 0 ? (size_t)capacity : 1;
-    scan_blocks = (int)((n + kScanBlock - 1) / kScanBlock);
-    size_t off = 0;
-    acc = off; off = align_up(off + n * kAccStride * sizeof(float), 256);
-    pair_base = off; off = align_up(off + (n + 1) * sizeof(uint32_t), 256);
-    block_sums = off; off = align_up(off + (size_t)scan_blocks * sizeof(uint32_t), 256);
-    flags = off; off = align_up(off + c * 4, 256);
-    partial = off; off = align_up(off + c * 4 * kAccStride * sizeof(float), 256);
-    total = off;
-  }
-};
+using namespace scorp;
 
 extern "C" size_t scorp_gs3d_backward_scratch_bytes_ex(int32_t N, int32_t W, int32_t H, uint64_t capacity, uint32_t flags) {
   (void)W; (void)H;
-  if (flags & SCORP_BACKWARD_DETERMINISTIC) return DetLayout(N, capacity).total;
+  if (flags & SCORP_BACKWARD_DETERMINISTIC) return DetLayout(N, capacity, kAccStride).total;
   return align_up((size_t)(N > 0 ? N : 1) * kAccStride * sizeof(float), 256);
 }
 
@@ -684,7 +678,7 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
   float *partial = nullptr;
   uint8_t *row_flags = nullptr;
   uint32_t *pair_base = nullptr;
-  const DetLayout DL(N, capacity);
+  const DetLayout DL(N, capacity, kAccStride);
   if (det) {
     char *p = (char *)scratch;
     partial = (float *)(p + DL.partial);
@@ -692,8 +686,7 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
     pair_base = (uint32_t *)(p + DL.pair_base);
     uint32_t *block_sums = (uint32_t *)(p + DL.block_sums);
     SCORP_HIP_CHECK(hipMemsetAsync(row_flags, 0, (size_t)(capacity > 0 ? capacity : 1) * 4, stream));
-    pair_count_kernel<<<DL.scan_blocks, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), block_sums);
-    pair_base_kernel<<<DL.scan_blocks, 256, 0, stream>>>(N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), block_sums, pair_base);
+    launch_pair_base(N, (const BinRec *)(base + L.bin), (const uint64_t *)(base + L.tile_mask), block_sums, pair_base, stream);
     SCORP_KERNEL_CHECK("pair_base", in->debug, stream);
   } else if (!(flags & SCORP_BACKWARD_SCRATCH_ZEROED)) {
     SCORP_HIP_CHECK(hipMemsetAsync(acc, 0, (size_t)N * kAccStride * sizeof(float), stream));

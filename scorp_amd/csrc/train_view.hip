@@ -66,6 +66,7 @@ extern "C" int scorp_gs2d_train_view(const ScorpGs2dTrainView *v, scorp_stream_t
     if (int e = scorp_gs2d_regularizers_backward(W, H, v->out_allmap, in->viewmatrix, v->rays_d, v->rays_o, v->depth_ratio,
                                                  v->lambda_normal, v->lambda_dist, nullptr, v->grad_allmap, stream)) return e;
   }
-  return scorp_gs2d_backward(in, v->state, v->pairs, v->capacity, v->grad_color, reg ? v->grad_allmap : nullptr, v->grads,
-                             v->backward_scratch, v->backward_scratch_bytes, stream);
+  return scorp_gs2d_backward_ex(in, v->state, v->pairs, v->capacity, v->grad_color, reg ? v->grad_allmap : nullptr, v->grads,
+                                v->backward_scratch, v->backward_scratch_bytes, v->backward_flags & ~SCORP_BACKWARD_SCRATCH_ZEROED,
+                                stream);
 }

@@ -42,6 +42,9 @@ def _forward2d(ctx, settings, means3D, sh, sh_rest, colors_precomp, opacities, s
     if PairPolicy.mode != "exact":
         PairPolicy.pend(state, N, H, W)   # the StateHeader only (see rasterizer3d.PairPolicy.pend)
     ctx.settings, ctx.capacity = settings, capacity
+    # rasterizer3d.backward_precision("exact_fp32" / "deterministic" / ...) and SCORP_BACKWARD_DETERMINISTIC reach the surfel
+    # rasterizer too (scorp_gs2d_backward_ex); the flag is fixed when the forward is issued, as in 3-D
+    ctx.backward_flags = R3._backward_flags() & ~_C.BACKWARD_SCRATCH_ZEROED
     return color, radii, allmap, state, pairs, keep
 
 
@@ -49,10 +52,12 @@ def _backward2d(ctx, args, N, dev, state, pairs, grad_color, grad_allmap, grads)
     L = _C.lib()
     gc = _prep(grad_color, "grad_color")
     ga = _prep(grad_allmap, "grad_allmap") if grad_allmap is not None else None
-    sbytes = L.scorp_gs2d_backward_scratch_bytes(N)
+    s = ctx.settings
+    sbytes = L.scorp_gs2d_backward_scratch_bytes_ex(N, int(s.image_width), int(s.image_height), ctx.capacity, ctx.backward_flags)
     scratch = torch.empty(sbytes, dtype=torch.uint8, device=dev)
-    _C.check(L.scorp_gs2d_backward(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(ga),
-                                   ctypes.byref(grads), _ptr(scratch), sbytes, _stream()), "scorp_gs2d_backward")
+    _C.check(L.scorp_gs2d_backward_ex(ctypes.byref(args), _ptr(state), _ptr(pairs), ctx.capacity, _ptr(gc), _ptr(ga),
+                                      ctypes.byref(grads), _ptr(scratch), sbytes, ctx.backward_flags, _stream()),
+             "scorp_gs2d_backward")
 
 
 class _RasterizeSurfels(torch.autograd.Function):

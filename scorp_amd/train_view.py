@@ -147,7 +147,8 @@ def train_view2d(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.
     ws = new((ws_bytes,), torch.uint8)
     rws_bytes = L.scorp_gs2d_regularizers_workspace_bytes(W, H)
     rws = new((rws_bytes,), torch.uint8)
-    scratch_bytes = L.scorp_gs2d_backward_scratch_bytes(N)
+    flags = _backward_flags() & ~_C.BACKWARD_SCRATCH_ZEROED   # backward_precision(...) reaches the 2DGS one-call view too
+    scratch_bytes = L.scorp_gs2d_backward_scratch_bytes_ex(N, W, H, capacity, flags)
     scratch = new((scratch_bytes,), torch.uint8)
     need = [p.requires_grad for p in leaves]
     need[1] = need[2] = need[1] or need[2]
@@ -169,6 +170,7 @@ def train_view2d(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.
     v.loss_workspace, v.loss_workspace_bytes, v.reg_workspace, v.reg_workspace_bytes = ws.data_ptr(), ws_bytes, rws.data_ptr(), rws_bytes
     v.grad_color, v.grad_allmap, v.grads = grad_color.data_ptr(), grad_allmap.data_ptr(), ctypes.addressof(grads)
     v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes
+    v.backward_flags = flags
     _C.check(L.scorp_gs2d_train_view(ctypes.byref(v), _stream()), "scorp_gs2d_train_view")
     header = PairPolicy.pend(state, N, H, W)
     for p, gp in zip(leaves, g):

@@ -126,9 +126,10 @@ def test_full_size_deterministic_backward(dev):
         PairPolicy.reset()
 
 
+@pytest.mark.parametrize("precision", ["split", "exact_fp32"])
 @pytest.mark.parametrize("cam", _VIEWS)
-def test_full_size_parity_vs_oracle_2d(cam, dev, parallel_oracle):
-    """S6: 1 M surfels at 1600x1200, SH3 - the 2-D oracle's first full-size frame."""
+def test_full_size_parity_vs_oracle_2d(cam, precision, dev, parallel_oracle):
+    """S6: 1 M surfels at 1600x1200, SH3 - the 2-D oracle's first full-size frame.  Both forms of the backward's reduction."""
     from tests.test_gs2d_gpu import _parity_2d
     kw = _scene_kw("S6", cam)
     kw["scale_modifier"] = 1.0
@@ -137,18 +138,19 @@ def test_full_size_parity_vs_oracle_2d(cam, dev, parallel_oracle):
     # is ASSERTED (tests.util.assert_no_further_from_f64) before the tensor is held against the fp32 oracle.
     # tie_outliers: at 1 M surfels a few dozen have a pixel ON the low-pass switch (tests.util.assert_grad_close)
     try:
-        _parity_2d(dict(seed=6), dev, report=report, kw=kw, tie_outliers=_S6_TIE_OUTLIERS, f64_report=f64)
+        _parity_2d(dict(seed=6), dev, report=report, kw=kw, tie_outliers=_S6_TIE_OUTLIERS, f64_report=f64, precision=precision)
     finally:
         from tests.util import BAND_TALLY
-        print("\nS6 full size, relative L1 per gradient tensor:  HIP vs f64 | oracle32 vs f64 | HIP vs oracle32 (max-norm)")
+        print(f"\nS6 full size ({precision}), relative L1 per gradient tensor:  HIP vs f64 | oracle32 vs f64 | HIP vs oracle32 (max-norm)")
         for k, (eh, eo) in f64.items():
             r = report.get(k, (float("nan"), float("nan")))
             print(f"  {k:10s} {eh:.2e} | {eo:.2e} | {r[1]:.2e} ({r[0]:.1e})")
         print("  elements beyond the max-norm tolerance after the band: " + ", ".join(f"{n} {c}" for n, c in BAND_TALLY.get("beyond", [])[-6:]))
 
 
+@pytest.mark.parametrize("precision", ["split", "exact_fp32"])
 @pytest.mark.parametrize("cam", _VIEWS)
-def test_full_size_given_transforms_2d(cam, dev, parallel_oracle):
+def test_full_size_given_transforms_2d(cam, precision, dev, parallel_oracle):
     """S6 (view 0 unless SCORP_FULLSIZE_VIEWS names others) with the surfels' transforms given (transmat_precomp = the fp32 oracle's T): HIP path, fp32 oracle and the
     exact answer (float64 build) start from bit-identical T, so the ill-conditioned intersections stop being a question of
     whose rounding of T one believes.  Asserted per gradient tensor: relL1(HIP, exact) <= max(1e-4, 1.25 x relL1(oracle32, exact))."""
@@ -157,9 +159,9 @@ def test_full_size_given_transforms_2d(cam, dev, parallel_oracle):
     kw["scale_modifier"] = 1.0
     report = {}
     try:
-        given_T_check(kw, 6, dev, report=report)
+        given_T_check(kw, 6, dev, report=report, precision=precision)
     finally:
-        print(f"\nS6 full size, view {cam}, transforms given:  relL1 HIP vs exact | oracle32 vs exact || max-norm HIP vs exact | oracle32 vs exact")
+        print(f"\nS6 full size ({precision}), view {cam}, transforms given:  relL1 HIP vs exact | oracle32 vs exact || max-norm HIP vs exact | oracle32 vs exact")
         for k, (eh, eo, mh, mo) in report.items():
             print(f"  {k:10s} {eh:.2e} | {eo:.2e} || {mh:.2e} | {mo:.2e}")
 

@@ -24,9 +24,17 @@ def dev():
     return torch.device("cuda:0")
 
 
-def hip_render2d(kw, dev, requires_grad=True):
+PRECISIONS = ["split", "exact_fp32"]   # both forms of the backward's pixel -> surfel reduction (scorp_gs2d_backward_ex)
+
+
+def hip_render2d(kw, dev, requires_grad=True, precision=None):
+    """`precision`: rasterizer3d.backward_precision mode recorded with this forward (None: the library's default, the split)."""
     from scorp_amd.refcall import render2d_reference_call
-    return render2d_reference_call(kw, dev, requires_grad=requires_grad)
+    if precision is None:
+        return render2d_reference_call(kw, dev, requires_grad=requires_grad)
+    from scorp_amd.rasterizer3d import backward_precision
+    with backward_precision(precision):
+        return render2d_reference_call(kw, dev, requires_grad=requires_grad)
 
 
 def assert_radii_match(got, ref):
@@ -52,12 +60,13 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", list(CASES))
-def test_forward_backward_parity_2d(name, dev):
-    _parity_2d(CASES[name], dev)
+def test_forward_backward_parity_2d(name, precision, dev):
+    _parity_2d(CASES[name], dev, precision=precision)
 
 
-def _parity_2d(case, dev, report=None, outlier_gaussians=0, kw=None, tie_outliers=0, f64_report=None):
+def _parity_2d(case, dev, report=None, outlier_gaussians=0, kw=None, tie_outliers=0, f64_report=None, precision=None):
     """`case`: arguments of make_case2d - or, with `kw` given (a full-size scene), only its "seed" is used.
     `f64_report` (a dict): every gradient tensor is ALSO held against the float64 build of the oracle
     (tests.util.assert_no_further_from_f64) and (relL1(HIP, f64), relL1(oracle32, f64)) is left there per tensor."""
@@ -66,7 +75,7 @@ def _parity_2d(case, dev, report=None, outlier_gaussians=0, kw=None, tie_outlier
         kw, _ = make_case2d(**case)
     o = OracleRender2D(np.float32, **kw)
     assert o.num_pairs > 0
-    out, t = hip_render2d(kw, dev)
+    out, t = hip_render2d(kw, dev, precision=precision)
     color, radii, allmap = out
     assert_radii_match(radii.cpu().numpy(), o.radii)
     c, am = color.detach().cpu().numpy(), allmap.detach().cpu().numpy()
@@ -136,19 +145,22 @@ FUZZ_2D = fuzz_cases("2d", int(os.environ.get("SCORP_FUZZ_N", "32")), _FUZZ_SEED
 FUZZ_2D_EXCEPTIONS = {}
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("k", range(len(FUZZ_2D)))
-def test_fuzz_parity_2d(k, dev):
+def test_fuzz_parity_2d(k, precision, dev):
     """Randomised surfel cases (seeded), forward + backward against the 2-D oracle, same assertions as above."""
-    _parity_2d(FUZZ_2D[k], dev, outlier_gaussians=FUZZ_2D_EXCEPTIONS.get(k, 0) if _FUZZ_SEED == 20261004 else 0)
+    _parity_2d(FUZZ_2D[k], dev, outlier_gaussians=FUZZ_2D_EXCEPTIONS.get(k, 0) if _FUZZ_SEED == 20261004 else 0,
+               precision=precision)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("seed,k", [(63, 122), (64, 140)])
-def test_faint_hits_keep_their_bits(seed, k, dev):
+def test_faint_hits_keep_their_bits(seed, k, precision, dev):
     """Two fuzz scenes whose means2D gradient is carried by a few low-pass pixels of faint or deeply covered surfels
     (alpha ~ 0.01, T down to 1e-4): the largest row of the tensor was 1e-3 / 1e-2 off while the backward's fp16 pairs rode on
     one power of two per wave, under their absolute floor of 2^-24; with the hit's own power of two (gs2d.hip, `sg`) it is
-    within 1e-5 (scripts/dev/diag2d_rows.py prints the rows)."""
-    _parity_2d(fuzz_cases("2d", 160, seed)[k], dev)
+    within 1e-5 (scripts/dev/diag2d_rows.py prints the rows).  The all-fp32 form has no such floor to begin with."""
+    _parity_2d(fuzz_cases("2d", 160, seed)[k], dev, precision=precision)
 
 
 def _given_T(kw, rows=None):
@@ -186,8 +198,9 @@ def _weights(seed, c, am):
 CONDITIONING_PICKS = [(62, 82, 250), (1, 115, 5145), (64, 159, 418), (63, 68, 66)]
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("pick", CONDITIONING_PICKS, ids=lambda p: "seed%d_case%d_surfel%d" % p)
-def test_fuzz_outliers_are_the_fp32_oracles_rounding_not_the_hip_paths(pick, dev):
+def test_fuzz_outliers_are_the_fp32_oracles_rounding_not_the_hip_paths(pick, precision, dev):
     """Each of those surfels alone, its transform given: against the EXACT answer for the same fp32 T (the float64 build) the
     HIP path's alpha map and gradients are closer than the fp32 oracle's - the reference's own order of operations in fp32
     (k = x Tw - Tu, p = k x l) loses 1e-4 .. 3e-2 there, the block-centred linear form (gs2d.hip, surfel_lin) 1e-6 .. 1e-4."""
@@ -197,7 +210,7 @@ def test_fuzz_outliers_are_the_fp32_oracles_rounding_not_the_hip_paths(pick, dev
     kw, _ = make_case2d(**case)
     given = _given_T(kw, rows=slice(gid, gid + 1))
     o32, o64 = OracleRender2D(np.float32, **given), OracleRender2D(np.float64, **given)
-    (color, radii, allmap), t = hip_render2d(given, dev)
+    (color, radii, allmap), t = hip_render2d(given, dev, precision=precision)
     assert int(radii[0]) == int(o32.radii[0]) > 0
     am = allmap.detach().cpu().numpy()
     e_hip, e_o32 = np.abs(am[1] - o64.allmap[1]).max(), np.abs(o32.allmap[1] - o64.allmap[1]).max()
@@ -213,7 +226,7 @@ def test_fuzz_outliers_are_the_fp32_oracles_rounding_not_the_hip_paths(pick, dev
         assert e_hip <= max(2e-4, e_o32), f"grad {nm}: HIP {e_hip:.3e} from exact, fp32 oracle {e_o32:.3e}"
 
 
-def given_T_check(kw, seed, dev, report=None):
+def given_T_check(kw, seed, dev, report=None, precision=None):
     """The scene with its transforms given: per gradient tensor the HIP path's relative L1 distance to the exact answer (the
     float64 build on the same fp32 T) is at most max(1e-4, 1.25 x the fp32 oracle's own) - tests.util.assert_no_further_from_f64;
     `report[name]` = (relL1(HIP, exact), relL1(oracle32, exact), max-norm(HIP, exact), max-norm(oracle32, exact))."""
@@ -221,7 +234,7 @@ def given_T_check(kw, seed, dev, report=None):
     from tests.util import assert_no_further_from_f64, grad_errors
     given = _given_T(kw)
     o32, o64 = OracleRender2D(np.float32, **given), OracleRender2D(np.float64, **given)
-    (color, radii, allmap), t = hip_render2d(given, dev)
+    (color, radii, allmap), t = hip_render2d(given, dev, precision=precision)
     assert_radii_match(radii.cpu().numpy(), o32.radii)
     c, am = color.detach().cpu().numpy(), allmap.detach().cpu().numpy()
     assert np.abs(c - o64.color).mean() <= max(IMG_L1_TOL, 1.25 * np.abs(o32.color - o64.color).mean())
@@ -237,12 +250,70 @@ def given_T_check(kw, seed, dev, report=None):
             report[nm] = e + (grad_errors(got, g64[nm])[0], grad_errors(g32[nm], g64[nm])[0])
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("k", list(range(8)) + [26])
-def test_given_transforms_hip_is_no_further_from_exact_than_the_fp32_oracle(k, dev):
+def test_given_transforms_hip_is_no_further_from_exact_than_the_fp32_oracle(k, precision, dev):
     """Whole fuzz scenes (2 and 26 are the two of the 32 whose gradients pass against the fp32 oracle only through its
     indecision band) with the transforms given."""
     case = FUZZ_2D[k]
-    given_T_check(make_case2d(**case)[0], case["seed"], dev)
+    given_T_check(make_case2d(**case)[0], case["seed"], dev, precision=precision)
+
+
+def _grads_2d(kw, dev, mode, weights, reps=1):
+    """`reps` backward passes on ONE forward issued under backward_precision(mode); per pass {leaf: gradient}."""
+    (color, _, allmap), t = hip_render2d(kw, dev, precision=mode)
+    loss = (color * weights[0]).sum() + (allmap * weights[1]).sum()
+    res = []
+    for r in range(reps):
+        for v in t.values():
+            if v is not None:
+                v.grad = None
+        loss.backward(retain_graph=r + 1 < reps)
+        res.append({k: v.grad.detach().clone() for k, v in t.items() if v is not None and v.grad is not None})
+    return res
+
+
+@pytest.mark.parametrize("name", ["sh3_bg", "tiny_surfels", "far_depth", "inside_cloud"])
+def test_split_backward_equals_exact_fp32_backward_2d(name, dev):
+    """The default backward (eight values per hit as two fp16 terms under the hit's own power of two, fp16 MFMAs) against
+    the all-fp32 form (fp32 values, fp32 MFMAs, no scales) on the same scene: every gradient tensor within 2e-5 relative L1
+    and 1e-4 of its maximum; upstream gradients scaled by 1e-6 and 1e+4 exercise the split form's per-wave scale."""
+    case = dict(CASES[name])
+    kw, _ = make_case2d(**case)
+    wc, wa = _weights(case["seed"], np.zeros((3, kw["H"], kw["W"])), np.zeros((7, kw["H"], kw["W"])))
+    for scale in (1.0, 1e-6, 1e4):
+        W2 = [torch.tensor(w * np.float32(scale), device=dev) for w in (wc, wa)]
+        (gs,), (ge,) = _grads_2d(kw, dev, "split", W2), _grads_2d(kw, dev, "exact_fp32", W2)
+        for k, ref in ge.items():
+            got, ref = gs[k].double(), ref.double()
+            assert torch.isfinite(got).all()
+            l1 = float((got - ref).abs().sum() / ref.abs().sum().clamp_min(1e-300))
+            mx = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-300))
+            assert l1 < 2e-5 and mx < 1e-4, f"{k} (upstream x{scale:g}): rel L1 {l1:.2e}, max {mx:.2e}"
+
+
+@pytest.mark.parametrize("mode", ["deterministic", "exact_fp32_deterministic"])
+@pytest.mark.parametrize("name", ["sh3_bg", "tiny_surfels", "precomp_color", "inside_cloud"])
+def test_deterministic_backward_2d_is_bit_reproducible_and_equals_the_atomic_form(name, mode, dev):
+    """SCORP_BACKWARD_DETERMINISTIC on the surfel rasterizer (plain per-(block, hit) rows of twenty sums + an ordered
+    per-surfel sum, no float atomics): two backward passes on one forward - what utils/mask.py:52,65,89 does before voting
+    on gradient signs (:124) - give the same bits, and every gradient tensor equals the atomic form's within 2e-5 relative
+    L1.  Both reduction forms."""
+    case = dict(CASES[name])
+    kw, _ = make_case2d(**case)
+    wc, wa = _weights(case["seed"], np.zeros((3, kw["H"], kw["W"])), np.zeros((7, kw["H"], kw["W"])))
+    W2 = [torch.tensor(w, device=dev) for w in (wc, wa)]
+    d1, d2 = _grads_2d(kw, dev, mode, W2, reps=2)
+    for k in d1:
+        assert torch.equal(d1[k], d2[k]), f"{k}: two deterministic backward passes differ"
+    (d3,) = _grads_2d(kw, dev, mode, W2)     # ... and so does a second forward + backward
+    for k in d1:
+        assert torch.equal(d1[k], d3[k]), f"{k}: a second deterministic forward + backward differs"
+    (a1,) = _grads_2d(kw, dev, mode.replace("_deterministic", "").replace("deterministic", "split"), W2)
+    for k, ref in a1.items():
+        got = d1[k].double()
+        l1 = float((got - ref.double()).abs().sum() / ref.double().abs().sum().clamp_min(1e-300))
+        assert l1 < 2e-5, f"{k}: deterministic vs atomic rel L1 {l1:.2e}"
 
 
 def test_edge_on_surfel_sliver_is_not_culled(dev):
