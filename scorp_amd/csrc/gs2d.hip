@@ -562,9 +562,14 @@ __device__ __forceinline__ float half_lo_2d(uint32_t p) { return (float)__builti
 // bits cleared (fp16 carries ten), so the remainder needs no conversion back and ONE v_cvt_pkrtz makes the whole dword:
 // three instructions per value (it was nine per two: two packs, two conversions back, two fma, two v_perm).  Below the
 // fp16 normal range (2^-14; the hit's largest value sits at 2^4 .. 2^14, see `sg`) the pair ends at the same 2^-24.
+// Round 6: TWO instructions - v_cvt_pkrtz writes h1 into the low half, v_fma_mixhi_f16 forms x - h1 in fp32 (exact: the
+// difference is representable) straight from that half and rounds it to fp16 into the high half of the same register.  The
+// remainder is rounded to nearest where it was truncated (either way x = h1 + h2 to 2^-22 relative); a value beyond the fp16
+// range (not reachable: the hit's largest is held below 1.4e4, see `sg`) now ends as inf instead of a silently wrong pair.
 __device__ __forceinline__ uint32_t split_one(float x) {
-  const float h1 = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
-  return pack_rtz16_2d(h1, x - h1);
+  uint32_t d = pack_rtz16_2d(x, 0.0f);
+  asm("v_fma_mixhi_f16 %0, %0, -1.0, %1 op_sel_hi:[1,0,0]" : "+v"(d) : "v"(x));
+  return d;
 }
 // What lane `o` (0..19 of either half of the wave) reads out of the result tile: out = alpha * D[row][c1] + beta * D[row][c2],
 // beta one of {0, 1, ox, oy, kF * offx, kF * offy} by `bsel`; `cls`: which unscaling applies (0: 1 / (sv Sh), 1: 1 / sv, 2: 1 / (sv 2^10))
@@ -588,12 +593,16 @@ __device__ __forceinline__ ReadOut read_out_of(int o) {
 #ifndef SCORP_2D_BCHUNK
 #define SCORP_2D_BCHUNK 32
 #endif
+#ifndef SCORP_2D_MFMA_CHAINS
+#define SCORP_2D_MFMA_CHAINS 1
+#endif
 constexpr int k2BChunk = SCORP_2D_BCHUNK;   // hits staged per chunk: 32 (the staging arrays are 112 bytes per hit; with 64 the wave's 11.5 KB of
                                             // LDS held the kernel at 13 waves per CU where its 124 registers allow 16: 706 -> 665 us)
 
-// 122 registers: four waves per SIMD.  Held to five (96 registers) it spills 26 dwords: 673 -> 740 us (same box).
+// Four waves per SIMD (128 registers; every instantiation fits without scratch when asked to - left at three by the launch
+// bounds the split form allocated 130).  Held to five (96 registers) it spills 26 dwords: 673 -> 740 us (same box, round 4).
 #ifndef SCORP_2D_BWAVES
-#define SCORP_2D_BWAVES 3
+#define SCORP_2D_BWAVES 4
 #endif
 // Three forms, as for the 3-D kernel (scorp_gs2d_backward_ex, include/scorp_gs.h):
 //   * SPLIT (default): the description above.
@@ -615,9 +624,13 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
                              const uint32_t *__restrict__ hits, float *__restrict__ partial, uint8_t *__restrict__ row_flags,
                              const uint32_t *__restrict__ pair_base, const BinRec *__restrict__ bin,
                              const uint64_t *__restrict__ tile_mask) {
-  __shared__ float4 q0[k2BChunk], q1[k2BChunk], q2[k2BChunk], q3[k2BChunk], q4[k2BChunk], q5[k2BChunk];
-  __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];   // q0..q3: SurfelLin, q4: (normal, r), q5: (g, b, ox, oy)
-  __shared__ float2 q6[k2BChunk];                        // (Sh, 1 / Sh): the hit's power-of-two scale for the 1 / p.z values
+  __shared__ float4 q0[k2BChunk], q1[k2BChunk], q2[k2BChunk], q3[k2BChunk], q4[k2BChunk];
+  __shared__ float2 q5[k2BChunk];                        // q0..q3: SurfelLin, q4: (normal, r), q5: (g, b)
+  __shared__ uint32_t q_id[k2BChunk], q_pos[k2BChunk];
+  __shared__ float q6[k2BChunk];                         // Sh: the hit's power-of-two scale for the 1 / p.z values (0: taken at replay)
+  // what the read-out lanes multiply with, one row of eight floats per hit, formed once by the staging lane:
+  // [0, 1, ox, oy, kF (cx - bxc), kF (cy - byc), 1 / Sh, 1] - a lane picks its two entries by index (it was five selects)
+  __shared__ __attribute__((aligned(16))) float q7[k2BChunk * 8];
   // [row = hit of the pair x kind][pixel] matrix of (h1 | h2 << 16) dwords; the 16 x 16 result tile reuses its first rows
   __shared__ __attribute__((aligned(16))) uint32_t xm2[16 * k2XStride];
   float *dbuf = reinterpret_cast<float *>(xm2);
@@ -671,7 +684,10 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
     inv_sv = __uint_as_float((uint32_t)(254 - sb) << 23);
   }
   dpix0 *= sv; dpix1 *= sv; dpix2 *= sv; ddep *= sv; dacc *= sv; dn0 *= sv; dn1 *= sv; dn2 *= sv; dmed *= sv; dreg *= sv;
-  const float bg_dot = bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2;   // (of the SCALED gradients, like everything below)
+  // (of the SCALED gradients, like everything below); per-pixel constants of the recurrence formed once: T_final bg . dL/dc,
+  // and the distortion term's final_A, final_D, final_D2 with the map's upstream gradient folded in
+  const float tf_bg = T_final * (bg[0] * dpix0 + bg[1] * dpix1 + bg[2] * dpix2);
+  const float far_ = final_A * dreg, fdr_ = final_D * dreg, fd2r_ = final_D2 * dreg;
   // B operand.  A lane supplies ONE column bn of the basis for the pixels 16 m + 4 bk + j (MFMA m, j = 0..3), each value twice
   // (once per fp16 term of the A side).  The six gradient columns come from the other lanes through LDS (the matrix is idle).
   Frag2 bh[kExact ? 1 : 4];
@@ -709,12 +725,14 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
     __builtin_amdgcn_wave_barrier();
   }
   const ReadOut ro = read_out_of(lane & 31);
+  const int ro_beta = ro.bsel, ro_us = kExact ? 7 : (ro.cls == 0 ? 6 : 7);   // this lane's entries of a hit's q7 row
   constexpr float kWCarry = kExact ? 1.0f : k2WScale;   // the blend weight travels as w * 2^10 in the split form only
   const float ro_unscale = ro.cls == 2 ? inv_sv * (1.0f / kWCarry) : inv_sv;
   const int abase = (lane & 15) * k2XStride + 4 * (lane >> 4);
   // Two hits per pass over the matrix pipe: `pend` halves of the matrix are filled (slots pend_s[0], pend_s[1] of the chunk)
   int pend = 0, pend_s0 = 0, pend_s1 = 0;
   float pend_iw0 = 1.0f, pend_iw1 = 1.0f;   // 1 / (the hit's block-floating-point scale, see `sg` below)
+  uint64_t pend_live = 0;                   // exact form: the pixels either hit of the pair is live on (wave-uniform)
   auto flush_pair = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -723,19 +741,36 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       float4 av[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) av[m] = *reinterpret_cast<const float4 *>(&xm2[abase + 16 * m]);
+      // MFMAs 4 m .. 4 m + 3 cover the pixels 16 m .. 16 m + 15 (two rows of the block).  A surfel's footprint is a few pixels
+      // across: where neither hit of the pair is live on those two rows every A value is an exact zero and the four fp32
+      // MFMAs (34 cycles each at the vector rate) are skipped - a wave-uniform branch on the pair's live-pixel mask.
+#ifndef SCORP_2D_EXACT_NOSKIP
+#define SCORP_2D_EXACT_NOSKIP 0
+#endif
 #pragma unroll
       for (int m = 0; m < 4; m++) {
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].x, bb[4 * m], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].y, bb[4 * m + 1], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].z, bb[4 * m + 2], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].w, bb[4 * m + 3], d, 0, 0, 0);
+        if (SCORP_2D_EXACT_NOSKIP || ((pend_live >> (16 * m)) & 0xFFFFull) != 0) {
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].x, bb[4 * m], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].y, bb[4 * m + 1], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].z, bb[4 * m + 2], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].w, bb[4 * m + 3], d, 0, 0, 0);
+        }
       }
     } else {
       Frag2 af[4];
 #pragma unroll
       for (int m = 0; m < 4; m++) af[m].q = *reinterpret_cast<const uint4 *>(&xm2[abase + 16 * m]);
+#if SCORP_2D_MFMA_CHAINS == 2   // two independent accumulation chains of two MFMAs each (latency) + four adds
+      f32x4_2d d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0].v, bh[0].v, d, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1].v, bh[1].v, d1, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2].v, bh[2].v, d, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[3].v, bh[3].v, d1, 0, 0, 0);
+      d += d1;
+#else
 #pragma unroll
       for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m].v, bh[m].v, d, 0, 0, 0);
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();   // every lane has its A operands: the result tile may overwrite the matrix
@@ -746,18 +781,10 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
     const int hh = lane >> 5;
     if ((lane & 31) < kAcc2Stride && hh < pend) {   // lanes 0..19: the first hit of the pair, 32..51: the second
       const int sl = hh ? pend_s1 : pend_s0;
-      const float4 gb = q5[sl];
-      const float4 a2 = q2[sl];
-      float2 sh = make_float2(1.0f, 1.0f);
-      if constexpr (!kExact) sh = q6[sl];
-      float beta = ro.bsel == 1 ? 1.0f : 0.0f;
-      beta = ro.bsel == 2 ? gb.z : beta;
-      beta = ro.bsel == 3 ? gb.w : beta;
-      beta = ro.bsel == 4 ? kFilterInvSq * (a2.z - bxc) : beta;
-      beta = ro.bsel == 5 ? kFilterInvSq * (a2.w - byc) : beta;
+      const float beta = q7[sl * 8 + ro_beta];
       const float *row = dbuf + (ro.row + 8 * hh) * k2DStride;
       float v = ro.alpha * row[ro.c1] + beta * row[ro.c2];
-      if constexpr (!kExact) v = v * (ro.cls == 0 ? ro_unscale * sh.y : ro_unscale) * (hh ? pend_iw1 : pend_iw0);
+      if constexpr (!kExact) v = v * (ro_unscale * q7[sl * 8 + ro_us]) * (hh ? pend_iw1 : pend_iw0);
       if constexpr (kDet) {   // (q_id holds the pair's ordinal; one beyond the reservation: an overflowed view, discarded anyway)
         const uint32_t pair = q_id[sl];
         if (pair < capacity) {
@@ -815,7 +842,8 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       const SurfelLin L = surfel_lin(r0, r1, r2, bxc, byc);
       q0[qi] = L.e0; q1[qi] = L.e1; q2[qi] = L.e2; q3[qi] = L.e3; q4[qi] = r3;
       // (ox, oy) = block centre - the surfel's accumulation point (its centre clamped into the image)
-      q5[qi] = make_float4(r4.x, r4.y, bxc - fminf(fmaxf(r2.y, 0.0f), (float)(W - 1)), byc - fminf(fmaxf(r2.z, 0.0f), (float)(H - 1)));
+      q5[qi] = make_float2(r4.x, r4.y);
+      float sh_stage = 1.0f, ish_stage = 1.0f;
       if constexpr (kDet) {
         // the (surfel, tile) pair's ordinal, surfel-major: pair_base[id] + the rank of this tile among the tiles the surfel
         // reaches (for_each_tile's order: the set bits of its mask, or its whole rectangle row by row)
@@ -841,8 +869,13 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         const float pzc = fabsf(L.e2.x);
         const bool steady = 3.5f * (fabsf(L.e0.z) + fabsf(L.e1.y)) <= SCORP_2D_STEADY_FRAC * pzc;
         const uint32_t eb = min(max(__float_as_uint(pzc) & 0x7F800000u, 0x10000000u), 0x6F000000u);
-        q6[qi] = steady ? make_float2(__uint_as_float(eb), __uint_as_float(0x7F000000u - eb)) : make_float2(0.0f, 0.0f);
+        sh_stage = steady ? __uint_as_float(eb) : 0.0f;
+        ish_stage = __uint_as_float(0x7F000000u - eb);
+        q6[qi] = sh_stage;
       }
+      float4 *tb = reinterpret_cast<float4 *>(q7 + 8 * qi);
+      tb[0] = make_float4(0.0f, 1.0f, bxc - fminf(fmaxf(r2.y, 0.0f), (float)(W - 1)), byc - fminf(fmaxf(r2.z, 0.0f), (float)(H - 1)));
+      tb[1] = make_float4(kFilterInvSq * (L.e2.z - bxc), kFilterInvSq * (L.e2.w - byc), ish_stage, 1.0f);
     }
     const int cnt = (int)min(todo - done_n, (uint32_t)k2BChunk);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -854,14 +887,15 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
       const float4 a0 = q0[s], a1 = q1[s], a2 = q2[s], a3 = q3[s];
       Eval2 h;
       const bool valid = eval_surfel(a0, a1, a2, a3, qxb, qyb, pxf, pyf, h) & (pos1 <= last);
-      if (__ballot(valid) == 0) continue;
+      const uint64_t live = __ballot(valid);
+      if (live == 0) continue;
       // The per-pixel recurrence runs under `valid`; it leaves three scalars (blend weight w, t = dL/dG * (-G), dL/dz)
       // that are zero on the other lanes, and the twenty sums are formed from them outside the branch with the
       // geometry zeroed where it is not used (pz ~ 0 makes s, rz, depth non-finite there), so no lane ever needs
       // its twenty accumulators cleared first.
       float w = 0.0f, t = 0.0f, dL_dz = 0.0f;
       const float4 nr = q4[s];
-      const float4 gb = q5[s];
+      const float2 gb = q5[s];
       if (valid) {
         const float rinv = __builtin_amdgcn_rcpf(1.0f - h.alpha);
         T *= rinv;
@@ -874,19 +908,21 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         float dL_dal = sc - R;
         s_last = sc;
         if (kHasMap) {
+          // distortion: dL/dweight = dreg (D2 + m^2 A - 2 m D) = fd2r + m (u - fdr), u = m far - fdr (also the depth term's factor)
           const float rd = h.rdepth;
-          const float m_d = fn * (1.0f - kNearZ * rd);
-          const float dmd_dd = (kFarZ * kNearZ / (kFarZ - kNearZ)) * rd * rd;
+          const float m_d = __builtin_fmaf(-fn * kNearZ, rd, fn);
+          const float dmd_dd = ((kFarZ * kNearZ / (kFarZ - kNearZ)) * rd) * rd;
+          const float u = __builtin_fmaf(m_d, far_, -fdr_);
+          const float dL_dweight = __builtin_fmaf(m_d, u - fdr_, fd2r_);
           dL_dz = (pos1 == med_c) ? dmed : 0.0f;
-          const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.0f * m_d * final_D) * dreg;
           dL_dal += dL_dweight - last_dL_dT;
           last_dL_dT = dL_dweight * h.alpha + (1.0f - h.alpha) * last_dL_dT;
-          dL_dz += 2.0f * w * (m_d * final_A - final_D) * dreg * dmd_dd;
-          dL_dz += w * ddep;
+          dL_dz = __builtin_fmaf(w + w, u * dmd_dd, dL_dz);
+          dL_dz = __builtin_fmaf(w, ddep, dL_dz);
         }
         dL_dal *= T;
         last_alpha = h.alpha;
-        dL_dal -= T_final * rinv * bg_dot;
+        dL_dal = __builtin_fmaf(-tf_bg, rinv, dL_dal);
         t = -h.Go * dL_dal;          // dL/dG * (-G), G = Go / opacity
       }
       float inv_sg = 1.0f;
@@ -903,11 +939,11 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         const bool u3 = valid & h.use3d;
         const float s0 = u3 ? h.s0 : 0.0f, s1 = u3 ? h.s1 : 0.0f, dep = u3 ? h.depth : 0.0f;
         float Sh = 1.0f;
-        if constexpr (!kExact) Sh = q6[s].x;                                // (wave-uniform: one LDS broadcast)
+        if constexpr (!kExact) Sh = q6[s];                                  // (wave-uniform: one LDS broadcast)
         if (!kExact && Sh == 0.0f) {   // no steady scale for this hit (see the staging): 2^-e of its largest |1 / p.z| over the valid 3-D pixels
           const uint32_t em = min(max(wave_max_u32(u3 ? (__float_as_uint(h.rz) & 0x7F800000u) : 0u), 0x10000000u), 0x6F000000u);
           Sh = __uint_as_float(0x7F000000u - em);
-          if (lane == 0) q6[s_] = make_float2(Sh, __uint_as_float(em));       // the read-out unscales with it
+          if (lane == 0) q7[8 * s_ + 6] = __uint_as_float(em);                // the read-out unscales with it
         }
         const float rzs = u3 ? h.rz * Sh : 0.0f;                            // 1 / p.z times the hit's power-of-two scale
         const float t2 = h.use3d ? 0.0f : t, z2 = h.use3d ? 0.0f : dL_dz;   // low-pass branch (t, dL_dz are 0 if !valid)
@@ -922,7 +958,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
         rowp[4 * k2XStride] = term(z2); rowp[5 * k2XStride] = term(t2);
         rowp[6 * k2XStride] = term(t); rowp[7 * k2XStride] = term(w * kWCarry);
       }
-      if (pend == 0) { pend_s0 = s_; pend_iw0 = inv_sg; } else { pend_s1 = s_; pend_iw1 = inv_sg; }
+      if (pend == 0) { pend_s0 = s_; pend_iw0 = inv_sg; pend_live = live; } else { pend_s1 = s_; pend_iw1 = inv_sg; pend_live |= live; }
       pend++;
       if (pend == 2) flush_pair();
     }

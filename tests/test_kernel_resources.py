@@ -19,11 +19,7 @@ from scorp_amd.build import ARCH, CSRC, HIPCC, ROOT
 BUDGETS = {
     "gs3d_forward.hip": {"blend_forward_wave_kernelILb1E": (80, 16, 160 * 1024 // 24, 6), "blend_forward_wave_kernelILb0E": (80, 16, 160 * 1024 // 24, 6)},
     "gs3d_backward.hip": {"blend_backward_wave_kernel": (128, 32, 160 * 1024 // 16, 4)},
-    "gs2d.hip": {"blend2d_forward_wave_kernel": (96, 16, 160 * 1024 // 20, 5), "blend2d_backward_wave_kernel": (128, 0, 160 * 1024 // 16, 4),
-                 # the deterministic instantiations (three gathers per staged hit: 129 - 130 registers in the split form) run three
-                 # waves per SIMD; they are not the training path
-                 "blend2d_backward_wave_kernelILb1ELb0ELb1E": (136, 0, 160 * 1024 // 12, 3),
-                 "blend2d_backward_wave_kernelILb0ELb0ELb1E": (136, 0, 160 * 1024 // 12, 3)},
+    "gs2d.hip": {"blend2d_forward_wave_kernel": (96, 16, 160 * 1024 // 20, 5), "blend2d_backward_wave_kernel": (128, 0, 160 * 1024 // 16, 4)},
     # (256-thread workgroups: the LDS figure is per workgroup; the unmasked backward is the one every training view runs)
     "loss.hip": {"ssim_l1_forward_strip_kernel": (128, 0, 5120, 4), "ssim_l1_backward_kernelILb0E": (80, 0, 13312, 6)},
 }
