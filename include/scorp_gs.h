@@ -304,6 +304,30 @@ int scorp_loss_l1_ssim_backward(const float *img, const float *gt, const float *
  * scorp_gs3d_check_overflow afterwards, as for scorp_gs3d_render without scorp_gs3d_num_pairs).
  * out_depth_raw is the rasterizer's un-normalised depth, out_depth = nan_to_num(depth / alpha) as render() returns
  * it; out_depth / out_visible may both be NULL (the tail is skipped then). */
+/* Optional optimizer step INSIDE the view (train_3dgs.py:180-193 for the iterations that neither densify nor reset): the
+ * per-Gaussian backward kernel holds every Gaussian's whole gradient row in registers / LDS and applies
+ * torch.optim.Adam's update there - the arithmetic of scorp_adam_step_guarded, bit for bit - together with the view's share of
+ * the densification statistics (scorp_densification_stats' arithmetic).  The 248-byte gradient row never travels to HBM
+ * and back and the parameters are not read a second time: 932 instead of 1652 bytes of optimizer traffic per Gaussian.
+ * Needs the raw-leaf convention (shs = _features_dc, shs_rest = _features_rest, raw_params = 7, scales + rotations): the
+ * arrays of `in` ARE the optimizer's parameters and are updated in place by the view's last kernel.  Leaves in the order
+ * xyz, features_dc, features_rest, opacity, scaling, rotation; exp_avg[k] == NULL: that leaf is frozen.  Nothing is updated
+ * (and *skipped_counter is incremented, if given) when the view overflowed its pair reservation (the overflow word of
+ * out_header, or of the state header) - the guard of scorp_adam_step_guarded, without the host in the loop. */
+typedef struct ScorpFusedAdam {
+  float *exp_avg[6];
+  float *exp_avg_sq[6];
+  float lr[6];
+  float _pad[2];
+  double beta1, beta2, eps;
+  int32_t step;                  /* 1-based step count of this update (bias corrections) */
+  int32_t _pad2;
+  uint32_t *skipped_counter;     /* device word or NULL */
+  float *max_radii2D;            /* [N] statistics, all three or none: updated for the visible Gaussians */
+  float *xyz_gradient_accum;     /* [N] += |(dL/dmeans2D.x, dL/dmeans2D.y)| */
+  float *denom;                  /* [N] += 1 */
+} ScorpFusedAdam;
+
 typedef struct ScorpGs3dTrainView {
   const ScorpGs3dInputs *in;
   int32_t *out_radii;            /* [N] */
@@ -329,6 +353,7 @@ typedef struct ScorpGs3dTrainView {
   size_t backward_scratch_bytes;
   uint32_t *out_header;          /* optional, 4 device words {pairs needed, overflow, capacity, 0}: the view's overflow word
                                     survives the state blob without a copy launch (the scatter kernel writes it) */
+  const ScorpFusedAdam *adam;    /* optional: the optimizer step and the statistics inside the view (see ScorpFusedAdam) */
 } ScorpGs3dTrainView;
 int scorp_gs3d_train_view(const ScorpGs3dTrainView *view, scorp_stream_t stream);
 
@@ -404,6 +429,12 @@ int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t num_tensors, double 
  * cannot move the parameters or the Adam moments - without a host round trip per iteration. */
 int scorp_adam_step_guarded(const ScorpAdamTensor *tensors, int32_t num_tensors, double beta1, double beta2, double eps,
                             int32_t step, const uint32_t *skip_if_nonzero, scorp_stream_t stream);
+
+/* The same; when the step is skipped, *skipped_counter (device word, NULL = not counted) is incremented by one - a training loop
+ * reads it at its next synchronisation point and takes the skipped steps out of its bias-correction counter.  Replicas of a
+ * data-parallel run skip on the all-reduced overflow word, so their counters agree (FusedAdam.take_skipped). */
+int scorp_adam_step_guarded_ex(const ScorpAdamTensor *tensors, int32_t num_tensors, double beta1, double beta2, double eps,
+                               int32_t step, const uint32_t *skip_if_nonzero, uint32_t *skipped_counter, scorp_stream_t stream);
 
 /* ---- per-view densification statistics (row a11; train_3dgs.py:180-181, train_2dgs.py:189-190,
  * gs3dgs/scene/gaussian_model.py:603-605) ----

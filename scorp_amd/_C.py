@@ -38,7 +38,14 @@ class ScorpGs3dTrainView(ctypes.Structure):
                 ("mask", ctypes.c_void_p), ("lambda_dssim", ctypes.c_float), ("backward_flags", ctypes.c_uint32),
                 ("out_loss3", ctypes.c_void_p), ("loss_workspace", ctypes.c_void_p), ("loss_workspace_bytes", ctypes.c_size_t),
                 ("grad_color", ctypes.c_void_p), ("grads", ctypes.c_void_p), ("backward_scratch", ctypes.c_void_p),
-                ("backward_scratch_bytes", ctypes.c_size_t), ("out_header", ctypes.c_void_p)]
+                ("backward_scratch_bytes", ctypes.c_size_t), ("out_header", ctypes.c_void_p), ("adam", ctypes.c_void_p)]
+
+
+class ScorpFusedAdam(ctypes.Structure):
+    _fields_ = [("exp_avg", ctypes.c_void_p * 6), ("exp_avg_sq", ctypes.c_void_p * 6), ("lr", ctypes.c_float * 6),
+                ("_pad", ctypes.c_float * 2), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
+                ("step", ctypes.c_int32), ("_pad2", ctypes.c_int32), ("skipped_counter", ctypes.c_void_p),
+                ("max_radii2D", ctypes.c_void_p), ("xyz_gradient_accum", ctypes.c_void_p), ("denom", ctypes.c_void_p)]
 
 
 class ScorpGs2dTrainView(ctypes.Structure):
@@ -70,7 +77,7 @@ EXPORTS = [
     "scorp_gs3d_render_image",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_backward_ex", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles", "scorp_gs3d_debug_work",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
-    "scorp_knn_dist2", "scorp_gaussians_transform", "scorp_adam_step", "scorp_adam_step_guarded", "scorp_densification_stats", "scorp_densification_stats_ex", "scorp_gather_rows", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
+    "scorp_knn_dist2", "scorp_gaussians_transform", "scorp_adam_step", "scorp_adam_step_guarded", "scorp_adam_step_guarded_ex", "scorp_densification_stats", "scorp_densification_stats_ex", "scorp_gather_rows", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
     "scorp_gs3d_pose_score_accumulate",
     "scorp_gs2d_state_bytes", "scorp_gs2d_backward_scratch_bytes", "scorp_gs2d_preprocess", "scorp_gs2d_render",
     "scorp_gs2d_render_image",
@@ -157,6 +164,8 @@ def lib():
     L.scorp_adam_step.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i32, vp]
     L.scorp_adam_step_guarded.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                           i32, vp, vp]
+    L.scorp_adam_step_guarded_ex.argtypes = [ctypes.POINTER(ScorpAdamTensor), i32, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                             i32, vp, vp, vp]
     L.scorp_gather_rows.argtypes = [ctypes.POINTER(ScorpRowTensor), i32, vp, u64, vp]
     L.scorp_densification_stats.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.scorp_densification_stats_ex.argtypes = [i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]

@@ -61,20 +61,15 @@ struct AdamPack {
 };
 constexpr int kAdamPerBlock = 256 * 4 * 4;  // 4 float4 per thread
 
-__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float omb1, float b2, float omb2,
-                                         float step_size, float inv_sqrt_bc2, float eps) {
-  // same operation order as torch.optim.Adam (single-tensor, non-capturable): exp_avg.lerp_, addcmul_, sqrt/div/add, addcdiv_
-  // (1 - beta) is formed in double on the host, as torch does, not as 1.0f - float(beta)
-  m = m + (g - m) * omb1;
-  v = v * b2 + omb2 * g * g;
-  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
-  p = p - step_size * (m / denom);
-}
+// (adam_one: common.hpp, shared with the fused epilogue of the per-Gaussian backward)
 
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamPack pk, float omb1, float beta2, float omb2, float eps, float bc1, float inv_sqrt_bc2,
-            const uint32_t *__restrict__ skip_if_nonzero) {
-  if (skip_if_nonzero && *skip_if_nonzero != 0u) return;   // the step is conditional on a device word (see the entry point)
+            const uint32_t *__restrict__ skip_if_nonzero, uint32_t *__restrict__ skipped_counter) {
+  if (skip_if_nonzero && *skip_if_nonzero != 0u) {   // the step is conditional on a device word (see the entry point)
+    if (skipped_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped_counter, 1u);
+    return;
+  }
   int ti = 0;
 #pragma unroll
   for (int k = 1; k < SCORP_ADAM_MAX_TENSORS; k++)
@@ -312,6 +307,12 @@ extern "C" int scorp_adam_step(const ScorpAdamTensor *tensors, int32_t n, double
 
 extern "C" int scorp_adam_step_guarded(const ScorpAdamTensor *tensors, int32_t n, double beta1, double beta2, double eps,
                                        int32_t step, const uint32_t *skip_if_nonzero, scorp_stream_t stream_) {
+  return scorp_adam_step_guarded_ex(tensors, n, beta1, beta2, eps, step, skip_if_nonzero, nullptr, stream_);
+}
+
+extern "C" int scorp_adam_step_guarded_ex(const ScorpAdamTensor *tensors, int32_t n, double beta1, double beta2, double eps,
+                                          int32_t step, const uint32_t *skip_if_nonzero, uint32_t *skipped_counter,
+                                          scorp_stream_t stream_) {
   if (n < 0 || n > SCORP_ADAM_MAX_TENSORS || (n > 0 && !tensors) || step < 1) {
     set_error("bad arguments to scorp_adam_step (n=%d, step=%d)", n, step); return SCORP_ERR_INVALID;
   }
@@ -335,7 +336,7 @@ extern "C" int scorp_adam_step_guarded(const ScorpAdamTensor *tensors, int32_t n
   {
     ProfScope prof(kKAdam, stream);
     adam_kernel<<<blocks, 256, 0, stream>>>(pk, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                                            (float)bc1, (float)(1.0 / sqrt(bc2)), skip_if_nonzero);
+                                            (float)bc1, (float)(1.0 / sqrt(bc2)), skip_if_nonzero, skipped_counter);
   }
   SCORP_KERNEL_CHECK("adam", 0, stream);
   return SCORP_OK;

@@ -335,8 +335,37 @@ int preprocess3d_impl(const ScorpGs3dInputs *in, int32_t *out_radii, uint8_t *ou
 int render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color, float *out_depth,
                   float *out_alpha, float *out_depth_norm, void *zero_buf, size_t zero_bytes, scorp_stream_t stream,
                   bool for_backward, uint32_t *header_copy = nullptr);
+// Fused Adam + densification statistics in the per-Gaussian backward (scorp_gs3d_train_view with `adam`): what the kernel
+// needs, already reduced to floats by the launcher.  Leaves in the order xyz, features_dc, features_rest, opacity, scaling,
+// rotation; m[k] == NULL: the leaf is frozen (no update).
+struct AdamEpi {
+  int on;
+  float *m[6], *v[6];
+  float step_size[6];                     // lr / bias_correction1
+  float omb1, beta2, omb2, eps, inv_sqrt_bc2;
+  const uint32_t *skip;                   // nothing is updated if *skip != 0 when the kernel runs
+  uint32_t *skipped_counter;              // ... and this word is incremented once instead (NULL: not counted)
+  float *max_radii2D, *accum, *denom;     // per-view densification statistics (all three or none)
+};
 void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L, const BinRec *bin, const float *acc,
-                                const ScorpGs3dGrads *grads, hipStream_t stream);
+                                const ScorpGs3dGrads *grads, hipStream_t stream, const AdamEpi *adam = nullptr);
+int backward3d_impl(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity, const float *dL_dcolor,
+                    const float *dL_ddepth, const float *dL_dalpha, const ScorpGs3dGrads *grads, void *scratch,
+                    size_t scratch_bytes, uint32_t flags, scorp_stream_t stream, const AdamEpi *adam);
+// one Adam update, the operation order of torch.optim.Adam (single-tensor, non-capturable): exp_avg.lerp_, addcmul_,
+// sqrt / div / add, addcdiv_; (1 - beta) is formed in double on the host, as torch does.  Shared by adam_kernel
+// (aux_kernels.hip) and the fused epilogue of preprocess_backward_kernel so that the two give the same bits.
+#ifdef __HIPCC__
+__device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, float omb1, float b2, float omb2,
+                                         float step_size, float inv_sqrt_bc2, float eps) {
+#pragma clang fp contract(off)   // every product and sum rounded on its own, wherever the function is inlined: the two call sites
+                                 // must not differ by which pairs the compiler happens to fuse into an fma
+  m = m + (g - m) * omb1;
+  v = v * b2 + omb2 * g * g;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p = p - step_size * (m / denom);
+}
+#endif
 
 // ---- binning shared by the 3DGS and 2DGS paths (gs3d_forward.hip) ----
 int copy_tile_lists_raster(const StateLayout &L, const PairLayout &P, const void *state, const void *pairs, uint64_t capacity,

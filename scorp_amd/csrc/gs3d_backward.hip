@@ -654,6 +654,15 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
                                       const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
                                       const ScorpGs3dGrads *grads, void *scratch, size_t scratch_bytes, uint32_t flags,
                                       scorp_stream_t stream_) {
+  return backward3d_impl(in, state, pairs, capacity, dL_dcolor, dL_ddepth, dL_dalpha, grads, scratch, scratch_bytes, flags, stream_,
+                         nullptr);
+}
+
+// `adam` (scorp_gs3d_train_view): the per-Gaussian kernel applies the optimizer step and the view's statistics itself
+int scorp::backward3d_impl(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
+                           const float *dL_dcolor, const float *dL_ddepth, const float *dL_dalpha,
+                           const ScorpGs3dGrads *grads, void *scratch, size_t scratch_bytes, uint32_t flags,
+                           scorp_stream_t stream_, const AdamEpi *adam) {
   if (!in || !state || !pairs || !grads || !scratch) { set_error("NULL argument to scorp_gs3d_backward"); return SCORP_ERR_INVALID; }
   if (!dL_dcolor) { set_error("dL_dcolor is NULL"); return SCORP_ERR_INVALID; }
   if (in->num_views > 1) { set_error("num_views > 1 is forward only"); return SCORP_ERR_INVALID; }
@@ -696,7 +705,8 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
     const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
     const bool da = dL_ddepth || dL_dalpha, exact = (flags & SCORP_BACKWARD_EXACT_FP32) != 0;
     // nothing but colour gradients wanted (every geometry / opacity output NULL): the colour-only replay
-    const bool color_only = !exact && !grads->means3D && !grads->means2D && !grads->opacities && !grads->scales &&
+    const bool adam_geom = adam && adam->on && (adam->m[0] || adam->m[3] || adam->m[4] || adam->m[5] || adam->accum);
+    const bool color_only = !exact && !adam_geom && !grads->means3D && !grads->means2D && !grads->opacities && !grads->scales &&
                             !grads->rotations && !grads->cov3D_precomp;
     auto wk = det ? (color_only ? blend_backward_wave_kernel<false, false, true, true>
                      : exact ? (da ? blend_backward_wave_kernel<true, true, false, true> : blend_backward_wave_kernel<false, true, false, true>)
@@ -717,7 +727,7 @@ extern "C" int scorp_gs3d_backward_ex(const ScorpGs3dInputs *in, const void *sta
   }
   {
     ProfScope prof(kKPreprocessBackward, stream);
-    launch_preprocess_backward(in, L, (const BinRec *)(base + L.bin), acc, grads, stream);
+    launch_preprocess_backward(in, L, (const BinRec *)(base + L.bin), acc, grads, stream, adam);
   }
   SCORP_KERNEL_CHECK("preprocess_backward", in->debug, stream);
   return SCORP_OK;

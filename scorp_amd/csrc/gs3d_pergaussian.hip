@@ -274,9 +274,74 @@ preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin
 // everything a Gaussian needs - radius word, accumulator row, parameters: 22 dwords - with untracked loads AHEAD of
 // the SH stream and pick them up at vmcnt(12); otherwise the chain "radius -> visible? -> accumulators, parameters"
 // would sit behind the 48 KiB stream (the compiler waits with vmcnt(0) while LDS-DMA loads are pending).
+// n consecutive floats of one leaf: Adam with the gradient in registers.  `p_in`: the parameter values the thread already
+// holds (NULL: read them).
+template <int n>
+__device__ __forceinline__ void adam_leaf(const AdamEpi &ad, int k, float *__restrict__ param, size_t at, const float *gr,
+                                          const float *p_in) {
+  if (!ad.m[k]) return;
+  float *pp = param + at, *pm_ = ad.m[k] + at, *pv = ad.v[k] + at;
+  float pvals[n], m[n], v[n];
+#pragma unroll
+  for (int q = 0; q < n; q++) { pvals[q] = p_in ? p_in[q] : pp[q]; m[q] = pm_[q]; v[q] = pv[q]; }
+#pragma unroll
+  for (int q = 0; q < n; q++) adam_one(pvals[q], gr[q], m[q], v[q], ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+#pragma unroll
+  for (int q = 0; q < n; q++) { pp[q] = pvals[q]; pm_[q] = m[q]; pv[q] = v[q]; }
+}
+__device__ __forceinline__ void adam_one4(const AdamEpi &ad, int k, float4 &p, const float4 g, float4 &m, float4 &v) {
+  adam_one(p.x, g.x, m.x, v.x, ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+  adam_one(p.y, g.y, m.y, v.y, ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+  adam_one(p.z, g.z, m.z, v.z, ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+  adam_one(p.w, g.w, m.w, v.w, ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+}
+// The SH leaves of a block, gradient rows in LDS.  Linear layout (a full block of the training layout): two 16-byte streams
+// per array; the parameters are read again from global memory - the block streamed those 46 KB into LDS microseconds ago
+// (L2) and has since overwritten them there with their gradients.
+__device__ __forceinline__ void adam_sh_linear(const AdamEpi &ad, const float *__restrict__ lds, float *__restrict__ dc,
+                                               float *__restrict__ rest, size_t i0) {
+  const float4 *l4 = reinterpret_cast<const float4 *>(lds), *lr4 = reinterpret_cast<const float4 *>(lds + kShLinearRest);
+  if (ad.m[1]) {
+    float4 *P = reinterpret_cast<float4 *>(dc + i0 * 3), *M = reinterpret_cast<float4 *>(ad.m[1] + i0 * 3), *V = reinterpret_cast<float4 *>(ad.v[1] + i0 * 3);
+    for (int e = threadIdx.x; e < 256 * 3 / 4; e += 256) {
+      float4 p = P[e], m = M[e], v = V[e];
+      adam_one4(ad, 1, p, l4[e], m, v);
+      P[e] = p; M[e] = m; V[e] = v;
+    }
+  }
+  if (ad.m[2]) {
+    float4 *P = reinterpret_cast<float4 *>(rest + i0 * 45), *M = reinterpret_cast<float4 *>(ad.m[2] + i0 * 45), *V = reinterpret_cast<float4 *>(ad.v[2] + i0 * 45);
+    for (int e = threadIdx.x; e < 256 * 45 / 4; e += 256) {
+      float4 p = P[e], m = M[e], v = V[e];
+      adam_one4(ad, 2, p, lr4[e], m, v);
+      P[e] = p; M[e] = m; V[e] = v;
+    }
+  }
+}
+// ... and the padded layout (the last, partial block; any K): element by element
+__device__ __forceinline__ void adam_sh_rows(const AdamEpi &ad, const float *__restrict__ lds, float *__restrict__ dc,
+                                             float *__restrict__ rest, int K, size_t i0, int nrows) {
+  if (ad.m[1])
+    for (int e = threadIdx.x; e < nrows * 3; e += 256) {
+      const size_t at = i0 * 3 + e;
+      float p = dc[at], m = ad.m[1][at], v = ad.v[1][at];
+      adam_one(p, lds[(e / 3) * kShStride + e % 3], m, v, ad.omb1, ad.beta2, ad.omb2, ad.step_size[1], ad.inv_sqrt_bc2, ad.eps);
+      dc[at] = p; ad.m[1][at] = m; ad.v[1][at] = v;
+    }
+  const int R3 = (K - 1) * 3;
+  if (ad.m[2] && R3 > 0)
+    for (int e = threadIdx.x; e < nrows * R3; e += 256) {
+      const int r = e / R3, c = e % R3;
+      const size_t at = i0 * R3 + e;
+      float p = rest[at], m = ad.m[2][at], v = ad.v[2][at];
+      adam_one(p, c < 45 ? lds[r * kShStride + 3 + c] : 0.0f, m, v, ad.omb1, ad.beta2, ad.omb2, ad.step_size[2], ad.inv_sqrt_bc2, ad.eps);
+      rest[at] = p; ad.m[2][at] = m; ad.v[2][at] = v;
+    }
+}
+
 template <int DEG, bool SPLIT, bool LIN>
 __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float *s_sh, const BinRec *__restrict__ bin,
-                                                         const float *__restrict__ acc, const ScorpGs3dGrads &g) {
+                                                         const float *__restrict__ acc, const ScorpGs3dGrads &g, const AdamEpi &ad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool active = LIN || i < a.N;
   const size_t i0 = (size_t)blockIdx.x * 256;
@@ -298,7 +363,12 @@ __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float 
     rad_bits = active ? bin[i].radius : 0;
   }
   const bool visible = (rad_bits & kRadiusMask) != 0;
-  const bool want_sh_grad = a.shs != nullptr && g.shs != nullptr;
+  // fused Adam (scorp_gs3d_train_view with `adam`): the SH gradient rows are wanted in LDS even when nobody asked for them
+  // in global memory, and the geometry chain runs even when every gradient pointer is NULL
+  const bool adam_on = SPLIT && ad.on != 0;
+  const bool adam_sh = adam_on && (ad.m[1] != nullptr || ad.m[2] != nullptr);
+  const bool adam_geom = adam_on && (ad.m[0] || ad.m[3] || ad.m[4] || ad.m[5] || ad.accum);
+  const bool want_sh_grad = a.shs != nullptr && (g.shs != nullptr || adam_sh);
   bool staged = false;
   constexpr bool lin = LIN;
   if (a.shs) {
@@ -323,7 +393,7 @@ __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float 
   float g_op = 0.0f;
   const ShRow row = sh_row(s_sh, threadIdx.x, lin);
   // colour-only calls (post_refine_gs.py:53-56: every geometry / opacity leaf frozen) skip the whole geometry chain
-  const bool want_geom = g.means3D || g.means2D || g.opacities || g.scales || g.rotations || g.cov3D_precomp;
+  const bool want_geom = g.means3D || g.means2D || g.opacities || g.scales || g.rotations || g.cov3D_precomp || adam_geom;
   if (visible && !want_geom) {
 #pragma unroll
     for (int q = 6; q < 9; q++) a_[q] = LIN ? pre_acc[q] : acc[(size_t)i * kAccStride + q];
@@ -517,26 +587,64 @@ __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float 
       for (int q = 0; q < 6; q++) g.cov3D_precomp[6 * (size_t)i + q] = gc6[q];
     }
   }
+  // The optimizer step of this Gaussian, here, where its whole gradient row is at hand (train_3dgs.py:191-193 over
+  // gs3dgs/scene/gaussian_model.py:197-206, as FusedAdam / scorp_adam_step_guarded apply it - same adam_one, same bits), and
+  // the view's share of the densification statistics (train_3dgs.py:180-181; scorp_densification_stats' arithmetic).
+  // Saves, per Gaussian and iteration, the 248-byte gradient row's trip to HBM and back and a second read of the 236
+  // bytes of parameters: 1652 -> 932 bytes of optimizer traffic.  Nothing moves if the view's overflow word is set.
+  bool adam_go = false;
+  if constexpr (SPLIT) {
+    if (adam_on) {
+      adam_go = !(ad.skip && *ad.skip != 0u);
+      if (!adam_go && ad.skipped_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ad.skipped_counter, 1u);
+      if (adam_go && active) {
+        float pin[11];
+        if constexpr (LIN) {
+#pragma unroll
+          for (int q = 0; q < 11; q++) pin[q] = pre[q];
+        }
+        adam_leaf<3>(ad, 0, const_cast<float *>(a.means3D), 3 * (size_t)i, gm, LIN ? pin : nullptr);
+        adam_leaf<1>(ad, 3, const_cast<float *>(a.opacities), (size_t)i, &g_op, LIN ? pin + 10 : nullptr);
+        adam_leaf<3>(ad, 4, const_cast<float *>(a.scales), 3 * (size_t)i, gs, LIN ? pin + 7 : nullptr);
+        adam_leaf<4>(ad, 5, const_cast<float *>(a.rotations), 4 * (size_t)i, gq, LIN ? pin + 3 : nullptr);
+        if (ad.accum && visible) {
+#pragma clang fp contract(off)
+          const float gx = a_[0], gy = a_[1];
+          ad.max_radii2D[i] = fmaxf(ad.max_radii2D[i], (float)(rad_bits & kRadiusMask));
+          ad.accum[i] += sqrtf(gx * gx + gy * gy + 0.0f);
+          ad.denom[i] += 1.0f;
+        }
+      }
+    }
+  }
   if (want_sh_grad) {
     if (!staged && active) sh_row_zero(row);  // nothing visible in this block: rows were never staged
     __syncthreads();
-    if (lin) unstage_sh_linear(s_sh, g.shs, g.shs_rest, i0);
-    else unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
+    if (g.shs) {
+      if (lin) unstage_sh_linear(s_sh, g.shs, g.shs_rest, i0);
+      else unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
+    }
+    if constexpr (SPLIT) {
+      if (adam_go && adam_sh) {
+        if (lin) adam_sh_linear(ad, s_sh, const_cast<float *>(a.shs), const_cast<float *>(a.shs_rest), i0);
+        else adam_sh_rows(ad, s_sh, const_cast<float *>(a.shs), const_cast<float *>(a.shs_rest), a.K, i0, nrows);
+      }
+    }
   }
 }
 
 template <int DEG, bool SPLIT>
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(PgArgs a, const BinRec *__restrict__ bin, const float *__restrict__ acc,
-                           ScorpGs3dGrads g) {
+                           ScorpGs3dGrads g, AdamEpi ad) {
   __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
   if constexpr (SPLIT && DEG == 3) {
     if (a.shs != nullptr && a.K == 16 && !a.cov3D_precomp && a.N - (int)blockIdx.x * 256 >= 256) {
-      preprocess_backward_body<DEG, SPLIT, true>(a, s_sh, bin, acc, g);
+      preprocess_backward_body<DEG, SPLIT, true>(a, s_sh, bin, acc, g, ad);
       return;
     }
   }
-  preprocess_backward_body<DEG, SPLIT, false>(a, s_sh, bin, acc, g);
+  preprocess_backward_body<DEG, SPLIT, false>(a, s_sh, bin, acc, g, ad);
 }
 
 PgArgs make_args(const ScorpGs3dInputs *in, const StateLayout &L) {
@@ -574,13 +682,16 @@ void launch_preprocess(const ScorpGs3dInputs *in, const StateLayout &L, SplatRec
 }
 
 void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L, const BinRec *bin, const float *acc,
-                                const ScorpGs3dGrads *grads, hipStream_t stream) {
+                                const ScorpGs3dGrads *grads, hipStream_t stream, const AdamEpi *adam) {
   const PgArgs a = make_args(in, L);
   const dim3 grid((a.N + 255) / 256), block(256);
   const int deg = in->shs ? in->sh_degree : 0;
   const bool split = in->shs_rest != nullptr;
   const ScorpGs3dGrads g = *grads;
-#define SCORP_LAUNCH_PB(D, S) preprocess_backward_kernel<D, S><<<grid, block, 0, stream>>>(a, bin, acc, g)
+  AdamEpi ad;
+  memset(&ad, 0, sizeof(ad));
+  if (adam && split) ad = *adam;   // (the fused step is defined for the training layout: dc / rest split leaves)
+#define SCORP_LAUNCH_PB(D, S) preprocess_backward_kernel<D, S><<<grid, block, 0, stream>>>(a, bin, acc, g, ad)
   if (split) {
     switch (deg) { case 0: SCORP_LAUNCH_PB(0, true); break; case 1: SCORP_LAUNCH_PB(1, true); break;
                    case 2: SCORP_LAUNCH_PB(2, true); break; default: SCORP_LAUNCH_PB(3, true); }

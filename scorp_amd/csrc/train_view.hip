@@ -1,6 +1,8 @@
 // train_view.hip — scorp_gs3d_train_view: one training view (render, L1 + SSIM loss, backward) enqueued by ONE call.
 // Host code only: it chains the library's own entry points, so the kernels, their order and their results are those
 // of the separate calls (train_3dgs.py:88-150 minus the optimizer step).  See include/scorp_gs.h for the contract.
+#include <math.h>
+
 #include "common.hpp"
 
 using namespace scorp;
@@ -29,10 +31,39 @@ extern "C" int scorp_gs3d_train_view(const ScorpGs3dTrainView *v, scorp_stream_t
                                 v->loss_workspace_bytes, 1, false, (hipStream_t)stream)) return e;
   if (int e = loss_backward_impl(v->out_color, v->gt, v->mask, 3, H, W, v->lambda_dssim, v->loss_workspace, nullptr,
                                  v->grad_color, v->out_loss3, (hipStream_t)stream)) return e;
-  return scorp_gs3d_backward_ex(in, v->state, v->pairs, v->capacity, v->grad_color, nullptr, nullptr, v->grads,
-                                v->backward_scratch, v->backward_scratch_bytes,
-                                (v->backward_flags & ~SCORP_BACKWARD_SCRATCH_ZEROED) | (zero_here ? SCORP_BACKWARD_SCRATCH_ZEROED : 0u),
-                                stream);
+  AdamEpi ad;
+  memset(&ad, 0, sizeof(ad));
+  if (v->adam) {
+    const ScorpFusedAdam *fa = v->adam;
+    if (!in->shs || !in->shs_rest || in->raw_params != 7 || !in->scales || !in->rotations || in->sh_coeffs < 2 || fa->step < 1) {
+      set_error("scorp_gs3d_train_view: the fused optimizer step needs the raw-leaf convention (shs + shs_rest, raw_params = 7, "
+                "scales + rotations) and step >= 1");
+      return SCORP_ERR_INVALID;
+    }
+    const bool stats = fa->max_radii2D || fa->xyz_gradient_accum || fa->denom;
+    if (stats && !(fa->max_radii2D && fa->xyz_gradient_accum && fa->denom)) {
+      set_error("scorp_gs3d_train_view: give all three statistics arrays or none"); return SCORP_ERR_INVALID;
+    }
+    uintptr_t al = 0;
+    for (int k = 0; k < 6; k++) {
+      if ((fa->exp_avg[k] == nullptr) != (fa->exp_avg_sq[k] == nullptr)) { set_error("scorp_gs3d_train_view: exp_avg / exp_avg_sq of leaf %d", k); return SCORP_ERR_INVALID; }
+      al |= (uintptr_t)fa->exp_avg[k] | (uintptr_t)fa->exp_avg_sq[k];
+      ad.m[k] = fa->exp_avg[k]; ad.v[k] = fa->exp_avg_sq[k];
+    }
+    if (al & 15) { set_error("scorp_gs3d_train_view: Adam moments must be 16-byte aligned"); return SCORP_ERR_INVALID; }
+    const double bc1 = 1.0 - pow(fa->beta1, (double)fa->step), bc2 = 1.0 - pow(fa->beta2, (double)fa->step);
+    for (int k = 0; k < 6; k++) ad.step_size[k] = fa->lr[k] / (float)bc1;     // (float / float, as adam_kernel forms it)
+    ad.on = 1;
+    ad.omb1 = (float)(1.0 - fa->beta1); ad.beta2 = (float)fa->beta2; ad.omb2 = (float)(1.0 - fa->beta2); ad.eps = (float)fa->eps;
+    ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    ad.skip = v->out_header ? v->out_header + 1 : reinterpret_cast<const uint32_t *>(v->state) + 1;   // the view's overflow word
+    ad.skipped_counter = fa->skipped_counter;
+    ad.max_radii2D = fa->max_radii2D; ad.accum = fa->xyz_gradient_accum; ad.denom = fa->denom;
+  }
+  return backward3d_impl(in, v->state, v->pairs, v->capacity, v->grad_color, nullptr, nullptr, v->grads,
+                         v->backward_scratch, v->backward_scratch_bytes,
+                         (v->backward_flags & ~SCORP_BACKWARD_SCRATCH_ZEROED) | (zero_here ? SCORP_BACKWARD_SCRATCH_ZEROED : 0u),
+                         stream, v->adam ? &ad : nullptr);
 }
 
 extern "C" int scorp_gs2d_train_view(const ScorpGs2dTrainView *v, scorp_stream_t stream) {

@@ -61,10 +61,15 @@ def _shared_overflow(pkg, data_parallel):
 
 def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteration, scene_extent=4.0, densify=True,
                        render_fn=render, loss_fn=fused_l1_ssim_loss, data_parallel=False, gt_depth=None, gt_depth_est=None,
-                       surfels=False, fused_view=False, white_background=False, sparse_gradients=False):
+                       surfels=False, fused_view=False, white_background=False, sparse_gradients=False, fused_step=True,
+                       view_fn=None):
     """Returns (loss tensor, render package). Mirrors train_3dgs.py:74-193 for one camera.  With `data_parallel` the
     caller hands each rank a different camera; gradients are averaged over ranks before the optimizer step and the
-    densification statistics are reduced before they are used, so the replicas stay bit-identical."""
+    densification statistics are reduced before they are used, so the replicas stay bit-identical.
+    `fused_step` (with `fused_view`): let the view apply the optimizer step itself where that is the same computation (see
+    below).  `view_fn`: the one-call view (default train_view.train_view; the CPU tests of the loop's bookkeeping pass a
+    stand-in)."""
+    stepped_in_view = False
     gaussians.update_learning_rate(iteration)
     if iteration % 1000 == 0:
         gaussians.oneupSHdegree()
@@ -87,14 +92,31 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
             and getattr(pipe, "fused_activations", False)):
         # plain photometric iteration: render + loss + backward enqueued by ONE library call (train_view.py); same
         # kernels and results, no autograd graph.  The pair buffer is reserved, the caller drains (see train()).
-        from .train_view import train_view
-        pkg = train_view(cam, gaussians, pipe, bg, gt_image, opt.lambda_dssim)
+        view_fn = view_fn or _default_view_fn()
+        # The optimizer step itself inside the view (ScorpFusedAdam: the per-Gaussian backward kernel applies Adam and the
+        # view's statistics while it holds the gradient row) on the iterations where the reference's optimizer.step() sees
+        # this view's gradients as they are: one replica (no averaging first) and neither a densification nor an opacity
+        # reset in between - after those the reference's leaves are fresh tensors without .grad and its step() passes them by
+        # (train_3dgs.py:183-193), which the separate path below reproduces.
+        will_densify = densify and iteration < opt.densify_until_iter and iteration > opt.densify_from_iter and \
+            iteration % opt.densification_interval == 0
+        will_reset = densify and iteration < opt.densify_until_iter and (
+            iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter))
+        step_in_view = fused_step and not data_parallel and not will_densify and not will_reset and \
+            hasattr(gaussians.optimizer, "fused_view_pack")
+        kw_view = {}
+        if step_in_view:
+            kw_view["optimizer"] = gaussians.optimizer
+            if densify and iteration < opt.densify_until_iter and getattr(type(gaussians), "_stats_norm_components", None) == 2:
+                kw_view["stats"] = (gaussians.max_radii2D, gaussians.xyz_gradient_accum, gaussians.denom)
+        pkg = view_fn(cam, gaussians, pipe, bg, gt_image, opt.lambda_dssim, **kw_view)
         loss = pkg["loss"]
+        stepped_in_view = bool(pkg.get("optimizer_stepped"))
         # The pair buffer was reserved, not sized from this view's count.  If the view overflowed it (device word
         # pkg["overflow"]), its gradients come from truncated tile lists: the optimizer step is skipped on the device and
         # the densification statistics below are masked - no host synchronisation, nothing wrong is ever applied.
         ovf = _shared_overflow(pkg, data_parallel)      # BEFORE the gradients are averaged and the flag is used
-        if hasattr(gaussians.optimizer, "skip_flag"):
+        if hasattr(gaussians.optimizer, "skip_flag") and not stepped_in_view:
             gaussians.optimizer.skip_flag = ovf
         pkg["visibility_filter"] = pkg["visibility_filter"] & (ovf == 0)
     else:
@@ -128,7 +150,8 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
                 average_gradients(ps)
         if densify and iteration < opt.densify_until_iter:
             vis, radii = pkg["visibility_filter"], pkg["radii"]
-            gaussians.accumulate_view_stats(pkg["viewspace_points"], vis, radii)   # train_3dgs.py:180-181, no mask indexing
+            if not pkg.get("stats_accumulated"):     # (the fused step's kernel has done it)
+                gaussians.accumulate_view_stats(pkg["viewspace_points"], vis, radii)   # train_3dgs.py:180-181, no mask indexing
             if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
                 size_threshold = opt.max_screen_size if iteration > opt.opacity_reset_interval else None   # train_3dgs.py:184
                 if data_parallel:
@@ -141,9 +164,15 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
                     _drain_reservation(optimizer=gaussians.optimizer)
             if iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter):
                 gaussians.reset_opacity()   # train_3dgs.py:187-188
-        gaussians.optimizer.step()
+        if not stepped_in_view:
+            gaussians.optimizer.step()
         gaussians.optimizer.zero_grad(set_to_none=True)
     return loss, pkg
+
+
+def _default_view_fn():
+    from .train_view import train_view
+    return train_view
 
 
 def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, background=None, seed=0, data_parallel=False,
@@ -176,7 +205,8 @@ def train(gaussians, cameras, gt_images, opt, pipe=None, iterations=None, backgr
             # If it overflowed it was discarded on the device and the reservation has grown: the same views run again,
             # instead of a context's default being wrong for every iteration up to the first periodic drain.
             retries += 1
-            first_checked = _drain_reservation(quiet=retries < 3, optimizer=gaussians.optimizer) or data_parallel or retries >= 3   # (data-parallel replicas must not diverge in their camera order)
+            # (data-parallel replicas take the same decision: the skipped-step count they read is that of the all-reduced word)
+            first_checked = _drain_reservation(quiet=retries < 3, optimizer=gaussians.optimizer) or retries >= 3
             if not first_checked:
                 stack.extend(reversed(ks))
                 continue
@@ -206,16 +236,29 @@ def _drain_reservation(quiet=False, optimizer=None):
     `optimizer`: FusedAdam counted a bias-correction step on the host for every view, the discarded ones included; they
     are taken back here (rollback_steps), so that the updates after a retry are scaled as those of a run that never
     overflowed (a first-view overflow is an expected event: the default reservation is four pairs per Gaussian)."""
+    from .rasterizer3d import PairOverflow
+    ok, msg = True, None
     try:
         PairPolicy.drain()
-        return True
-    except RuntimeError as e:
-        if optimizer is not None and hasattr(optimizer, "rollback_steps"):
-            optimizer.rollback_steps(getattr(e, "count", 1))
-        if not quiet:
-            import warnings
-            warnings.warn(f"train(fused_view=True): {e}; the overflowed views were skipped (no optimizer step, no statistics)")
-        return False
+    except PairOverflow as e:      # (only the reservation's own report: any other error propagates)
+        ok, msg = False, str(e)
+    # How many steps to take back is read from the optimizer's OWN device counter (FusedAdam.take_skipped: incremented by the
+    # guarded step where its guard word was set) - not from the rank-local list of pending views: it counts this optimizer's
+    # steps and nothing else (evaluation renders, other models' views are not in it), and in a data-parallel run the guard
+    # is the all-reduced overflow word, so every replica takes back the same number at the same drain and their bias
+    # corrections stay equal (round 5 rolled back on the rank that overflowed only: replicas diverged by one step).
+    if optimizer is not None and hasattr(optimizer, "take_skipped"):
+        n = optimizer.take_skipped()
+        if n:
+            optimizer.rollback_steps(n)
+            ok = False
+            msg = msg or f"{n} optimizer step(s) were skipped on the device because a replica's view overflowed its pair reservation"
+    elif optimizer is not None and hasattr(optimizer, "rollback_steps") and not ok:
+        optimizer.rollback_steps(1)
+    if not ok and not quiet:
+        import warnings
+        warnings.warn(f"train(fused_view=True): {msg}; the overflowed views were skipped (no optimizer step, no statistics)")
+    return ok
 
 
 def post_refine(gaussians, cameras, gt_images, gt_alphas, opt, iterations=800, pipe=None, background=None, seed=0,

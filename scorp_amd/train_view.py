@@ -29,9 +29,19 @@ def _accumulate(p, g):
         p.grad += g
 
 
-def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2, mask=None, scaling_modifier=1.0):
+def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2, mask=None, scaling_modifier=1.0,
+               optimizer=None, stats=None):
     """Returns the dict of `renderer.render` plus "loss", "l1", "ssim" (0-d views of one device tensor); parameter
-    gradients are accumulated into `pc`'s leaves.  Needs the model's raw leaves (fused activations)."""
+    gradients are accumulated into `pc`'s leaves.  Needs the model's raw leaves (fused activations).
+
+    `optimizer` (a FusedAdam holding the model's leaves): the optimizer step of this iteration is applied INSIDE the view, by
+    the per-Gaussian backward kernel (ScorpFusedAdam, include/scorp_gs.h) - same update as optimizer.step() on the view's
+    gradients, bit for bit, but the gradient rows never go to HBM: the leaves get NO .grad, the result carries
+    "optimizer_stepped": True and the caller must not call optimizer.step() for this iteration.  Skipped on the device if
+    the view overflowed its pair reservation (counted in optimizer.take_skipped()).  `stats` = (max_radii2D,
+    xyz_gradient_accum, denom): the view's share of the densification statistics (GaussianModel.accumulate_view_stats) by
+    the same kernel; then "viewspace_points".grad is None.  If the step cannot be fused (pending gradients, a leaf the
+    optimizer does not hold) the view runs as without `optimizer` and says "optimizer_stepped": False."""
     L = _C.lib()
     xyz = pc.get_xyz
     if not xyz.is_cuda:
@@ -68,10 +78,20 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     scratch = new((scratch_bytes,), torch.uint8)
     need = [p.requires_grad for p in leaves]          # frozen leaves (post-refine) get no gradient buffer: NULL = not wanted
     need[1] = need[2] = need[1] or need[2]            # the SH gradient is written as a whole
-    g = [torch.empty_like(x) if n else None for x, n in zip(t, need)]
+    pack = None
+    if (optimizer is not None and hasattr(optimizer, "fused_view_pack") and f_rest.numel() > 0
+            and all(x.data_ptr() == p.data_ptr() for x, p in zip(t, leaves))):
+        st = None
+        if stats is not None and xyz.requires_grad:
+            st = tuple(s_ if (s_.dtype == torch.float32 and s_.is_contiguous()) else None for s_ in stats)
+            st = None if any(s_ is None for s_ in st) else st
+        pack = optimizer.fused_view_pack(leaves, st)
+        stats = st
+    fused_step = pack is not None
+    g = [torch.empty_like(x) if (n and not fused_step) else None for x, n in zip(t, need)]
     # the screen-space gradient feeds the densification statistics: not produced when the positions are frozen
     # (renderer.render does the same), which leaves the backward with colour gradients only -> its colour-only path
-    g_means2D = new((N, 3)) if xyz.requires_grad else None
+    g_means2D = new((N, 3)) if (xyz.requires_grad and not (fused_step and stats is not None)) else None
     grads = _C.ScorpGs3dGrads()
     grads.means3D, grads.means2D, grads.shs, grads.shs_rest = _ptr(g[0]), _ptr(g_means2D), _ptr(g[1]), _ptr(g[2])
     grads.opacities, grads.scales, grads.rotations = _ptr(g[3]), _ptr(g[4]), _ptr(g[5])
@@ -87,12 +107,15 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes
     header = new((64,), torch.uint8)                  # {pairs needed, overflow, capacity, 0}: written by the scatter kernel
     v.out_header = header.data_ptr()
+    if fused_step:
+        v.adam = ctypes.addressof(pack[0])
     _C.check(L.scorp_gs3d_train_view(ctypes.byref(v), _stream()), "scorp_gs3d_train_view")
     PairPolicy.pend(state, N, H, W, header=header)    # queued for drain(): no copy launch, the state blob is not pinned
-    for p, gp in zip(leaves, g):
-        if p.requires_grad:
-            _accumulate(p, gp.view_as(p))
-    return {"render": color, "viewspace_points": _ViewspaceGrad(g_means2D), "visibility_filter": visible.view(torch.bool),
+    if not fused_step:
+        for p, gp in zip(leaves, g):
+            if p.requires_grad:
+                _accumulate(p, gp.view_as(p))
+    return {"optimizer_stepped": fused_step, "stats_accumulated": fused_step and stats is not None, "render": color, "viewspace_points": _ViewspaceGrad(g_means2D), "visibility_filter": visible.view(torch.bool),
             "radii": radii, "render_depth": depth, "render_alpha": alpha, "loss": loss3[0], "l1": loss3[1], "ssim": loss3[2],
             # != 0 if this view needed more pairs than were reserved (its images and gradients then come from truncated
             # tile lists): a device word, so the caller can make the optimizer step conditional without a host sync

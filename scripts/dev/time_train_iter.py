@@ -19,6 +19,8 @@ if SURFELS:
 model = (GaussianModel2D if SURFELS else GaussianModel).from_raw(raw, deg, device=dev); model.active_sh_degree = deg
 render3d = render2d if SURFELS else render3d
 KW = dict(surfels=True) if SURFELS else {}
+if os.environ.get("NO_FUSED_STEP"):      # A/B: the optimizer step as a separate launch (round 5's iteration)
+    KW["fused_step"] = False
 cams = ring_cameras(8, 1600, 1200, 4, device=dev)
 pipe = PipelineParams(); pipe.fused_activations = True
 bg = torch.zeros(3, device=dev)

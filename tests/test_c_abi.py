@@ -49,7 +49,8 @@ def test_struct_layout_matches_header():
     from scorp_amd import _C
     assert ctypes.sizeof(_C.ScorpGs3dInputs) == 40 + 12 * 8 + 8   # 10 ints/floats, 12 pointers, raw_params + padding
     assert ctypes.sizeof(_C.ScorpGs3dGrads) == 9 * 8
-    assert ctypes.sizeof(_C.ScorpGs3dTrainView) == 13 * 8 + 2 * 4 + 8 * 8   # see the struct in include/scorp_gs.h
+    assert ctypes.sizeof(_C.ScorpGs3dTrainView) == 13 * 8 + 2 * 4 + 9 * 8   # see the struct in include/scorp_gs.h
+    assert ctypes.sizeof(_C.ScorpFusedAdam) == 12 * 8 + 8 * 4 + 3 * 8 + 2 * 4 + 4 * 8
 
 
 def test_header_is_plain_c(tmp_path):
@@ -59,13 +60,14 @@ def test_header_is_plain_c(tmp_path):
     from scorp_amd import _C
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "t.c"
-    src.write_text('#include <stdio.h>\n#include "scorp_gs.h"\nint main(void) { printf("%zu %zu %zu %zu\\n", '
-                   'sizeof(ScorpGs3dInputs), sizeof(ScorpGs3dGrads), sizeof(ScorpGs3dTrainView), sizeof(ScorpGs2dTrainView)); return 0; }\n')
+    src.write_text('#include <stdio.h>\n#include "scorp_gs.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", '
+                   'sizeof(ScorpGs3dInputs), sizeof(ScorpGs3dGrads), sizeof(ScorpGs3dTrainView), sizeof(ScorpGs2dTrainView), '
+                   'sizeof(ScorpFusedAdam)); return 0; }\n')
     exe = tmp_path / "t"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
-    a, b, c, d = (int(x) for x in subprocess.check_output([str(exe)]).split())
-    assert (a, b, c, d) == (ctypes.sizeof(_C.ScorpGs3dInputs), ctypes.sizeof(_C.ScorpGs3dGrads), ctypes.sizeof(_C.ScorpGs3dTrainView),
-                            ctypes.sizeof(_C.ScorpGs2dTrainView))
+    a, b, c, d, e = (int(x) for x in subprocess.check_output([str(exe)]).split())
+    assert (a, b, c, d, e) == (ctypes.sizeof(_C.ScorpGs3dInputs), ctypes.sizeof(_C.ScorpGs3dGrads), ctypes.sizeof(_C.ScorpGs3dTrainView),
+                               ctypes.sizeof(_C.ScorpGs2dTrainView), ctypes.sizeof(_C.ScorpFusedAdam))
 
 
 def test_shim_packages_expose_reference_names(built_lib):

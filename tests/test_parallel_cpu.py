@@ -216,6 +216,112 @@ def test_two_rank_data_parallel_training_keeps_replicas_identical():
     assert (ref - flat).abs().max() < 1e-5
 
 
+# ---- an overflow on ONE replica: both skip the step, both take it back (the advisor's round-5 finding), two gloo ranks ----
+class _GuardedAdamStandin(torch.optim.Adam):
+    """FusedAdam's bookkeeping on CPU tensors: the host counter advances on every step(), the update is skipped when the guard
+    word is set and the optimizer's own counter says so (take_skipped), rollback_steps takes the skipped steps back."""
+    def __init__(self, params, **kw):
+        super().__init__(params, **kw)
+        self.skip_flag, self._skipped, self._stepped = None, 0, []
+
+    def step(self, closure=None):
+        skip, self.skip_flag = self.skip_flag, None
+        if skip is not None and int(skip.reshape(-1)[0]) != 0:
+            self._skipped += 1
+            self._stepped = []
+            for g in self.param_groups:
+                for p in g["params"]:
+                    if p.grad is not None:
+                        st = self.state[p]
+                        if len(st) == 0:
+                            st["step"], st["exp_avg"], st["exp_avg_sq"] = torch.tensor(0.0), torch.zeros_like(p), torch.zeros_like(p)
+                        st["step"] += 1
+                        self._stepped.append(st)
+            return None
+        super().step()
+        self._stepped = [self.state[p] for g in self.param_groups for p in g["params"] if p.grad is not None]
+        return None
+
+    def take_skipped(self):
+        n, self._skipped = self._skipped, 0
+        return n
+
+    def rollback_steps(self, n=1):
+        for st in self._stepped:
+            st["step"] -= min(float(n), float(st["step"]))
+
+
+class _Sink:
+    def __init__(self, grad):
+        self.grad = grad
+
+
+def _overflowing_view(rank, calls):
+    """A stand-in for train_view.train_view on CPU: the gradients of _fake_render / _plain_loss land in the leaves' .grad, and
+    the view says it overflowed its pair reservation on RANK 0's FIRST call only."""
+    def view(cam, pc, pipe, bg, gt, lambda_dssim, **kw):
+        assert not kw, "the step inside the view is not for data-parallel replicas"
+        pkg = _fake_render(cam, pc, pipe, bg)
+        loss = _plain_loss(pkg["render"], gt, lambda_dssim)
+        loss.backward()
+        calls.append(cam.k)
+        over = 1 if (rank == 0 and len(calls) == 1) else 0
+        return {"loss": loss.detach(), "overflow": torch.tensor([over], dtype=torch.int32), "radii": pkg["radii"],
+                "visibility_filter": pkg["visibility_filter"], "viewspace_points": _Sink(pkg["viewspace_points"].grad),
+                "render": pkg["render"].detach()}
+    return view
+
+
+def _overflow_worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        import warnings
+        from scorp_amd.fused_loss import fused_l1_ssim_loss
+        from scorp_amd.train import PipelineParams, train
+        m, opt, cams, gts = _dp_setup()
+        opt.densify_from_iter = 1 << 30
+        m.training_setup(opt)
+        m.optimizer = _GuardedAdamStandin(m.optimizer.param_groups, lr=0.0, eps=1e-15)
+        calls = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            train(m, cams, gts, opt, PipelineParams(), iterations=5, data_parallel=True, fused_view=True, loss_fn=fused_l1_ssim_loss,
+                  view_fn=_overflowing_view(rank, calls), scene_extent=4.0)
+        steps = sorted({float(st["step"]) for st in m.optimizer.state.values()})
+        flat = torch.cat([p.detach().reshape(-1) for p in (m._xyz, m._features_dc, m._features_rest, m._opacity, m._scaling, m._rotation)])
+        both = [torch.zeros_like(flat) for _ in range(world_size)]
+        dist.all_gather(both, flat)
+        q.put((rank, "ok", steps, len(calls), bool(torch.equal(both[0], both[1]))))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc(), [], 0, False))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_an_overflow_on_one_replica_keeps_step_counters_and_parameters_equal():
+    """Round 5's FusedAdam.rollback_steps() was driven by the rank-local list of overflowed views: the replica whose view
+    overflowed rolled its bias-correction counter back, the one that skipped the same step because of its peer did not, and
+    from then on the two applied differently scaled updates.  The count now comes from the optimizer's own counter of steps
+    skipped on the all-reduced word: after five iterations that begin with an overflow on rank 0 only, both replicas have
+    taken the first view again (six views each), their step counters read 5 and their parameters are the same bits."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+    for rank, _, steps, ncalls, same in res:
+        assert steps == [5.0], (rank, steps)
+        assert ncalls == 6, (rank, ncalls)      # the discarded first view ran again - on BOTH replicas
+        assert same, "replicas diverged"
+
+
 # ---- rotation_sweep itself on two gloo ranks (a stand-in renderer replaces the HIP rasterizer on CPU) ----
 def _standin_render(cam, pc, pipe, bg, **_):
     """Orthographic depth / alpha splat of the points onto a 16x16 grid: enough for the fitness to prefer the planted

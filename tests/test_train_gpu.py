@@ -193,6 +193,104 @@ def test_training_with_fused_views_matches_the_autograd_loop(dev):
     assert abs(na - nb) <= 0.02 * na, (na, nb)      # clone / split decisions sit on thresholds: a handful may flip
 
 
+@pytest.mark.parametrize("deg,n", [(3, 3000), (1, 1500), (3, 256)])
+def test_optimizer_step_inside_the_view_equals_fused_adam_on_the_written_gradients(deg, n, dev):
+    """ScorpFusedAdam: the per-Gaussian backward kernel applies the Adam step and the view's densification statistics while
+    it holds the gradient row (train_view(optimizer=..., stats=...)).  Against the separate path - the same view writing
+    its gradients, GaussianModel.accumulate_view_stats, FusedAdam.step() - over four iterations with a moving learning
+    rate, under the deterministic backward (so that both runs see the same gradient bits): parameters, both Adam moments
+    and the three statistics arrays are the SAME BITS.  3000 = 11 full blocks (linear SH layout) + a partial one (padded
+    layout); SH degree 1 takes the padded layout throughout."""
+    from scorp_amd import rasterizer3d as R
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams
+    from scorp_amd.train_view import train_view
+    raw = make_gaussians(n, deg, 31, log_scale_mean=math.log(0.05))
+    cams = ring_cameras(4, 160, 112, 5, radius=3.2, device=dev)
+    gts = [torch.rand(3, 112, 160, device=dev, generator=torch.Generator(device=dev).manual_seed(k)) for k in range(4)]
+    bg, pipe = torch.tensor([0.1, 0.2, 0.3], device=dev), PipelineParams()
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    res = []
+    PairPolicy.reset()
+    try:
+        with R.backward_precision("deterministic"):
+            for in_view in (False, True):
+                m = GaussianModel.from_raw(raw, deg, device=dev)
+                m.active_sh_degree = deg
+                opt = OptimizationParams()
+                m.training_setup(opt)
+                for it in range(4):
+                    m.update_learning_rate(it + 1)
+                    if in_view:
+                        pkg = train_view(cams[it], m, pipe, bg, gts[it], 0.2, optimizer=m.optimizer,
+                                         stats=(m.max_radii2D, m.xyz_gradient_accum, m.denom))
+                        assert pkg["optimizer_stepped"] and pkg["stats_accumulated"]
+                        assert all(getattr(m, nm).grad is None for nm in names)
+                    else:
+                        pkg = train_view(cams[it], m, pipe, bg, gts[it], 0.2)
+                        assert not pkg["optimizer_stepped"]
+                        m.accumulate_view_stats(pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
+                        m.optimizer.step()
+                        m.optimizer.zero_grad(set_to_none=True)
+                PairPolicy.drain()
+                assert {float(st["step"]) for st in m.optimizer.state.values()} == {4.0}
+                assert m.optimizer.take_skipped() == 0
+                st = [m.optimizer.state[getattr(m, nm)] for nm in names]
+                res.append(([getattr(m, nm).detach().clone() for nm in names], [s_["exp_avg"].clone() for s_ in st],
+                            [s_["exp_avg_sq"].clone() for s_ in st],
+                            [m.max_radii2D.clone(), m.xyz_gradient_accum.clone(), m.denom.clone()]))
+    finally:
+        PairPolicy.reset()
+    (pa, ma, va, sa), (pb, mb, vb, sb) = res
+    assert float(sa[2].sum()) > 0
+    for nm, a, b in zip(names, pa, pb):
+        assert torch.equal(a, b), f"parameter {nm}: {float((a - b).abs().max()):.3e}"
+    for nm, a, b in zip(names, ma, mb):
+        assert torch.equal(a, b), f"exp_avg of {nm}"
+    for nm, a, b in zip(names, va, vb):
+        assert torch.equal(a, b), f"exp_avg_sq of {nm}"
+    for nm, a, b in zip(("max_radii2D", "xyz_gradient_accum", "denom"), sa, sb):
+        assert torch.equal(a, b), nm
+
+
+def test_step_inside_the_view_is_skipped_and_counted_when_the_view_overflows(dev):
+    """The fused step honours the view's own overflow word: an overflowed view moves no parameter, no moment and no statistic,
+    and the optimizer's device counter says one step was skipped (FusedAdam.take_skipped -> rollback_steps)."""
+    from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams, _drain_reservation
+    from scorp_amd.train_view import train_view
+    PairPolicy.reset()
+    try:
+        m = GaussianModel.from_raw(make_gaussians(3000, 3, 4, log_scale_mean=math.log(0.05)), 3, device=dev)
+        m.active_sh_degree = 3
+        m.training_setup(OptimizationParams())
+        cam = ring_cameras(3, 128, 96, 2, radius=3.0, device=dev)[1]
+        gt, bg = torch.rand(3, 96, 128, device=dev), torch.zeros(3, device=dev)
+        PairPolicy.set_context(3000, 96, 128, 64)
+        names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+        before = [getattr(m, nm).detach().clone() for nm in names]
+        pkg = train_view(cam, m, PipelineParams(), bg, gt, 0.2, optimizer=m.optimizer, stats=(m.max_radii2D, m.xyz_gradient_accum, m.denom))
+        assert pkg["optimizer_stepped"] and int(pkg["overflow"]) != 0
+        for nm, b in zip(names, before):
+            assert torch.equal(b, getattr(m, nm).detach()), nm
+            assert float(m.optimizer.state[getattr(m, nm)]["exp_avg"].abs().sum()) == 0.0
+        assert float(m.denom.sum()) == 0.0 and float(m.max_radii2D.sum()) == 0.0
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert _drain_reservation(optimizer=m.optimizer) is False          # reads the counter (1), rolls the step back
+        assert {float(st["step"]) for st in m.optimizer.state.values()} == {0.0}
+        pkg = train_view(cam, m, PipelineParams(), bg, gt, 0.2, optimizer=m.optimizer)
+        assert int(pkg["overflow"]) == 0 and not torch.equal(before[0], m._xyz.detach())
+        assert _drain_reservation(optimizer=m.optimizer) is True
+    finally:
+        PairPolicy.reset()
+
+
 def test_overflowed_fused_view_is_discarded_on_the_device(dev):
     """A fused view whose reserved pair buffer is too small reports it in a device word; the guarded Adam step then
     updates nothing and the view's visibility filter is empty (no densification statistics) - no host synchronisation
