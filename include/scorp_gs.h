@@ -102,7 +102,7 @@ typedef struct ScorpGs3dGrads {
 
 int scorp_version(void);
 /* First 16 hex digits of the sha256 over the kernel sources (csrc/ *.hip, *.hpp, this header) the library was built
- * from; profiles/traffic.json and profiles/valu.json carry the same stamp. */
+ * from; profiles/traffic.json and profiles/valu_mix.json carry the same stamp. */
 const char *scorp_source_sha(void);
 const char *scorp_last_error(void);
 

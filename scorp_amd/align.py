@@ -85,9 +85,15 @@ class StackedSweep:
     camera together is invisible) and rendering all V views as ONE stacked image (ScorpGs3dInputs.num_views): per
     hypothesis one preprocess -> bin -> sort -> blend launch set of training-frame size plus ONE score launch, instead
     of a model clone + ~20 torch kernels + V x 7 latency-bound launches.  The camera matrices of every hypothesis are
-    formed by three batched matmuls up front."""
+    formed by three batched matmuls up front.
 
-    def __init__(self, model, cameras, targets, bg):
+    `batch` hypotheses share a launch set (round 6): their batch x V views are one stacked image.  Measured before it was
+    built (scripts/dev/time_sweep_batch.py, S4: 100 k Gaussians, 15 x 800x800): 567 us per hypothesis alone, 504 in pairs,
+    577 in fours (beyond 8 192 cells the stacked image leaves the two-level binning) - the binning kernels gain 15 - 25 %
+    from the doubled launch, the blend, which is 300 of the 567 us and bound by its own arithmetic, 4 %.  The sweep is not a
+    chain of latency-bound launches any more; it costs what its 5.9 M (tile, splat) pairs per hypothesis cost."""
+
+    def __init__(self, model, cameras, targets, bg, batch=None):
         from .multiview import ViewStack
         self.model, self.bg = model, bg
         self.dev = model._xyz.device
@@ -96,7 +102,12 @@ class StackedSweep:
         self.t_depth = torch.cat([t["render_depth"].reshape(self.stack.H, self.stack.W) for t in targets]).contiguous()
         self.t_alpha = torch.cat([t["render_alpha"].reshape(self.stack.H, self.stack.W) for t in targets]).contiguous()
         self.centre = model._xyz.detach().mean(0)
-        # sizing pass (setup): the exact pair count of the unrotated object; the sweep reserves twice that
+        # hypotheses per launch set: as many as keep the stacked image on the two-level binning (common.hpp: kMaxCells = 8192
+        # cells of 64 x 64 pixels), at most two - four were measured slower than two
+        cells = -(-self.stack.W // 64) * -(-(self.stack.V * self.stack.H) // 64)
+        self.batch = max(1, min(2, 8192 // max(cells, 1))) if batch is None else max(1, int(batch))
+        self._stacks = {1: self.stack}
+        # sizing pass (setup): the exact pair count of the unrotated object; the sweep reserves twice that per hypothesis
         from .multiview import render_stacked
         prev = PairPolicy.mode
         PairPolicy.mode = "exact"
@@ -105,41 +116,59 @@ class StackedSweep:
         finally:
             PairPolicy.mode = prev
 
-    def score(self, rotations, ids):
+    def _stack_of(self, h):
+        """The ViewStack of h hypotheses' views (h x V cameras; only its sizes are used, the matrices are replaced per call)."""
+        if h not in self._stacks:
+            import copy as _copy
+            st = _copy.copy(self.stack)
+            st.V = h * self.stack.V
+            st.view, st.proj, st.campos = (t.repeat((h,) + (1,) * (t.dim() - 1)) for t in (self.stack.view, self.stack.proj, self.stack.campos))
+            self._stacks[h] = st
+        return self._stacks[h]
+
+    def _score_all(self, view, proj, campos, acc):
+        """Enqueue every hypothesis (self.batch per launch set); acc[k] += the mismatch of hypothesis k."""
         import ctypes
-        import numpy as np
         from . import _C
         from .multiview import render_stacked
         from .rasterizer3d import _stream
+        L = _C.lib()
+        n = self.t_alpha.numel()
+        p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 4 * off)
+        nh, V = view.shape[0], self.stack.V
+        k = 0
+        while k < nh:
+            h = min(self.batch, nh - k)
+            st = self._stack_of(h)
+            out = render_stacked(self.model, st, self.bg, view[k:k + h].reshape(h * V, 4, 4), proj[k:k + h].reshape(h * V, 4, 4),
+                                 campos[k:k + h].reshape(h * V, 3))
+            d, a = out["render_depth_raw"], out["render_alpha"]
+            for j in range(h):      # hypothesis k + j: rows [j V H, (j + 1) V H) of the stacked image
+                _C.check(L.scorp_gs3d_pose_score_accumulate(p(d, j * n), p(a, j * n), p(self.t_depth), p(self.t_alpha), n, 1.0 / n,
+                                                            ctypes.c_void_p(acc[k + j:k + j + 1].data_ptr()), _stream()),
+                         "scorp_gs3d_pose_score_accumulate")
+            k += h
+
+    def score(self, rotations, ids):
+        import numpy as np
         if len(ids) == 0:
             return []
-        L = _C.lib()
         R = torch.as_tensor(np.asarray([rotations[i] for i in ids]), dtype=torch.float32).to(self.dev)     # [n,3,3]
         d = self.centre - self.centre @ R.transpose(-1, -2)                                                     # c - R c
         view, proj, campos = self.stack.moved(R, d)
         acc = torch.zeros(len(ids), dtype=torch.float32, device=self.dev)
-        n = self.t_alpha.numel()
-        p = lambda t: ctypes.c_void_p(t.data_ptr())
         prev, prev_reserve = PairPolicy.mode, PairPolicy.reserve
-        PairPolicy.mode, PairPolicy.reserve = "reserve", max(prev_reserve, self.reserve)
+        PairPolicy.mode, PairPolicy.reserve = "reserve", max(prev_reserve, self.batch * self.reserve)
         try:
-            for k in range(len(ids)):
-                out = render_stacked(self.model, self.stack, self.bg, view[k], proj[k], campos[k])
-                _C.check(L.scorp_gs3d_pose_score_accumulate(p(out["render_depth_raw"]), p(out["render_alpha"]), p(self.t_depth),
-                                                            p(self.t_alpha), n, 1.0 / n, ctypes.c_void_p(acc[k:k + 1].data_ptr()),
-                                                            _stream()), "scorp_gs3d_pose_score_accumulate")
+            self._score_all(view, proj, campos, acc)
             try:
-                PairPolicy.drain()       # the sweep's one synchronisation: every view's overflow word
+                PairPolicy.drain()       # the sweep's one synchronisation: every launch set's overflow word
             except RuntimeError:
                 # the reservation was too small for some hypothesis (drain has grown it): score again
                 log.warning("StackedSweep: pair reservation grown during the sweep; scoring the hypotheses again")
                 acc.zero_()
-                for k in range(len(ids)):
-                    out = render_stacked(self.model, self.stack, self.bg, view[k], proj[k], campos[k])
-                    _C.check(L.scorp_gs3d_pose_score_accumulate(p(out["render_depth_raw"]), p(out["render_alpha"]), p(self.t_depth),
-                                                                p(self.t_alpha), n, 1.0 / n, ctypes.c_void_p(acc[k:k + 1].data_ptr()),
-                                                                _stream()), "scorp_gs3d_pose_score_accumulate")
-                self.reserve = max(self.reserve, PairPolicy.drain() * 2)
+                self._score_all(view, proj, campos, acc)
+                self.reserve = max(self.reserve, PairPolicy.drain() * 2 // self.batch)
         finally:
             PairPolicy.mode, PairPolicy.reserve = prev, prev_reserve
         return [(-acc[k]).reshape(1) for k in range(len(ids))]

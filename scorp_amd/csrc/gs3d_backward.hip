@@ -50,7 +50,19 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr int kXStride = 68;                 // dwords per slot row of the wave-private matrices: rows stay 16-byte
+// Timing probes only (scripts/dev/lds_conflicts.py; profiles/r06_3d_backward_bank_conflicts.txt): SCORP_BWD_XSTRIDE=72 with
+// SCORP_BWD_KOFF=4 is the conflict-free A-operand read of the 2-D kernel (its K mapping does not match this kernel's B operand:
+// WRONG gradients, same instructions and LDS traffic), SCORP_BWD_LDS_PAD pads the other arm to the same LDS footprint.
+#ifndef SCORP_BWD_XSTRIDE
+#define SCORP_BWD_XSTRIDE 68
+#endif
+#ifndef SCORP_BWD_KOFF
+#define SCORP_BWD_KOFF 16
+#endif
+#ifndef SCORP_BWD_LDS_PAD
+#define SCORP_BWD_LDS_PAD 0
+#endif
+constexpr int kXStride = SCORP_BWD_XSTRIDE;  // dwords per slot row of the wave-private matrices: rows stay 16-byte
                                              // aligned for the A-operand's ds_read_b128; row writes are conflict-free
 constexpr int kGroup = 16;                   // splats per MFMA group
 #ifndef SCORP_BWD_DSTRIDE
@@ -135,8 +147,13 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
   float *dbuf = reinterpret_cast<float *>(xm);   // the 2 x 16 x 14 result tile reuses the matrix once the MFMAs have consumed it
   float *xs = reinterpret_cast<float *>(xm);     // prologue scratch: 64 x 4 floats
   static_assert(2 * kGroup * kDStride <= 13 * kXStride && 64 * 4 <= 13 * kXStride, "scratch fits below the zero fragments");
-  static_assert(sizeof(uint4) * 3 * kChunk + sizeof(float4) * 2 * kChunk + sizeof(float2) * kChunk + 4 * kChunk + 4 * 16 * kXStride == 10240,
+  static_assert(kXStride != 68 || SCORP_BWD_LDS_PAD != 0 ||
+                sizeof(uint4) * 3 * kChunk + sizeof(float4) * 2 * kChunk + sizeof(float2) * kChunk + 4 * kChunk + 4 * 16 * kXStride == 10240,
                 "10 KiB of LDS per wave: four waves per SIMD fill the CU's 160 KiB exactly");
+#if SCORP_BWD_LDS_PAD
+  __shared__ uint32_t lds_pad[SCORP_BWD_LDS_PAD];
+  if (W < 0) lds_pad[threadIdx.x] = 1u;   // (never taken: keeps the padding allocated)
+#endif
   const int lane = threadIdx.x;
   const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
   const int tile = (kk >> 2) * 8 + xcd, quad = kk & 3;
@@ -238,7 +255,8 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
     dpix0 *= sq; dpix1 *= sq; dpix2 *= sq; ddep *= sq; dalp *= sq;
   }
   float T = kExact ? T_final : kWScale * T_final, R = 0.0f, s_last = 0.0f, last_alpha = 0.0f;
-  const int abase = (lane & 15) * kXStride + 16 * (lane >> 4);
+  const int abase = (lane & 15) * kXStride + SCORP_BWD_KOFF * (lane >> 4);
+  constexpr int kAStep = SCORP_BWD_KOFF == 16 ? 4 : 16;   // dwords between the lane's four 16-byte reads
   float park_v[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // a group's sums, parked until flush_sums
   uint32_t park_o[4] = {det ? 0xFFFFFFFFu : 0u, det ? 0xFFFFFFFFu : 0u, det ? 0xFFFFFFFFu : 0u, det ? 0xFFFFFFFFu : 0u};
                                                 // ... and their float offsets in acc (N * 16 < 2^32, checked at the entry
@@ -346,7 +364,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
         if constexpr (kExact) {
           float4 av[4];
 #pragma unroll
-          for (int t4 = 0; t4 < 4; t4++) av[t4] = *reinterpret_cast<const float4 *>(&xm[abase + 4 * t4]);
+          for (int t4 = 0; t4 < 4; t4++) av[t4] = *reinterpret_cast<const float4 *>(&xm[abase + kAStep * t4]);
 #ifdef SCORP_BWD_PROBE_HALF_MFMA
           if (h == 0)     // diagnostic build (wrong gradients): what halving the fp32 matrix work would buy
 #endif
@@ -360,7 +378,7 @@ blend_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32
         } else {
           Frag af[4];
 #pragma unroll
-          for (int m = 0; m < 4; m++) af[m].q = *reinterpret_cast<const uint4 *>(&xm[abase + 4 * m]);
+          for (int m = 0; m < 4; m++) af[m].q = *reinterpret_cast<const uint4 *>(&xm[abase + kAStep * m]);
 #pragma unroll
           for (int m = 0; m < 4; m++) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m].v, bh[m].v, d, 0, 0, 0);
         }

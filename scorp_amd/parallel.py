@@ -123,6 +123,77 @@ def sweep(n_units, score_fn, device="cpu"):
     return ids, scores, best
 
 
+class GradArena:
+    """The gradients of a model's leaves as views of ONE persistent flat buffer, widest leaf first (round 6).
+
+    `average_gradients` packs the leaves' .grad into 64 MiB buckets (torch.cat: a pass over 248 MB at 1 M Gaussians),
+    all-reduces each bucket while the host waits, and copies the result back (a third pass).  With the arena the one-call view
+    (train_view(grad_out=arena.views)) writes its gradients where the collective reads them and the averaged values are read by
+    the optimizer where the collective left them: no packing, no copy-back, no allocation per iteration.  The buffer is
+    exchanged as TWO collectives issued back to back without a host wait in between - `_features_rest` (180 of the 248
+    bytes per Gaussian) and everything else - so that the second one's launch and the first one's wire time overlap; the
+    wait happens once, behind both.  On RCCL each part is a reduce-scatter + all-gather pair (every rank reduces 1 / G of
+    the floats, all seven xGMI links of a GPU carry payload both ways); on gloo (the CPU tests) an all-reduce.
+    `views[k]` is None for a leaf that does not require a gradient."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        live = [p for p in self.params if p.requires_grad]
+        dev, dt = live[0].device, live[0].dtype
+        order = sorted(range(len(live)), key=lambda i: -live[i].numel())      # the widest leaf (features_rest) first
+        _, w = world()
+        pad = lambda n: -(-n // (4 * max(w, 1))) * (4 * max(w, 1))            # every part divisible by the world size, 16-byte pieces
+        sizes = [pad(live[i].numel()) for i in order]
+        self.flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
+        self.key = tuple((p.shape, p.requires_grad) for p in self.params)
+        offs, off = {}, 0
+        for i, sz in zip(order, sizes):
+            offs[id(live[i])] = off
+            off += sz
+        self.views = [self.flat[offs[id(p)]:offs[id(p)] + p.numel()].view_as(p) if p.requires_grad else None for p in self.params]
+        head = sizes[0]
+        self.parts = [self.flat[:head], self.flat[head:]] if len(sizes) > 1 else [self.flat]
+
+    def matches(self, params):
+        return tuple((p.shape, p.requires_grad) for p in params) == self.key and all(
+            v is None or v.device == p.device for v, p in zip(self.views, params))
+
+    def attach(self):
+        """Point every leaf's .grad at its view (for gradients that were produced elsewhere: they are copied in)."""
+        for p, v in zip(self.params, self.views):
+            if v is None:
+                continue
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+    def average(self):
+        """In place: every float of the arena becomes its mean over the ranks."""
+        _, w = world()
+        if not collective():
+            return
+        works = []
+        nccl = dist.get_backend() == "nccl"
+        for part in self.parts:
+            if part.numel() == 0:
+                continue
+            if nccl:
+                shard = torch.empty(part.numel() // w, dtype=part.dtype, device=part.device)
+                dist.reduce_scatter_tensor(shard, part, op=dist.ReduceOp.SUM)
+                shard /= w
+                works.append(dist.all_gather_into_tensor(part, shard, async_op=True))
+            else:
+                works.append((dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True), part))
+        for wk in works:
+            if isinstance(wk, tuple):
+                wk[0].wait()
+                wk[1].div_(w)
+            else:
+                wk.wait()
+
+
 def average_gradients(params, bucket_bytes=64 << 20):
     """Data-parallel training of ONE scene: every rank renders a different view, then the
     per-Gaussian gradients are averaged before the optimizer step.  Gradients are packed into a few large flat

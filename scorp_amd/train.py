@@ -105,6 +105,11 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
         step_in_view = fused_step and not data_parallel and not will_densify and not will_reset and \
             hasattr(gaussians.optimizer, "fused_view_pack")
         kw_view = {}
+        if data_parallel and not sparse_gradients and not step_in_view:
+            # the view writes its gradients straight into the flat arena the collective reduces in place (parallel.GradArena)
+            arena = _grad_arena(gaussians)
+            if arena is not None:
+                kw_view["grad_out"] = arena.views
         if step_in_view:
             kw_view["optimizer"] = gaussians.optimizer
             if densify and iteration < opt.densify_until_iter and getattr(type(gaussians), "_stats_norm_components", None) == 2:
@@ -144,8 +149,13 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
             # flows through the rasterizer: the isotropic regulariser gives EVERY Gaussian a scaling gradient, a
             # caller-supplied render / loss function may do anything, and then the dense average is the right one.
             rasterizer_only = not extra_terms and loss_fn is fused_l1_ssim_loss and (render_fn is render or surfels)
+            arena = getattr(gaussians, "_grad_arena_obj", None)
             if sparse_gradients and rasterizer_only:
                 average_gradients_sparse(ps, pkg["radii"] > 0)    # (the view's own visibility: not masked by an overflow)
+            elif arena is not None and fused_view and all(p.grad is None or (v is not None and p.grad.data_ptr() == v.data_ptr())
+                                                          for p, v in zip(arena.params, arena.views)):
+                arena.attach()        # (a leaf nothing was written for: zeros)
+                arena.average()       # in place, two collectives back to back, one wait
             else:
                 average_gradients(ps)
         if densify and iteration < opt.densify_until_iter:
@@ -168,6 +178,19 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
             gaussians.optimizer.step()
         gaussians.optimizer.zero_grad(set_to_none=True)
     return loss, pkg
+
+
+def _grad_arena(gaussians):
+    """The model's persistent gradient arena (leaves in the one-call view's order), rebuilt when the model was resized."""
+    from .parallel import GradArena
+    if not hasattr(gaussians, "raw_leaves"):
+        return None
+    leaves = [gaussians.get_xyz] + list(gaussians.raw_leaves())
+    arena = getattr(gaussians, "_grad_arena_obj", None)
+    if arena is None or not arena.matches(leaves) or any(a is not b for a, b in zip(arena.params, leaves)):
+        arena = GradArena(leaves)
+        gaussians._grad_arena_obj = arena
+    return arena
 
 
 def _default_view_fn():

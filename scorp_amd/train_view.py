@@ -30,7 +30,7 @@ def _accumulate(p, g):
 
 
 def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2, mask=None, scaling_modifier=1.0,
-               optimizer=None, stats=None):
+               optimizer=None, stats=None, grad_out=None):
     """Returns the dict of `renderer.render` plus "loss", "l1", "ssim" (0-d views of one device tensor); parameter
     gradients are accumulated into `pc`'s leaves.  Needs the model's raw leaves (fused activations).
 
@@ -41,7 +41,11 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     the view overflowed its pair reservation (counted in optimizer.take_skipped()).  `stats` = (max_radii2D,
     xyz_gradient_accum, denom): the view's share of the densification statistics (GaussianModel.accumulate_view_stats) by
     the same kernel; then "viewspace_points".grad is None.  If the step cannot be fused (pending gradients, a leaf the
-    optimizer does not hold) the view runs as without `optimizer` and says "optimizer_stepped": False."""
+    optimizer does not hold) the view runs as without `optimizer` and says "optimizer_stepped": False.
+
+    `grad_out` (six tensors or None entries, the leaves' order xyz, features_dc, features_rest, opacity, scaling, rotation; e.g.
+    parallel.GradArena.views): the gradients are WRITTEN there (not accumulated) and become the leaves' .grad - the
+    data-parallel loop's collective then reads them where the kernel left them."""
     L = _C.lib()
     xyz = pc.get_xyz
     if not xyz.is_cuda:
@@ -89,6 +93,11 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
         stats = st
     fused_step = pack is not None
     g = [torch.empty_like(x) if (n and not fused_step) else None for x, n in zip(t, need)]
+    if grad_out is not None and not fused_step:
+        for k, (x, n, go) in enumerate(zip(t, need, grad_out)):
+            if n and go is not None:
+                assert go.shape == x.shape and go.dtype == torch.float32 and go.is_contiguous() and go.device == x.device
+                g[k] = go
     # the screen-space gradient feeds the densification statistics: not produced when the positions are frozen
     # (renderer.render does the same), which leaves the backward with colour gradients only -> its colour-only path
     g_means2D = new((N, 3)) if (xyz.requires_grad and not (fused_step and stats is not None)) else None
@@ -112,9 +121,12 @@ def train_view(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2,
     _C.check(L.scorp_gs3d_train_view(ctypes.byref(v), _stream()), "scorp_gs3d_train_view")
     PairPolicy.pend(state, N, H, W, header=header)    # queued for drain(): no copy launch, the state blob is not pinned
     if not fused_step:
-        for p, gp in zip(leaves, g):
+        for k, (p, gp) in enumerate(zip(leaves, g)):
             if p.requires_grad:
-                _accumulate(p, gp.view_as(p))
+                if grad_out is not None and grad_out[k] is not None:
+                    p.grad = gp.view_as(p)      # written in place of whatever was there: the arena is the gradient
+                else:
+                    _accumulate(p, gp.view_as(p))
     return {"optimizer_stepped": fused_step, "stats_accumulated": fused_step and stats is not None, "render": color, "viewspace_points": _ViewspaceGrad(g_means2D), "visibility_filter": visible.view(torch.bool),
             "radii": radii, "render_depth": depth, "render_alpha": alpha, "loss": loss3[0], "l1": loss3[1], "ssim": loss3[2],
             # != 0 if this view needed more pairs than were reserved (its images and gradients then come from truncated

@@ -60,6 +60,18 @@ def main():
             assert moved == int(vis.sum())
         assert all(torch.equal(p.grad, w) for p, w in zip(params, want)), mode
 
+    # --- the gradient arena: reduce_scatter_tensor + all_gather_into_tensor on the two parts of one flat buffer, in place ---
+    params = [torch.nn.Parameter(R(*s_)) for s_ in shapes]
+    arena = P.GradArena(params)
+    want = []
+    for p_, v_ in zip(params, arena.views):
+        v_.copy_(R(*p_.shape))
+        p_.grad = v_
+        want.append(v_.clone())
+    arena.attach()
+    arena.average()
+    assert all(torch.equal(p_.grad, w_) and p_.grad.data_ptr() == v_.data_ptr() for p_, w_, v_ in zip(params, want, arena.views))
+
     # --- one scene trained data-parallel on the group of one == the same loop without a group's help ---
     from scorp_amd.gaussian_model import GaussianModel, OptimizationParams
     from scorp_amd.rasterizer3d import PairPolicy, backward_precision

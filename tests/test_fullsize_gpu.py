@@ -293,8 +293,15 @@ def test_config3_full_size_rotation_sweep(dev):
         targets = render_views(tgt, cams, bg)
         plan = SweepPlan(obj, cams, targets, bg)                       # SH-0 object: cameras moved, the 15 views stacked
         assert plan.stacked is not None, "the sweep did not take the stacked-views form"
+        assert plan.stacked.batch == 2, "two hypotheses per launch set (30 x 800x800 stays on the two-level binning)"
         ids, fit, best = rotation_sweep(obj, rots, cams, targets, bg, plan=plan)
         assert ids.numel() == 128 and best == planted
+        # ... and one hypothesis per launch set (round 5's form), on an odd number of them: the batching changes no score
+        # beyond the order of the score kernel's float atomics
+        from scorp_amd.align import StackedSweep
+        single = StackedSweep(obj, cams, targets, bg, batch=1)
+        f1 = torch.stack(single.score(rots, list(range(37))))
+        assert float((f1 - fit[:37]).abs().max()) < 2e-6
         assert float(fit[planted, 0]) > -1e-5 and float(fit[:, 0].sort().values[-2]) < float(fit[planted, 0]) - 1e-4
         graph_plan = SweepPlan(obj, cams, targets, bg, use_graph=True, stacked=False)    # object rotated, captured plan
         assert graph_plan.graph is not None, "the sweep's plan was not captured"

@@ -259,11 +259,16 @@ class _Sink:
 def _overflowing_view(rank, calls):
     """A stand-in for train_view.train_view on CPU: the gradients of _fake_render / _plain_loss land in the leaves' .grad, and
     the view says it overflowed its pair reservation on RANK 0's FIRST call only."""
-    def view(cam, pc, pipe, bg, gt, lambda_dssim, **kw):
+    def view(cam, pc, pipe, bg, gt, lambda_dssim, grad_out=None, **kw):
         assert not kw, "the step inside the view is not for data-parallel replicas"
         pkg = _fake_render(cam, pc, pipe, bg)
         loss = _plain_loss(pkg["render"], gt, lambda_dssim)
         loss.backward()
+        assert grad_out is not None, "the data-parallel loop hands the one-call view its gradient arena"
+        for p, v in zip([pc.get_xyz] + list(pc.raw_leaves()), grad_out):    # as train_view: written in place, .grad = the view
+            if v is not None:
+                v.copy_(p.grad)
+                p.grad = v
         calls.append(cam.k)
         over = 1 if (rank == 0 and len(calls) == 1) else 0
         return {"loss": loss.detach(), "overflow": torch.tensor([over], dtype=torch.int32), "radii": pkg["radii"],
@@ -486,6 +491,62 @@ def _sparse_worker(rank, world_size, port, q):
         q.put((rank, repr(e) + traceback.format_exc()))
     finally:
         dist.destroy_process_group()
+
+
+def _arena_worker(rank, world_size, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from scorp_amd.parallel import GradArena, average_gradients
+        g = torch.Generator().manual_seed(7 + rank)
+        shapes = [(37, 3), (37, 1, 3), (37, 15, 3), (37, 1), (37, 3), (37, 4)]
+        params = [torch.nn.Parameter(torch.zeros(*s_)) for s_ in shapes]
+        params[3].requires_grad_(False)                       # a frozen leaf: no view, no traffic
+        grads = [torch.randn(*s_, generator=g) for s_ in shapes]
+        ref = [torch.nn.Parameter(torch.zeros(*s_)) for s_ in shapes]
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        ref[3].requires_grad_(False)
+        average_gradients(ref, bucket_bytes=1 << 10)
+        arena = GradArena(params)
+        assert arena.views[3] is None and arena.views[2].data_ptr() == arena.flat.data_ptr()     # features_rest leads the buffer
+        for k, (p, gr) in enumerate(zip(params, grads)):
+            if k in (0, 1, 2):
+                arena.views[k].copy_(gr)
+                p.grad = arena.views[k]                       # written in place by the view
+            elif k == 4:
+                p.grad = gr.clone()                           # produced elsewhere: attach() copies it in
+            elif k == 5:
+                p.grad = None                                 # nothing produced on this rank: zeros
+        arena.attach()
+        arena.average()
+        for k in (0, 1, 2, 4):
+            assert torch.allclose(params[k].grad, ref[k].grad, rtol=0, atol=1e-7), k
+            assert params[k].grad.data_ptr() == arena.views[k].data_ptr()
+        other = [torch.zeros_like(arena.flat) for _ in range(world_size)]
+        dist.all_gather(other, arena.flat)
+        assert torch.equal(other[0], other[1])
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_arena_average_equals_the_bucketed_average_on_two_gloo_ranks():
+    """parallel.GradArena: the leaves' gradients as views of one flat buffer, averaged in place by two collectives - same
+    values as average_gradients' pack / all-reduce / copy-back, a frozen leaf left out, a leaf without a gradient as zeros."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_arena_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
 
 
 def test_sparse_gradient_average_equals_dense_on_two_gloo_ranks():
