@@ -135,6 +135,16 @@ int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *pairs, uint6
  *     renders, evaluation views).  Same arguments, same outputs bit for bit. */
 int scorp_gs3d_render_image(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, float *out_color,
                             float *out_depth, float *out_alpha, scorp_stream_t stream);
+/* 3''. render-and-compare in one: step 3 for a caller that only wants to know how far the render is from a target (the
+ *      rotation sweep's scoring, align_3dgs_clpe_9dof.py:80-111 / :336-368, as scorp_gs3d_pose_score_accumulate defines it).
+ *      No image is written and no colour accumulated; the image's rows are cut into bands of rows_per_score rows (a
+ *      multiple of 16 dividing the image height - with num_views = V stacked views: V * image_height, or a multiple of it
+ *      when several hypotheses share the launch), every band is compared with the SAME target tgt_depth / tgt_alpha
+ *      [rows_per_score, W] (tgt_depth normalised, as scorp_gs3d_render_tail writes it), and
+ *        acc[j] += scale * sum over band j of |alpha - tgt_alpha| + |nan_to_num(depth / alpha, 0, 0) - tgt_depth|.
+ *      The per-block partial sums are added in a fixed order: two runs give the same bits. */
+int scorp_gs3d_render_score(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity, const float *tgt_depth,
+                            const float *tgt_alpha, int32_t rows_per_score, float scale, float *acc, scorp_stream_t stream);
 /* Synchronises; returns SCORP_ERR_OVERFLOW if the last render on this state needed more than `capacity` pairs
  * (and the needed count in *num_pairs), SCORP_OK otherwise. */
 int scorp_gs3d_check_overflow(const void *state, scorp_stream_t stream, uint64_t *num_pairs);

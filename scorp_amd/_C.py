@@ -74,7 +74,7 @@ class ScorpAdamTensor(ctypes.Structure):
 EXPORTS = [
     "scorp_version", "scorp_source_sha", "scorp_last_error", "scorp_gs3d_state_bytes", "scorp_gs3d_pairs_bytes",
     "scorp_gs3d_backward_scratch_bytes", "scorp_gs3d_backward_scratch_bytes_ex", "scorp_gs3d_preprocess", "scorp_gs3d_num_pairs", "scorp_gs3d_render",
-    "scorp_gs3d_render_image",
+    "scorp_gs3d_render_image", "scorp_gs3d_render_score",
     "scorp_gs3d_check_overflow", "scorp_gs3d_backward", "scorp_gs3d_backward_ex", "scorp_gs3d_debug_geom", "scorp_gs3d_debug_tiles", "scorp_gs3d_debug_work",
     "scorp_loss_workspace_bytes", "scorp_loss_l1_ssim_forward", "scorp_loss_l1_ssim_backward",
     "scorp_knn_dist2", "scorp_gaussians_transform", "scorp_adam_step", "scorp_adam_step_guarded", "scorp_adam_step_guarded_ex", "scorp_densification_stats", "scorp_densification_stats_ex", "scorp_gather_rows", "scorp_gs3d_render_tail", "scorp_gs3d_render_tail_backward",
@@ -122,6 +122,7 @@ def lib():
     L.scorp_gs3d_num_pairs.argtypes = [vp, vp, ctypes.POINTER(u64)]
     L.scorp_gs3d_render.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp, vp]
     L.scorp_gs3d_render_image.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp, vp]
+    L.scorp_gs3d_render_score.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, i32, ctypes.c_float, vp, vp]
     L.scorp_gs3d_check_overflow.argtypes = [vp, vp, ctypes.POINTER(u64)]
     L.scorp_gs3d_backward.argtypes = [ctypes.POINTER(ScorpGs3dInputs), vp, vp, u64, vp, vp, vp,
                                       ctypes.POINTER(ScorpGs3dGrads), vp, sz, vp]

@@ -91,7 +91,9 @@ class StackedSweep:
     built (scripts/dev/time_sweep_batch.py, S4: 100 k Gaussians, 15 x 800x800): 567 us per hypothesis alone, 504 in pairs,
     577 in fours (beyond 8 192 cells the stacked image leaves the two-level binning) - the binning kernels gain 15 - 25 %
     from the doubled launch, the blend, which is 300 of the 567 us and bound by its own arithmetic, 4 %.  The sweep is not a
-    chain of latency-bound launches any more; it costs what its 5.9 M (tile, splat) pairs per hypothesis cost."""
+    chain of latency-bound launches any more; it costs what its 5.9 M (tile, splat) pairs per hypothesis cost.  With the
+    scoring form of the blend (scorp_gs3d_render_score: no colour, no images, no score launch) a whole sweep of 128 runs at
+    1 830 / 1 965 / 2 001 hypotheses per second for batch = 1 / 2 / 3 (scripts/dev/prof_sweep.py; round 5: 1 580)."""
 
     def __init__(self, model, cameras, targets, bg, batch=None):
         from .multiview import ViewStack
@@ -103,9 +105,9 @@ class StackedSweep:
         self.t_alpha = torch.cat([t["render_alpha"].reshape(self.stack.H, self.stack.W) for t in targets]).contiguous()
         self.centre = model._xyz.detach().mean(0)
         # hypotheses per launch set: as many as keep the stacked image on the two-level binning (common.hpp: kMaxCells = 8192
-        # cells of 64 x 64 pixels), at most two - four were measured slower than two
+        # cells of 64 x 64 pixels), at most three (three were 2 % faster than two; four leave the two-level binning at 800x800)
         cells = -(-self.stack.W // 64) * -(-(self.stack.V * self.stack.H) // 64)
-        self.batch = max(1, min(2, 8192 // max(cells, 1))) if batch is None else max(1, int(batch))
+        self.batch = max(1, min(3, 8192 // max(cells, 1))) if batch is None else max(1, int(batch))
         self._stacks = {1: self.stack}
         # sizing pass (setup): the exact pair count of the unrotated object; the sweep reserves twice that per hypothesis
         from .multiview import render_stacked
@@ -128,25 +130,17 @@ class StackedSweep:
 
     def _score_all(self, view, proj, campos, acc):
         """Enqueue every hypothesis (self.batch per launch set); acc[k] += the mismatch of hypothesis k."""
-        import ctypes
-        from . import _C
-        from .multiview import render_stacked
-        from .rasterizer3d import _stream
-        L = _C.lib()
+        # One launch set per `batch` hypotheses, ending in the SCORING form of the blend (scorp_gs3d_render_score, round 6):
+        # the comparison with the target happens where depth and alpha are formed - no image leaves the kernel, no colour is
+        # accumulated for a score that does not look at it, and the score launch (it read 150 MB per hypothesis) is gone.
+        from .multiview import score_stacked
         n = self.t_alpha.numel()
-        p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 4 * off)
         nh, V = view.shape[0], self.stack.V
         k = 0
         while k < nh:
             h = min(self.batch, nh - k)
-            st = self._stack_of(h)
-            out = render_stacked(self.model, st, self.bg, view[k:k + h].reshape(h * V, 4, 4), proj[k:k + h].reshape(h * V, 4, 4),
-                                 campos[k:k + h].reshape(h * V, 3))
-            d, a = out["render_depth_raw"], out["render_alpha"]
-            for j in range(h):      # hypothesis k + j: rows [j V H, (j + 1) V H) of the stacked image
-                _C.check(L.scorp_gs3d_pose_score_accumulate(p(d, j * n), p(a, j * n), p(self.t_depth), p(self.t_alpha), n, 1.0 / n,
-                                                            ctypes.c_void_p(acc[k + j:k + j + 1].data_ptr()), _stream()),
-                         "scorp_gs3d_pose_score_accumulate")
+            score_stacked(self.model, self._stack_of(h), self.bg, view[k:k + h].reshape(h * V, 4, 4), proj[k:k + h].reshape(h * V, 4, 4),
+                          campos[k:k + h].reshape(h * V, 3), self.t_depth, self.t_alpha, acc[k:k + h], V * self.stack.H, 1.0 / n)
             k += h
 
     def score(self, rotations, ids):
@@ -296,12 +290,23 @@ class SweepPlan:
         return out
 
 
-def _raise_together(failed_rows, err, what):
-    """A rank whose local part failed sends NaN rows into the exchange it would otherwise have skipped: the all-gather is
-    entered by everyone (nobody waits for a rank that never arrives), the success path has no extra collective and no
-    extra host synchronisation, and the NaNs - checked where the result is read anyway - raise on EVERY rank."""
-    if err is not None or bool(failed_rows):
+def _raise_together(any_failed, err, what):
+    """A rank whose local part failed still enters the exchange it would otherwise have skipped (nobody waits for a rank that
+    never arrives) and says so in the status row every rank sends through the same all-gather (parallel.gather_results,
+    `failed=`): no extra collective and no extra host synchronisation on the success path; the flag - read where the result
+    is read anyway - raises on EVERY rank.  (Round 5 marked a failure by NaN rows: a legitimately NaN score raised "another
+    rank failed", and a failing rank with an empty shard had no row to put the NaN in.)"""
+    if err is not None or bool(any_failed):
         raise RuntimeError(f"{what}: the local part failed on " + ("this rank" if err is not None else "another rank")) from err
+
+
+def _to_device_or_reraise(rows, dev, err):
+    """The (zero) rows a failed rank sends, built on the host: if even the copy to the device fails - the local error was a device
+    fault - the original error is raised instead of a second one (the peers then see the collective's timeout)."""
+    try:
+        return rows.to(dev)
+    except Exception:   # noqa: BLE001
+        raise err
 
 
 def align_objects(models, rotations, cameras, targets_per_object, bg, render_fn=render):
@@ -318,11 +323,15 @@ def align_objects(models, rotations, cameras, targets_per_object, bg, render_fn=
             _, fit, best = rotation_sweep(models[j], rotations, cameras, targets_per_object[j], bg, render_fn=render_fn, shard=False)
             rows.append(torch.stack([torch.tensor(float(best), device=fit.device), fit[best, 0].float()]))
     except Exception as e:   # noqa: BLE001   (raised below, on every rank, behind the exchange)
-        err, rows = e, [torch.full((2,), float("nan"), device=dev) for _ in mine]
-    v = torch.stack(rows) if rows else torch.zeros((0, 2), dtype=torch.float32, device=dev)
-    _, vals = gather_results(mine, v.to(dev), n_total=len(models))
-    vals = vals.cpu()                   # the one synchronisation of the call: the results are read here
-    _raise_together(torch.isnan(vals).any(), err, "align_objects")
+        err, rows = e, None
+    if err is not None:
+        v = _to_device_or_reraise(torch.zeros((len(mine), 2), dtype=torch.float32), dev, err)
+    else:
+        v = torch.stack(rows).to(dev) if rows else torch.zeros((0, 2), dtype=torch.float32, device=dev)
+    _, vals, bad = gather_results(mine, v, n_total=len(models), failed=err is not None)
+    vals = torch.cat([vals.reshape(-1), bad.reshape(1).to(vals.dtype)]).cpu()     # the one synchronisation of the call
+    _raise_together(float(vals[-1]) != 0.0, err, "align_objects")
+    vals = vals[:-1].view(len(models), 2)
     return [(int(vals[j, 0]), float(vals[j, 1])) for j in range(len(models))]
 
 
@@ -345,14 +354,18 @@ def rotation_sweep(model, rotations, cameras, targets, bg, use_graph=None, plan=
             plan = SweepPlan(model, cameras, targets, bg, use_graph=use_graph, render_fn=render_fn)
         vals = plan.score(rotations, mine) if mine else []
     except Exception as e:   # noqa: BLE001   (raised below, on every rank, behind the exchange)
-        err, vals = e, [torch.full((1,), float("nan"), device=dev) for _ in mine]
-    v = torch.stack(vals) if vals else torch.zeros((0, 1), dtype=torch.float32, device=dev)
-    ids, scores = gather_results(mine, v.to(dev), n_total=len(rotations))      # ONE fixed-size all-gather, no host sync
+        err, vals = e, None
+    if err is not None:
+        v = _to_device_or_reraise(torch.zeros((len(mine), 1), dtype=torch.float32), dev, err)
+    else:
+        v = torch.stack(vals).to(dev) if vals else torch.zeros((0, 1), dtype=torch.float32, device=dev)
+    # ONE fixed-size all-gather, no host sync; every rank's status row rides in it
+    ids, scores, any_failed = gather_results(mine, v, n_total=len(rotations), failed=err is not None)
     if not ids.numel():
-        _raise_together(False, err, "rotation_sweep")
+        _raise_together(float(any_failed) != 0.0, err, "rotation_sweep")
         return ids, scores, -1
-    # (a failed rank's rows are NaN: one reduction tells, in the same device-to-host read that fetches the arg-max)
+    # (the flag comes back in the same device-to-host read that fetches the arg-max; a NaN score is a score, not a failure)
     best, bad = (int(x) for x in torch.stack([ids[torch.argmax(torch.nan_to_num(scores[:, 0], nan=-float("inf")))].long(),
-                                              torch.isnan(scores).any().long()]).tolist())
+                                              (any_failed != 0).long().to(ids.device)]).tolist())
     _raise_together(bad, err, "rotation_sweep")
     return ids, scores, best

@@ -117,6 +117,12 @@ __device__ __forceinline__ float dpp_add(float v) {
 // Wave-wide maximum of a u32 (also of non-negative floats, through their bits), uniform result: four DPP steps inside
 // each row of 16 lanes (xor 1, xor 2, half-mirror, mirror), two row broadcasts, one v_readlane.  No LDS round trips
 // (the __shfl_xor form is six dependent ds_bpermute).
+// CALL IT WITH ALL 64 LANES ACTIVE (wave-uniform control flow only): the result is read from lane 63, and the row
+// broadcasts (row_bcast15 / row_bcast31) take their source from lanes that must have executed the steps before.  Those two
+// DPP controls exist on GFX9-family targets only - this library is built for gfx950 and nothing else (build.py: ARCH).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libscorp_gs is written for gfx950 (wave64, row_bcast DPP, 160 KiB LDS): no other target is supported"
+#endif
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   // old = 0 (the identity of an unsigned maximum) lets the compiler fold each move into v_max_u32_dpp; the rows are joined
   // by the two row broadcasts and one v_readlane (it was four v_readlane and three s_max behind unfolded v_mov_dpp pairs)
@@ -191,12 +197,27 @@ constexpr int kMaxCells = 8192;         // the scatter's prologue scans this man
 #ifndef SCORP_TWO_LEVEL_MIN_N
 #define SCORP_TWO_LEVEL_MIN_N 0
 #endif
+// Fewer cells than this: the one-level kernels.  The second level runs ONE workgroup per cell (expand_cells_kernel) and the
+// first level's LDS atomics land on `cells` counters: a 256 x 256 image has 16 cells - sixteen workgroups would move every
+// pair of a 100 k-Gaussian object while 240 CUs idle (the advisor's round-5 finding; profiles/r06_small_image_binning.txt
+// has the measurement behind the number).
+// Measured (scripts/dev/time_small_image.py, 100 k Gaussians, count + scatter [+ expand] us, two-level | one-level): 256x256
+// (16 cells) 56 | 20, 384x384 (36) 46 | 19, 512x512 (64) 39 | 20, 800x800 (169) 45 | 35; S3 (1 M Gaussians, 475 cells) 48 | 52.
+#ifndef SCORP_TWO_LEVEL_MIN_CELLS
+#define SCORP_TWO_LEVEL_MIN_CELLS 256
+#endif
 
 // SCORP_ONE_LEVEL_BINNING=1 in the environment (read once per process): every view takes the one-level binning - what images
 // beyond kMaxCells cells or 2^28 (virtual) Gaussians take anyway - so that the tests can hold that path against the oracle as well.
 inline bool one_level_binning_forced() {
   static const bool forced = [] { const char *e = getenv("SCORP_ONE_LEVEL_BINNING"); return e && e[0] == '1'; }();
   return forced;
+}
+
+// (SCORP_TWO_LEVEL_MIN_CELLS in the environment overrides the compiled-in threshold: A/B runs)
+inline int two_level_min_cells() {
+  static const int v = [] { const char *e = getenv("SCORP_TWO_LEVEL_MIN_CELLS"); return e && e[0] ? atoi(e) : SCORP_TWO_LEVEL_MIN_CELLS; }();
+  return v;
 }
 
 struct StateLayout {
@@ -244,7 +265,7 @@ struct StateLayout {
     // (stacked views too: the V x N virtual Gaussians of the stacked image are binned in ONE pass - a cell that straddles two
     // views' bands is only a bucket - instead of V passes with a tile histogram each and a one-workgroup scan of all tiles)
     two_level = lds_binning && N < (1 << kCellShift) && N >= SCORP_TWO_LEVEL_MIN_N && cells <= kMaxCells &&
-                !one_level_binning_forced();
+                cells >= two_level_min_cells() && !one_level_binning_forced();
     if (views > 1 && !two_level) {
       // (a view's blocks write only the view's segment of their histogram row, so nb is the number of blocks PER VIEW; more
       // than ~16 bought nothing at 15 views: the scatter is bound by its 8-byte pair stores, 64 blocks measured 69 vs 68 us)

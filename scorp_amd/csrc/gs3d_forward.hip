@@ -797,14 +797,23 @@ __device__ unsigned long long g_fwd_trace[3 * 40000];
 // iterations a wave would run if its hits were listed per 8x4 half / per 4x4 quadrant / per pixel instead of per block
 __device__ unsigned long long g_fwd_stats[12];
 #endif
-template <bool kForBackward>
+// kScore (scorp_gs3d_render_score; never with kForBackward): the render-and-compare scoring of a pose hypothesis
+// (align.StackedSweep) needs depth and alpha only and needs them only to be compared with a target: no colour is
+// accumulated (three of the hit loop's thirteen vector instructions), no image is written, and the epilogue forms this
+// pixel's |alpha - alpha*| + |nan_to_num(depth / alpha) - depth*| (scorp_gs3d_pose_score_accumulate's term), sums it over
+// the block and leaves ONE float per block in the state's block_hits array - plain stores, added up in a fixed order by
+// score_reduce_kernel (so the score, unlike the atomic form's, is the same bits from run to run).
+template <bool kForBackward, bool kScore = false>
 __global__ void __launch_bounds__(64, SCORP_FWD_WAVES)
 blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_t *__restrict__ point_list,
                           const SplatRec *__restrict__ rec, uint32_t capacity, int W, int H, int tiles_x, int tiles,
                           const float *__restrict__ bg, float *__restrict__ out_color, float *__restrict__ out_depth,
                           float *__restrict__ out_alpha, float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                           uint32_t *__restrict__ hits, uint32_t *__restrict__ block_hits, float *__restrict__ out_depth_norm,
-                          float4 *__restrict__ zero_buf, uint32_t zero_per_wave, uint32_t zero_total, int band_h) {
+                          float4 *__restrict__ zero_buf, uint32_t zero_per_wave, uint32_t zero_total, int band_h,
+                          const float *__restrict__ tgt_depth = nullptr, const float *__restrict__ tgt_alpha = nullptr,
+                          int score_rows = 0) {
+  static_assert(!(kForBackward && kScore), "the scoring form leaves nothing behind for a backward pass");
   __shared__ uint4 q_k[3][kFRing + 1];   // the three bf16 terms of a hit's six coefficients; slot kFRing stays zero
   __shared__ float4 q_col[kFRing];       // r, g, b, depth
   __shared__ uint32_t q_id[kFRing];      // the hit's splat: written to the block's hit list only if some pixel took it (blend_group)
@@ -944,7 +953,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
           const bool ok = test_T >= kTMin;
           const float ae = ok ? al : 0.0f;
           const float w = ae * T;
-          C0 += col.x * w; C1 += col.y * w; C2 += col.z * w;
+          if constexpr (!kScore) { C0 += col.x * w; C1 += col.y * w; C2 += col.z * w; }
           Dp += col.w * w;
           T = ok ? test_T : -fabsf(T);
           if constexpr (kForBackward) {
@@ -1078,6 +1087,18 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     }
   }
 #endif
+  if constexpr (kScore) {
+    float term = 0.0f;
+    if (inside) {
+      const float a_ = 1.0f - fabsf(T);
+      const size_t tp = (size_t)(py % score_rows) * W + px;     // (the target is ONE hypothesis' stack of views)
+      term = fabsf(a_ - tgt_alpha[tp]) + fabsf(nan_to_num00(Dp / a_) - tgt_depth[tp]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) term += __shfl_xor(term, off, 64);
+    if (lane == 0) reinterpret_cast<float *>(block_hits)[tile * 4 + quad] = term;
+    return;
+  }
   if (inside) {
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
     T = fabsf(T);
@@ -1092,6 +1113,37 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     out_alpha[pix] = 1.0f - T;   // = sum of the blend weights (sum_i alpha_i T_i telescopes to 1 - T)
     if (out_depth_norm) out_depth_norm[pix] = nan_to_num00(Dp / (1.0f - T));   // render()'s depth, as render_tail_kernel forms it
   }
+}
+
+// acc[j] += scale * (the per-block terms of band j), added in a FIXED order and without atomics, in two small launches
+// (a band of the sweep holds 150 000 terms: one workgroup walking them is a chain of 600 dependent round trips, ~100 us):
+// kScoreSlices workgroups per band each sum a contiguous slice into partial[band][slice], then one workgroup per band adds
+// its kScoreSlices partial sums.
+constexpr int kScoreSlices = 128;
+__device__ __forceinline__ float block_sum_256(float sum, float *s_part) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  return (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+__global__ void __launch_bounds__(256)
+score_slices_kernel(const float *__restrict__ block_terms, int blocks_per_score, float *__restrict__ partial) {
+  __shared__ float s_part[4];
+  const int band = blockIdx.x / kScoreSlices, slice = blockIdx.x % kScoreSlices;
+  const int per = (blocks_per_score + kScoreSlices - 1) / kScoreSlices;
+  const int i0 = slice * per, i1 = min(i0 + per, blocks_per_score);
+  const float *src = block_terms + (size_t)band * blocks_per_score;
+  float sum = 0.0f;
+  for (int i = i0 + (int)threadIdx.x; i < i1; i += 256) sum += src[i];
+  const float tot = block_sum_256(sum, s_part);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256)
+score_reduce_kernel(const float *__restrict__ partial, float scale, float *__restrict__ acc) {
+  __shared__ float s_part[4];
+  const float tot = block_sum_256(threadIdx.x < kScoreSlices ? partial[blockIdx.x * kScoreSlices + threadIdx.x] : 0.0f, s_part);
+  if (threadIdx.x == 0) acc[blockIdx.x] += scale * tot;
 }
 
 int validate(const ScorpGs3dInputs *in) {
@@ -1362,7 +1414,7 @@ int scorp::render3d_impl(const ScorpGs3dInputs *in, void *state, void *pairs, ui
         tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
         out_color, out_depth, out_alpha, (float *)(base + L.final_T), (uint32_t *)(base + L.n_contrib),
         (uint32_t *)(pb + P.hits), (uint32_t *)(base + L.block_hits), out_depth_norm, (float4 *)zero_buf,
-        (uint32_t)zero_per_wave, (uint32_t)zero_total, V > 1 ? in->image_height : 0);
+        (uint32_t)zero_per_wave, (uint32_t)zero_total, V > 1 ? in->image_height : 0, nullptr, nullptr, 0);
   }
   SCORP_KERNEL_CHECK("blend_forward", in->debug, stream);
   return SCORP_OK;
@@ -1376,6 +1428,43 @@ extern "C" int scorp_gs3d_render(const ScorpGs3dInputs *in, void *state, void *p
 extern "C" int scorp_gs3d_render_image(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
                                        float *out_color, float *out_depth, float *out_alpha, scorp_stream_t stream) {
   return render3d_impl(in, state, pairs, capacity, out_color, out_depth, out_alpha, nullptr, nullptr, 0, stream, false);
+}
+
+extern "C" int scorp_gs3d_render_score(const ScorpGs3dInputs *in, void *state, void *pairs, uint64_t capacity,
+                                       const float *tgt_depth, const float *tgt_alpha, int32_t rows_per_score, float scale,
+                                       float *acc, scorp_stream_t stream_) {
+  if (int e = validate(in)) return e;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int V = in->num_views > 1 ? in->num_views : 1;
+  const int N = V * in->num_gaussians, W = in->image_width, H = V * in->image_height;
+  if (!tgt_depth || !tgt_alpha || !acc || rows_per_score <= 0 || rows_per_score % kTile != 0 || H % rows_per_score != 0) {
+    set_error("scorp_gs3d_render_score: targets / acc NULL, or rows_per_score (%d) not a multiple of 16 dividing the %d rows", rows_per_score, H);
+    return SCORP_ERR_INVALID;
+  }
+  const StateLayout L(N, W, H, false, V);
+  const PairLayout P(capacity);
+  if (!state || ((uintptr_t)state & 255) || !pairs || ((uintptr_t)pairs & 255)) { set_error("state / pairs NULL or misaligned"); return SCORP_ERR_INVALID; }
+  if (capacity > 0xFFFFFFFFull) { set_error("capacity above 2^32-1 pairs"); return SCORP_ERR_INVALID; }
+  char *base = (char *)state, *pb = (char *)pairs;
+  if (int e = bin_scatter_and_sort(L, P, base, pb, N, (uint32_t)capacity, in->debug, stream, nullptr)) return e;
+  const uint32_t *tile_start = (const uint32_t *)(base + L.tile_start);
+  const uint32_t *point_list = (const uint32_t *)(pb + P.list);
+  {
+    ProfScope prof(kKBlendForward, stream);
+    const int blocks = ((L.tiles + 7) / 8) * 8 * 4;
+    blend_forward_wave_kernel<false, true><<<blocks, 64, 0, stream>>>(
+        tile_start, point_list, (const SplatRec *)(base + L.rec), (uint32_t)capacity, W, H, L.tiles_x, L.tiles, in->bg,
+        nullptr, nullptr, nullptr, nullptr, nullptr, (uint32_t *)(pb + P.hits), (uint32_t *)(base + L.block_hits), nullptr, nullptr,
+        0u, 0u, V > 1 ? in->image_height : 0, tgt_depth, tgt_alpha, rows_per_score);
+    // the blocks of score j are the tiles of rows [j, j + 1) * rows_per_score: contiguous tile ids, four blocks each
+    const int scores = H / rows_per_score, blocks_per_score = (rows_per_score / kTile) * L.tiles_x * 4;
+    float *partial = (float *)(base + L.final_T);   // (the per-pixel state of a backward pass: unused by this form)
+    if ((size_t)scores * kScoreSlices > (size_t)W * H) { set_error("scorp_gs3d_render_score: too many bands for the image"); return SCORP_ERR_INVALID; }
+    score_slices_kernel<<<scores * kScoreSlices, 256, 0, stream>>>((const float *)(base + L.block_hits), blocks_per_score, partial);
+    score_reduce_kernel<<<scores, 256, 0, stream>>>(partial, scale, acc);
+  }
+  SCORP_KERNEL_CHECK("blend_forward_score", in->debug, stream);
+  return SCORP_OK;
 }
 
 extern "C" int scorp_gs3d_debug_geom(const void *state, int32_t N, int32_t W, int32_t H, float *xy, float *depth,

@@ -96,3 +96,38 @@ def render_stacked(pc, stack, bg, view=None, proj=None, campos=None, scaling_mod
     if PairPolicy.mode != "exact":
         PairPolicy.pend(state, Nt, Ht, W)
     return {"render": color, "render_depth_raw": depth, "render_alpha": alpha, "radii": radii.view(V, N), "num_pairs": num_pairs}
+
+
+@torch.no_grad()
+def score_stacked(pc, stack, bg, view, proj, campos, tgt_depth, tgt_alpha, acc, rows_per_score, scale, scaling_modifier=1.0):
+    """`render_stacked` for a caller that only wants the mismatch with a target (the rotation sweep): preprocess + bin + sort
+    + the scoring form of the blend (scorp_gs3d_render_score) - no images, no colour, depth and alpha compared with
+    tgt_depth / tgt_alpha [rows_per_score, W] where they are formed.  acc[j] += scale * (mismatch of rows
+    [j, j + 1) * rows_per_score of the stacked image); `acc`: float32 device tensor with V * H / rows_per_score entries.
+    Reserve-mode sizing only (the sweep verifies its launch sets with one PairPolicy.drain())."""
+    L = _C.lib()
+    xyz = pc.get_xyz
+    dev = xyz.device
+    V, W, H, N = stack.V, stack.W, stack.H, xyz.shape[0]
+    f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw = pc.raw_leaves()
+    t = [_prep(x.detach(), n) for x, n in zip((xyz, f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw),
+                                              ("means3D", "features_dc", "features_rest", "opacity", "scaling", "rotation"))]
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=stack.tanfovx, tanfovy=stack.tanfovy, bg=bg, scale_modifier=scaling_modifier,
+        viewmatrix=view, projmatrix=proj, sh_degree=pc.active_sh_degree, campos=campos, prefiltered=False, debug=False)
+    keep = []
+    args = _inputs_struct(settings, t[0], t[1], None, t[3], t[4], t[5], None, keep, t[2], 7)
+    args.num_views = V
+    Nt, Ht = V * N, V * H
+    assert acc.dtype == torch.float32 and acc.is_contiguous() and acc.numel() * rows_per_score == Ht
+    assert tgt_depth.is_contiguous() and tgt_alpha.is_contiguous() and tgt_depth.numel() == rows_per_score * W == tgt_alpha.numel()
+    radii = torch.empty((Nt,), dtype=torch.int32, device=dev)
+    state_bytes = L.scorp_gs3d_state_bytes(Nt, W, Ht)
+    state = torch.empty((state_bytes,), dtype=torch.uint8, device=dev)
+    stream = _stream()
+    _C.check(L.scorp_gs3d_preprocess(ctypes.byref(args), _ptr(radii), _ptr(state), state_bytes, stream), "scorp_gs3d_preprocess")
+    capacity = PairPolicy.capacity(Nt, Ht, W)
+    pairs = torch.empty((L.scorp_gs3d_pairs_bytes(capacity),), dtype=torch.uint8, device=dev)
+    _C.check(L.scorp_gs3d_render_score(ctypes.byref(args), _ptr(state), _ptr(pairs), capacity, _ptr(tgt_depth), _ptr(tgt_alpha),
+                                       int(rows_per_score), float(scale), _ptr(acc), stream), "scorp_gs3d_render_score")
+    PairPolicy.pend(state, Nt, Ht, W)

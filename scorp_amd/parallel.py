@@ -68,8 +68,14 @@ def broadcast_tensors(tensors, src=0):
     return tensors
 
 
-def gather_results(ids, values, n_total=None):
+def gather_results(ids, values, n_total=None, failed=None):
     """All ranks receive every (id, value-row) pair, ordered by id.  `ids`: int64[m]; `values`: float32[m, c].
+
+    `failed` (with `n_total`; a bool, this rank's local part raised): one extra row per rank carries the flag through the SAME
+    all-gather - every rank sends it, also one whose share of the units is empty - and the call returns a third value, a
+    0-d device tensor that is non-zero if ANY rank failed (read it together with the results: no extra collective, no extra
+    host synchronisation).  A failed rank's value rows are whatever it passed (zeros): a score that is legitimately NaN is
+    not mistaken for a failure, and a failure cannot hide behind an empty shard.
 
     With `n_total` (the units were dealt by `shard_indices(n_total)`, as every caller here does) the exchange is ONE
     fixed-size all-gather and no host synchronisation: every rank's share is at most ceil(n_total / world) rows, so the
@@ -81,15 +87,20 @@ def gather_results(ids, values, n_total=None):
     ids = torch.as_tensor(ids, dtype=torch.int64, device=dev)
     if collective() and n_total is not None and n_total < (1 << 24):
         m, c = -(-int(n_total) // w), values.shape[1]
-        buf = torch.full((m, c + 1), -1.0, dtype=torch.float32, device=dev)
+        mr = m + (1 if failed is not None else 0)          # (+ the status row)
+        buf = torch.full((mr, c + 1), -1.0, dtype=torch.float32, device=dev)
         buf[: ids.numel(), 0] = ids.to(torch.float32)
         buf[: ids.numel(), 1:] = values.to(torch.float32)
-        out = torch.empty((w * m, c + 1), dtype=torch.float32, device=dev)
+        if failed is not None:
+            buf[m, 0] = 1.0 if failed else 0.0
+        out = torch.empty((w * mr, c + 1), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(out, buf)
         # rank r's row k is unit r + k * world, so unit u sits in row (u mod world) * m + u div world: the valid rows and
         # their order follow from n_total alone - index arithmetic, no boolean mask (out[mask] is a host synchronisation)
         unit = torch.arange(int(n_total), device=dev)
-        rows = out[(unit % w) * m + unit // w]
+        rows = out[(unit % w) * mr + unit // w]
+        if failed is not None:
+            return rows[:, 0].to(torch.int64), rows[:, 1:].to(values.dtype), out.view(w, mr, c + 1)[:, m, 0].amax()
         return rows[:, 0].to(torch.int64), rows[:, 1:].to(values.dtype)
     if collective():
         counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(w)]
@@ -107,6 +118,11 @@ def gather_results(ids, values, n_total=None):
         keep = ids >= 0
         ids, values = ids[keep], values[keep]
     order = torch.argsort(ids)
+    if failed is not None:      # (no group, or the ragged exchange: the flag is this rank's own / reduced apart)
+        f = torch.tensor(1.0 if failed else 0.0, device=dev)
+        if collective():
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        return ids[order], values[order], f
     return ids[order], values[order]
 
 

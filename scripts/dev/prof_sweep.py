@@ -22,12 +22,18 @@ tgt._xyz, tgt._rotation, tgt._features_rest = obj._xyz.detach().clone(), obj._ro
 gaussians_rotate(tgt, torch.tensor(rots[77], dtype=torch.float32, device=dev), fix_center=True)
 targets = render_views(tgt, cams, bg)
 plan = SweepPlan(obj, cams, targets, bg)
+if os.environ.get("SWEEP_BATCH"):
+    plan.stacked.batch = int(os.environ["SWEEP_BATCH"])
 rotation_sweep(obj, rots[:4], cams, targets, bg, plan=plan)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-ids, fit, best = rotation_sweep(obj, rots[:nh], cams, targets, bg, plan=plan)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
+dts = []
+for _ in range(3):      # (the first timed sweep still pays allocations of the full-length sweep: the last one is reported)
+    t0 = time.perf_counter()
+    ids, fit, best = rotation_sweep(obj, rots[:nh], cams, targets, bg, plan=plan)
+    torch.cuda.synchronize()
+    dts.append(time.perf_counter() - t0)
+print("sweeps (s):", [round(x, 4) for x in dts], file=sys.stderr)
+dt = dts[-1]
 _C.prof_enable(True)
 rotation_sweep(obj, rots[:16], cams, targets, bg, plan=plan)
 torch.cuda.synchronize()

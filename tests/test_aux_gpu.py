@@ -443,3 +443,46 @@ def test_view_statistics_of_the_surfel_model_norm_the_whole_row(dev):
         assert torch.equal(m.max_radii2D, ref_max) and torch.equal(m.denom, ref_den)
     torch.testing.assert_close(ours.xyz_gradient_accum, ref_acc, rtol=1e-6, atol=0)
     torch.testing.assert_close(custom.xyz_gradient_accum, ref_l1, rtol=1e-6, atol=0)
+
+
+def test_scoring_render_equals_render_then_score_and_is_bit_repeatable(dev):
+    import math
+    """scorp_gs3d_render_score (the scoring form of the blend: no colour, no images, the comparison with the target in the
+    epilogue, per-block partial sums added in a fixed order) against the stacked render followed by
+    scorp_gs3d_pose_score_accumulate: the same mismatch per hypothesis band up to float summation order, and the same BITS
+    from two runs.  Two hypotheses x three views share the launch set; every band is held against the same target."""
+    import ctypes
+    from scorp_amd import _C
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.multiview import ViewStack, render_stacked, score_stacked
+    from scorp_amd.rasterizer3d import PairPolicy, _stream
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    L = _C.lib()
+    m = GaussianModel.from_raw(make_gaussians(4000, 0, 5, log_scale_mean=math.log(0.05)), 0, device=dev)
+    cams = ring_cameras(5, 112, 80, 3, radius=3.4, device=dev)
+    bg = torch.zeros(3, device=dev)
+    PairPolicy.reset()
+    try:
+        tgt = render_stacked(m, ViewStack(cams[:3], dev), bg)                      # the target: views 0..2
+        a_t = tgt["render_alpha"]
+        d_t = torch.nan_to_num(tgt["render_depth_raw"] / a_t, 0.0, 0.0).contiguous()
+        stack6 = ViewStack([cams[0], cams[1], cams[2], cams[2], cams[3], cams[4]], dev)   # band 0 == the target, band 1 not
+        out = render_stacked(m, stack6, bg)
+        n = a_t.numel()
+        ref = torch.zeros(2, device=dev)
+        p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 4 * off)
+        for j in range(2):
+            _C.check(L.scorp_gs3d_pose_score_accumulate(p(out["render_depth_raw"], j * n), p(out["render_alpha"], j * n), p(d_t), p(a_t),
+                                                        n, 1.0 / n, ctypes.c_void_p(ref[j:j + 1].data_ptr()), _stream()), "score")
+        PairPolicy.mode = "reserve"
+        got = []
+        for _ in range(2):
+            acc = torch.zeros(2, device=dev)
+            score_stacked(m, stack6, bg, stack6.view, stack6.proj, stack6.campos, d_t, a_t.contiguous(), acc, 3 * stack6.H, 1.0 / n)
+            got.append(acc)
+        PairPolicy.drain()
+        assert torch.equal(got[0], got[1]), "two scoring renders differ"
+        assert float(ref[0]) < 1e-7 and float(ref[1]) > 1e-3, ref            # band 0 IS the target, band 1 is not
+        assert float((got[0] - ref).abs().max()) <= 2e-6 * max(float(ref.abs().max()), 1.0), (got[0], ref)
+    finally:
+        PairPolicy.reset()

@@ -293,7 +293,7 @@ def test_config3_full_size_rotation_sweep(dev):
         targets = render_views(tgt, cams, bg)
         plan = SweepPlan(obj, cams, targets, bg)                       # SH-0 object: cameras moved, the 15 views stacked
         assert plan.stacked is not None, "the sweep did not take the stacked-views form"
-        assert plan.stacked.batch == 2, "two hypotheses per launch set (30 x 800x800 stays on the two-level binning)"
+        assert plan.stacked.batch == 3, "three hypotheses per launch set (45 x 800x800 stays on the two-level binning)"
         ids, fit, best = rotation_sweep(obj, rots, cams, targets, bg, plan=plan)
         assert ids.numel() == 128 and best == planted
         # ... and one hypothesis per launch set (round 5's form), on an odd number of them: the batching changes no score

@@ -654,6 +654,26 @@ def test_indefinite_conic_is_skipped_where_power_is_positive(precision, dev):
     compare_grads(t, o.backward(wc, wd, wa), g64_fn=oracle64_grads(kw, wc, wd, wa))
 
 
+def test_two_level_binning_on_small_images_in_a_child_process():
+    """Images of fewer than 256 cells of 64 x 64 pixels take the one-level binning since round 6 (common.hpp,
+    SCORP_TWO_LEVEL_MIN_CELLS: sixteen workgroups moving every pair of a 256 x 256 view was the slower way) - which is
+    nearly every image of this suite.  The two-level kernels keep their coverage on those cases: a child process with the
+    threshold at zero runs the stage-parity and forward / backward parity tests of the cases below, and the stacked views."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SCORP_TWO_LEVEL_MIN_CELLS="0")
+    sel = "sh2_ragged or many_tiles or long_lists or huge_splats or sh3_bg_mod or tiny_splats"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        f"(test_forward_backward_parity or test_stage_parity_geom_and_tile_lists) and ({sel})"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+    aux = os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_aux_gpu.py")
+    r = subprocess.run([sys.executable, "-m", "pytest", aux, "-q", "-x", "-m", "gpu", "-k", "test_stacked_views_equal_single_views"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_one_level_binning_path_in_a_child_process():
     """Views take the two-level binning (cells, then tiles).  The one-level path - what images beyond 8 192 cells or 2^28
     (virtual) Gaussians take - is held against the oracle too: a child process with SCORP_ONE_LEVEL_BINNING=1 (the switch is read
