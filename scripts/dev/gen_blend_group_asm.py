@@ -174,7 +174,7 @@ __device__ __forceinline__ bool {name}(const f32x16 &e, uint32_t gcb, float &T, 
 def main():
     hdr = '''// blend_group_asm.hpp - GENERATED by scripts/gen_blend_group_asm.py (edit the generator, not this file).
 // The blend forward's full clamp-free group of sixteen hits as one inline-assembly block; see the generator's docstring and
-// DESIGN.md section 4.2a.  gfx950 only.
+// profiles/DESIGN_history_r01-r05.md section 8.0 (2).  gfx950 only.
 #pragma once
 #include "common.hpp"
 #include "exp_mfma.hpp"

@@ -1,7 +1,7 @@
 // mb_atomic_rows.hip — what the memory side of gfx950 sustains for the blend backward's accumulator traffic: global float
 // atomics shaped as WHOLE 64-byte rows, four rows per wave-instruction (lane = float of a row, 10 or 16 of 16 lanes
 // active), at random rows of a 64 MB table (1 M Gaussians x 64 B).  MI355X_MICROARCH.md lists this shape as unmeasured;
-// DESIGN.md section 8 extrapolated a floor of ~216 us for the 4.42 M (block, hit) rows of one S3 view from the 256-byte
+// profiles/DESIGN_history_r01-r05.md section 8.1 extrapolated a floor of ~216 us for the 4.42 M (block, hit) rows of one S3 view from the 256-byte
 // contiguous figure.  This measures it, together with what a tile-level redesign would change:
 //   * rows per view 4.42 M (one per (8x8 block, hit)) against 2.43 M (one per (tile, splat));
 //   * the four waves of a tile hitting the SAME rows at about the same time (today) against disjoint rows;

@@ -1,5 +1,5 @@
 // Microbenchmark (round 5): what ONE INSTRUCTION of each class the blend kernels use costs a SIMD of gfx950 when W waves
-// share it - vector, scalar and LDS alike.  DESIGN.md section 8.0: the blend kernels are bound by instructions issued, so the
+// share it - vector, scalar and LDS alike.  profiles/DESIGN_history_r01-r05.md section 8.0: the blend kernels are bound by instructions issued, so the
 // price list that matters is per instruction CLASS, not per FLOP.
 //   hipcc --offload-arch=gfx950 -O3 scripts/mb_issue_costs.hip -o build/mb/mb_issue_costs && ./build/mb/mb_issue_costs
 // Every kernel runs W = 2, 4, 6, 8 waves per SIMD on every CU; eight independent register chains per wave; reported:
