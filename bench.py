@@ -257,6 +257,30 @@ def secondary_s6(dev, steps=40, warmup=8, cams=4, lead_in=24, parity=False):
     finally:
         R._tls.backward_flags = prev_flags
     PairPolicy.drain()
+    # extra: FULL 2DGS training iterations (train_2dgs.py:95-199 without the densification itself): the one-call view with the
+    # optimizer step and the statistics inside it (ScorpGs2dTrainView.adam), the library's default backward
+    train_its = None
+    try:
+        from scorp_amd.gaussian_model import OptimizationParams2D
+        from scorp_amd.train import training_iteration
+        opt_ = OptimizationParams2D()
+        opt_.densify_from_iter, opt_.opacity_reset_interval, opt_.random_background = 1 << 30, 1 << 30, False
+        opt_.depth_from_iter = 1 << 30      # (no depth / isotropic terms: the plain photometric loss + the two regularisers)
+        model.optimizer = None
+        model.training_setup(opt_)
+        n_it = 40
+
+        def it_(i):
+            training_iteration(model, my_cams[i % cams], gts[i % cams], opt_, pipe, bg, 8000 + i, scene_extent=3.0, fused_view=True, surfels=True)
+        dt_it, _ = _event_region(lambda: [it_(i) for i in range(10)], lambda: [it_(10 + i) for i in range(n_it)])
+        PairPolicy.drain()
+        train_its = round(n_it / dt_it, 1)
+    except Exception as e:   # noqa: BLE001   (an extra: never costs the record)
+        train_its = f"{type(e).__name__}: {e}"[:200]
+    finally:
+        model.optimizer = None
+        for p in params:
+            p.grad = None
     PairPolicy.reset()
     kus = {k: round(ms / cnt * 1e3, 1) for k, (ms, cnt) in kern.items() if cnt}
     bwd_exact_us = round(kern_exact["blend_backward_2d"][0] / max(kern_exact["blend_backward_2d"][1], 1) * 1e3, 1)
@@ -275,6 +299,7 @@ def secondary_s6(dev, steps=40, warmup=8, cams=4, lead_in=24, parity=False):
            "value_exact_fp32": round(steps / dt_exact, 2), "ms_per_step_exact_fp32": round(dt_exact / steps * 1e3, 4),
            "value_split22": round(steps / dt, 2), "ms_per_step_split22": round(dt / steps * 1e3, 4),
            "library_default_backward": "2-term fp16 split under a per-hit power of two (value_split22)",
+           "train_iterations_per_s": train_its,
            "steps": steps, "ms_per_step": round(dt_exact / steps * 1e3, 4), "pairs_per_view_D": round(float(np.mean(Ds))), "visible": round(nvis),
            "kernels_us": kus, "kernels_us_note": "probe views of the split form; blend_backward_2d in the all-fp32 form: blend_backward_2d_exact_fp32_us",
            "blend_backward_2d_exact_fp32_us": bwd_exact_us,

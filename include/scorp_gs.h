@@ -399,6 +399,8 @@ typedef struct ScorpGs2dTrainView {
   void *backward_scratch;        /* scorp_gs2d_backward_scratch_bytes(N) (scorp_gs2d_backward_scratch_bytes_ex with backward_flags) */
   size_t backward_scratch_bytes;
   uint32_t backward_flags;       /* flags of scorp_gs2d_backward_ex for the view's backward; 0 = default */
+  const ScorpFusedAdam *adam;    /* optional: the optimizer step and the statistics inside the view (see ScorpFusedAdam; the
+                                    scaling leaf is [N,2], the statistic norms the whole means2D-gradient row) */
 } ScorpGs2dTrainView;
 int scorp_gs2d_train_view(const ScorpGs2dTrainView *view, scorp_stream_t stream);
 

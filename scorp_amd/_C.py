@@ -59,7 +59,7 @@ class ScorpGs2dTrainView(ctypes.Structure):
                 ("reg_workspace", ctypes.c_void_p), ("reg_workspace_bytes", ctypes.c_size_t),
                 ("grad_color", ctypes.c_void_p), ("grad_allmap", ctypes.c_void_p), ("grads", ctypes.c_void_p),
                 ("backward_scratch", ctypes.c_void_p), ("backward_scratch_bytes", ctypes.c_size_t),
-                ("backward_flags", ctypes.c_uint32)]
+                ("backward_flags", ctypes.c_uint32), ("adam", ctypes.c_void_p)]
 
 
 class ScorpRowTensor(ctypes.Structure):

@@ -186,8 +186,8 @@ inline int bin_blocks(int N, int tiles) {
 
 // Two-level binning (round 5).  The (tile, splat) pairs of a view are bucketed FIRST by cell - kCellTiles x kCellTiles tiles,
 // 64 x 64 pixels - and only then, one workgroup per cell, by tile: a bin block's pairs for one cell are a run of ~20
-// consecutive 8-byte keys (they were 1.4 scattered keys per (block, tile): the scatter wrote 110 MB for 35 MB, section 8 of
-// DESIGN.md), the block x bin histogram matrix shrinks sixteenfold, and the second level's stores stay inside one cell's
+// consecutive 8-byte keys (they were 1.4 scattered keys per (block, tile): the scatter wrote 110 MB for 35 MB, history
+// section 4.10), the block x bin histogram matrix shrinks sixteenfold, and the second level's stores stay inside one cell's
 // ~40 KB.  A level-one key carries the tile's index inside its cell in bits 28..31 of its low word, which is why the path
 // takes fewer than 2^28 (virtual) Gaussians; the tile lists then lie in memory in CELL-major order, so every tile has its
 // own (start, end) pair: tile_start[2 t], tile_start[2 t + 1] (both paths write that form).
@@ -373,6 +373,9 @@ void launch_preprocess_backward(const ScorpGs3dInputs *in, const StateLayout &L,
 int backward3d_impl(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity, const float *dL_dcolor,
                     const float *dL_ddepth, const float *dL_dalpha, const ScorpGs3dGrads *grads, void *scratch,
                     size_t scratch_bytes, uint32_t flags, scorp_stream_t stream, const AdamEpi *adam);
+int backward2d_impl(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity, const float *dL_dcolor,
+                    const float *dL_dallmap, const ScorpGs3dGrads *grads, void *scratch, size_t scratch_bytes, uint32_t flags,
+                    scorp_stream_t stream, const AdamEpi *adam);
 // one Adam update, the operation order of torch.optim.Adam (single-tensor, non-capturable): exp_avg.lerp_, addcmul_,
 // sqrt / div / add, addcdiv_; (1 - beta) is formed in double on the host, as torch does.  Shared by adam_kernel
 // (aux_kernels.hip) and the fused epilogue of preprocess_backward_kernel so that the two give the same bits.

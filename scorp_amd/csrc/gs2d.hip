@@ -609,7 +609,7 @@ constexpr int k2BChunk = SCORP_2D_BCHUNK;   // hits staged per chunk: 32 (the st
 //   * kExact (SCORP_BACKWARD_EXACT_FP32): the eight values of a hit stay fp32 in the matrix, the B operand holds the basis and
 //     the six upstream gradients in fp32 (nine columns), the reduction is 16 v_mfma_f32_16x16x4_f32 per pair of hits.  No
 //     fp16 terms, so none of the three power-of-two scales either (wave, hit, 1 / p.z): every operand is the fp32 number the
-//     reference's arithmetic would carry.  The fp32 MFMA runs at the vector rate (34 cycles each, DESIGN section 8): this
+//     reference's arithmetic would carry.  The fp32 MFMA runs at the vector rate (34 cycles each, DESIGN.md section 4.4): this
 //     form pays 8 of them per hit where the split form pays 2 fp16 ones, and saves the split's ~40 instructions.
 //   * kDet (SCORP_BACKWARD_DETERMINISTIC): the twenty sums of a (block, hit) leave as one plain row
 //     partial[4 * pair + block] (pair = the (surfel, tile) pair's ordinal in surfel-major order, gs3d_backward.hip) with a
@@ -977,7 +977,7 @@ blend2d_backward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint
 template <int DEG, bool SPLIT, bool LIN>
 __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, float *s_sh, const Surfel *__restrict__ rec,
                                                            const BinRec *__restrict__ bin, const float *__restrict__ acc,
-                                                           const ScorpGs3dGrads &g) {
+                                                           const ScorpGs3dGrads &g, const AdamEpi &ad) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool active = LIN || i < a.N;
   const size_t i0 = (size_t)blockIdx.x * 256;
@@ -1015,7 +1015,10 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
     rad_bits = active ? bin[i].radius : 0;
   }
   const bool visible = (rad_bits & kRadiusMask) != 0;
-  const bool want_sh_grad = a.shs != nullptr && g.shs != nullptr;
+  // the optimizer step inside the view (scorp_gs2d_train_view with `adam`; see preprocess_backward_body in gs3d_pergaussian.hip)
+  const bool adam_on = SPLIT && ad.on != 0;
+  const bool adam_sh = adam_on && (ad.m[1] != nullptr || ad.m[2] != nullptr);
+  const bool want_sh_grad = a.shs != nullptr && (g.shs != nullptr || adam_sh);
   bool staged = false;
   constexpr bool lin = LIN;
   if (a.shs) {
@@ -1173,26 +1176,61 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
       for (int q = 0; q < 9; q++) g.cov3D_precomp[9 * (size_t)i + q] = gT[q];
     }
   }
+  // Adam + the view's densification statistics where the gradient row is at hand (train_2dgs.py:189-199 over
+  // gs2dgs/scene/gaussian_model.py:494-495: the statistic norms the whole means2D-gradient row, whose third component is 0)
+  bool adam_go = false;
+  if constexpr (SPLIT) {
+    if (adam_on) {
+      adam_go = !(ad.skip && *ad.skip != 0u);
+      if (!adam_go && ad.skipped_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ad.skipped_counter, 1u);
+      if (adam_go && active && !a.transmat) {
+        float pin[11];
+        if constexpr (LIN) {
+#pragma unroll
+          for (int q = 0; q < 11; q++) pin[q] = pre[q];
+        }
+        adam_leaf<3>(ad, 0, const_cast<float *>(a.means3D), 3 * (size_t)i, gm, LIN ? pin : nullptr);
+        adam_leaf<1>(ad, 3, const_cast<float *>(a.opacities), (size_t)i, &g_op, LIN ? pin + 10 : nullptr);
+        adam_leaf<2>(ad, 4, const_cast<float *>(a.scales), 2 * (size_t)i, gs, LIN ? pin + 7 : nullptr);
+        adam_leaf<4>(ad, 5, const_cast<float *>(a.rotations), 4 * (size_t)i, gq, LIN ? pin + 3 : nullptr);
+        if (ad.accum && visible) {
+#pragma clang fp contract(off)
+          const float gx = gm2[0], gy = gm2[1];
+          ad.max_radii2D[i] = fmaxf(ad.max_radii2D[i], (float)(rad_bits & kRadiusMask));
+          ad.accum[i] += sqrtf(gx * gx + gy * gy + 0.0f);
+          ad.denom[i] += 1.0f;
+        }
+      }
+    }
+  }
   if (want_sh_grad) {
     if (!staged && active) sh_row_zero(row);
     __syncthreads();
-    if (lin) unstage_sh_linear(s_sh, g.shs, g.shs_rest, i0);
-    else unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
+    if (g.shs) {
+      if (lin) unstage_sh_linear(s_sh, g.shs, g.shs_rest, i0);
+      else unstage_sh_rows<SPLIT>(s_sh, g.shs, g.shs_rest, a.K, i0, nrows);
+    }
+    if constexpr (SPLIT) {
+      if (adam_go && adam_sh) {
+        if (lin) adam_sh_linear(ad, s_sh, const_cast<float *>(a.shs), const_cast<float *>(a.shs_rest), i0);
+        else adam_sh_rows(ad, s_sh, const_cast<float *>(a.shs), const_cast<float *>(a.shs_rest), a.K, i0, nrows);
+      }
+    }
   }
 }
 
 template <int DEG, bool SPLIT>
 __global__ void __launch_bounds__(256)
 preprocess2d_backward_kernel(Pg2Args a, const Surfel *__restrict__ rec, const BinRec *__restrict__ bin,
-                             const float *__restrict__ acc, ScorpGs3dGrads g) {
+                             const float *__restrict__ acc, ScorpGs3dGrads g, AdamEpi ad) {
   __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
   if constexpr (SPLIT && DEG == 3) {
     if (a.shs != nullptr && a.K == 16 && !a.transmat && a.N - (int)blockIdx.x * 256 >= 256) {
-      preprocess2d_backward_body<DEG, SPLIT, true>(a, s_sh, rec, bin, acc, g);
+      preprocess2d_backward_body<DEG, SPLIT, true>(a, s_sh, rec, bin, acc, g, ad);
       return;
     }
   }
-  preprocess2d_backward_body<DEG, SPLIT, false>(a, s_sh, rec, bin, acc, g);
+  preprocess2d_backward_body<DEG, SPLIT, false>(a, s_sh, rec, bin, acc, g, ad);
 }
 
 // Deterministic mode: the rows of one surfel are contiguous - partial[4 * pair_base[i] ... 4 * pair_base[i + 1]) - so the
@@ -1336,6 +1374,13 @@ extern "C" int scorp_gs2d_backward(const ScorpGs3dInputs *in, const void *state,
 extern "C" int scorp_gs2d_backward_ex(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
                                       const float *dL_dcolor, const float *dL_dallmap, const ScorpGs3dGrads *grads,
                                       void *scratch, size_t scratch_bytes, uint32_t flags, scorp_stream_t stream_) {
+  return backward2d_impl(in, state, pairs, capacity, dL_dcolor, dL_dallmap, grads, scratch, scratch_bytes, flags, stream_, nullptr);
+}
+
+// `adam` (scorp_gs2d_train_view): the per-surfel kernel applies the optimizer step and the view's statistics itself
+int scorp::backward2d_impl(const ScorpGs3dInputs *in, const void *state, const void *pairs, uint64_t capacity,
+                           const float *dL_dcolor, const float *dL_dallmap, const ScorpGs3dGrads *grads, void *scratch,
+                           size_t scratch_bytes, uint32_t flags, scorp_stream_t stream_, const AdamEpi *adam) {
   if (!in || !state || !pairs || !grads || !scratch || !dL_dcolor) { set_error("NULL argument to scorp_gs2d_backward"); return SCORP_ERR_INVALID; }
   hipStream_t stream = (hipStream_t)stream_;
   const int N = in->num_gaussians, W = in->image_width, H = in->image_height;
@@ -1394,7 +1439,10 @@ extern "C" int scorp_gs2d_backward_ex(const ScorpGs3dInputs *in, const void *sta
     const ScorpGs3dGrads g = *grads;
     const Surfel *rec = (const Surfel *)(base + L.rec);
     const BinRec *bin = (const BinRec *)(base + L.bin);
-#define SCORP_B2(D, S) preprocess2d_backward_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, acc, g)
+    AdamEpi ad;
+    memset(&ad, 0, sizeof(ad));
+    if (adam && in->shs_rest) ad = *adam;   // (the fused step is defined for the training layout: dc / rest split leaves)
+#define SCORP_B2(D, S) preprocess2d_backward_kernel<D, S><<<grid, block, 0, stream>>>(a, rec, bin, acc, g, ad)
     if (in->shs_rest) { switch (deg) { case 0: SCORP_B2(0, true); break; case 1: SCORP_B2(1, true); break; case 2: SCORP_B2(2, true); break; default: SCORP_B2(3, true); } }
     else { switch (deg) { case 0: SCORP_B2(0, false); break; case 1: SCORP_B2(1, false); break; case 2: SCORP_B2(2, false); break; default: SCORP_B2(3, false); } }
 #undef SCORP_B2

@@ -1010,7 +1010,7 @@ blend_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint32_
     };
 #if SCORP_FWD_MERGE
     // full clamp-free groups: adjacent hits whose live pixels are disjoint share an iteration (blend_group_asm.hpp: the
-    // sixteen slots as one hand-allocated assembly block; section 4.2a of DESIGN.md)
+    // sixteen slots as one hand-allocated assembly block; profiles/DESIGN_history_r01-r05.md section 8.0 (2))
     auto blend_group_merged = [&](const f32x16 &e) -> bool {
       const uint32_t gcb = (uint32_t)(size_t)(const void *)(q_col + head);   // LDS byte address of the group's first slot
       bool all_done;

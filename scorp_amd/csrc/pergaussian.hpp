@@ -278,6 +278,72 @@ __device__ __forceinline__ void sh_row_backward(ShRow srow, float x, float y, fl
         }
 }
 
+// ---- the optimizer step inside the per-Gaussian backward kernels (ScorpFusedAdam; 3-D and 2-D) ----
+// n consecutive floats of one leaf: Adam with the gradient in registers.  `p_in`: the parameter values the thread already
+// holds (NULL: read them).
+template <int n>
+__device__ __forceinline__ void adam_leaf(const AdamEpi &ad, int k, float *__restrict__ param, size_t at, const float *gr,
+                                          const float *p_in) {
+  if (!ad.m[k]) return;
+  float *pp = param + at, *pm_ = ad.m[k] + at, *pv = ad.v[k] + at;
+  float pvals[n], m[n], v[n];
+#pragma unroll
+  for (int q = 0; q < n; q++) { pvals[q] = p_in ? p_in[q] : pp[q]; m[q] = pm_[q]; v[q] = pv[q]; }
+#pragma unroll
+  for (int q = 0; q < n; q++) adam_one(pvals[q], gr[q], m[q], v[q], ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+#pragma unroll
+  for (int q = 0; q < n; q++) { pp[q] = pvals[q]; pm_[q] = m[q]; pv[q] = v[q]; }
+}
+__device__ __forceinline__ void adam_one4(const AdamEpi &ad, int k, float4 &p, const float4 g, float4 &m, float4 &v) {
+  adam_one(p.x, g.x, m.x, v.x, ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+  adam_one(p.y, g.y, m.y, v.y, ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+  adam_one(p.z, g.z, m.z, v.z, ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+  adam_one(p.w, g.w, m.w, v.w, ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+}
+// The SH leaves of a block, gradient rows in LDS.  Linear layout (a full block of the training layout): two 16-byte streams
+// per array; the parameters are read again from global memory - the block streamed those 46 KB into LDS microseconds ago
+// (L2) and has since overwritten them there with their gradients.
+__device__ __forceinline__ void adam_sh_linear(const AdamEpi &ad, const float *__restrict__ lds, float *__restrict__ dc,
+                                               float *__restrict__ rest, size_t i0) {
+  const float4 *l4 = reinterpret_cast<const float4 *>(lds), *lr4 = reinterpret_cast<const float4 *>(lds + kShLinearRest);
+  if (ad.m[1]) {
+    float4 *P = reinterpret_cast<float4 *>(dc + i0 * 3), *M = reinterpret_cast<float4 *>(ad.m[1] + i0 * 3), *V = reinterpret_cast<float4 *>(ad.v[1] + i0 * 3);
+    for (int e = threadIdx.x; e < 256 * 3 / 4; e += 256) {
+      float4 p = P[e], m = M[e], v = V[e];
+      adam_one4(ad, 1, p, l4[e], m, v);
+      P[e] = p; M[e] = m; V[e] = v;
+    }
+  }
+  if (ad.m[2]) {
+    float4 *P = reinterpret_cast<float4 *>(rest + i0 * 45), *M = reinterpret_cast<float4 *>(ad.m[2] + i0 * 45), *V = reinterpret_cast<float4 *>(ad.v[2] + i0 * 45);
+    for (int e = threadIdx.x; e < 256 * 45 / 4; e += 256) {
+      float4 p = P[e], m = M[e], v = V[e];
+      adam_one4(ad, 2, p, lr4[e], m, v);
+      P[e] = p; M[e] = m; V[e] = v;
+    }
+  }
+}
+// ... and the padded layout (the last, partial block; any K): element by element
+__device__ __forceinline__ void adam_sh_rows(const AdamEpi &ad, const float *__restrict__ lds, float *__restrict__ dc,
+                                             float *__restrict__ rest, int K, size_t i0, int nrows) {
+  if (ad.m[1])
+    for (int e = threadIdx.x; e < nrows * 3; e += 256) {
+      const size_t at = i0 * 3 + e;
+      float p = dc[at], m = ad.m[1][at], v = ad.v[1][at];
+      adam_one(p, lds[(e / 3) * kShStride + e % 3], m, v, ad.omb1, ad.beta2, ad.omb2, ad.step_size[1], ad.inv_sqrt_bc2, ad.eps);
+      dc[at] = p; ad.m[1][at] = m; ad.v[1][at] = v;
+    }
+  const int R3 = (K - 1) * 3;
+  if (ad.m[2] && R3 > 0)
+    for (int e = threadIdx.x; e < nrows * R3; e += 256) {
+      const int r = e / R3, c = e % R3;
+      const size_t at = i0 * R3 + e;
+      float p = rest[at], m = ad.m[2][at], v = ad.v[2][at];
+      adam_one(p, c < 45 ? lds[r * kShStride + 3 + c] : 0.0f, m, v, ad.omb1, ad.beta2, ad.omb2, ad.step_size[2], ad.inv_sqrt_bc2, ad.eps);
+      rest[at] = p; ad.m[2][at] = m; ad.v[2][at] = v;
+    }
+}
+
 // activations of the raw-parameter convention (gaussian_model.py:37-45: sigmoid, exp, F.normalize)
 __device__ __forceinline__ float act_opacity(float v, int raw) { return (raw & 1) ? 1.0f / (1.0f + expf(-v)) : v; }
 __device__ __forceinline__ float act_scale(float v, int raw) { return (raw & 2) ? expf(v) : v; }

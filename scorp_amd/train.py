@@ -82,10 +82,16 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
         from .train_view import train_view2d
         lambda_normal = opt.lambda_normal if iteration > 7000 else 0.0
         lambda_dist = opt.lambda_dist if iteration > 3000 else 0.0
-        pkg = train_view2d(cam, gaussians, pipe, bg, gt_image, opt.lambda_dssim, lambda_normal, lambda_dist)
+        kw_view = {}
+        if _step_in_view_ok(gaussians, opt, iteration, densify, data_parallel, white_background, fused_step):
+            kw_view["optimizer"] = gaussians.optimizer
+            if densify and iteration < opt.densify_until_iter and _stats_components(gaussians) == 3:
+                kw_view["stats"] = (gaussians.max_radii2D, gaussians.xyz_gradient_accum, gaussians.denom)
+        pkg = train_view2d(cam, gaussians, pipe, bg, gt_image, opt.lambda_dssim, lambda_normal, lambda_dist, **kw_view)
         loss = pkg["loss"]
+        stepped_in_view = bool(pkg.get("optimizer_stepped"))
         ovf = _shared_overflow(pkg, data_parallel)
-        if hasattr(gaussians.optimizer, "skip_flag"):
+        if hasattr(gaussians.optimizer, "skip_flag") and not stepped_in_view:
             gaussians.optimizer.skip_flag = ovf
         pkg["visibility_filter"] = pkg["visibility_filter"] & (ovf == 0)
     elif (fused_view and not surfels and not extra_terms and render_fn is render and loss_fn is fused_l1_ssim_loss
@@ -98,12 +104,7 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
         # this view's gradients as they are: one replica (no averaging first) and neither a densification nor an opacity
         # reset in between - after those the reference's leaves are fresh tensors without .grad and its step() passes them by
         # (train_3dgs.py:183-193), which the separate path below reproduces.
-        will_densify = densify and iteration < opt.densify_until_iter and iteration > opt.densify_from_iter and \
-            iteration % opt.densification_interval == 0
-        will_reset = densify and iteration < opt.densify_until_iter and (
-            iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter))
-        step_in_view = fused_step and not data_parallel and not will_densify and not will_reset and \
-            hasattr(gaussians.optimizer, "fused_view_pack")
+        step_in_view = _step_in_view_ok(gaussians, opt, iteration, densify, data_parallel, white_background, fused_step)
         kw_view = {}
         if data_parallel and not sparse_gradients and not step_in_view:
             # the view writes its gradients straight into the flat arena the collective reduces in place (parallel.GradArena)
@@ -112,7 +113,7 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
                 kw_view["grad_out"] = arena.views
         if step_in_view:
             kw_view["optimizer"] = gaussians.optimizer
-            if densify and iteration < opt.densify_until_iter and getattr(type(gaussians), "_stats_norm_components", None) == 2:
+            if densify and iteration < opt.densify_until_iter and _stats_components(gaussians) == 2:
                 kw_view["stats"] = (gaussians.max_radii2D, gaussians.xyz_gradient_accum, gaussians.denom)
         pkg = view_fn(cam, gaussians, pipe, bg, gt_image, opt.lambda_dssim, **kw_view)
         loss = pkg["loss"]
@@ -178,6 +179,25 @@ def training_iteration(gaussians, cam, gt_image, opt, pipe, background, iteratio
             gaussians.optimizer.step()
         gaussians.optimizer.zero_grad(set_to_none=True)
     return loss, pkg
+
+
+def _stats_components(gaussians):
+    """Over how many components of a means2D-gradient row the model's add_densification_stats norms - declared next to the
+    method by the class that DEFINES it (GaussianModel.accumulate_view_stats uses the same rule); None: an override the fused
+    statistics do not restate."""
+    owner = next((c for c in type(gaussians).__mro__ if "add_densification_stats" in c.__dict__), None)
+    return None if owner is None else owner.__dict__.get("_stats_norm_components")
+
+
+def _step_in_view_ok(gaussians, opt, iteration, densify, data_parallel, white_background, fused_step):
+    """May this iteration's optimizer step run inside the one-call view?  One replica (no averaging first), a FusedAdam, and
+    neither a densification nor an opacity reset between backward() and step() (train_3dgs.py:183-193)."""
+    will_densify = densify and iteration < opt.densify_until_iter and iteration > opt.densify_from_iter and \
+        iteration % opt.densification_interval == 0
+    will_reset = densify and iteration < opt.densify_until_iter and (
+        iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter))
+    return bool(fused_step and not data_parallel and not will_densify and not will_reset and
+                hasattr(gaussians.optimizer, "fused_view_pack"))
 
 
 def _grad_arena(gaussians):

@@ -143,12 +143,13 @@ class _ViewspaceGrad:
 
 
 def train_view2d(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.2, lambda_normal=0.0, lambda_dist=0.0,
-                 mask=None, scaling_modifier=1.0):
+                 mask=None, scaling_modifier=1.0, optimizer=None, stats=None):
     """The 2DGS twin of `train_view`: one iteration of train_2dgs.py:95-150 for the plain photometric loss plus the
     normal-consistency / depth-distortion regularisers (train_2dgs.py:142-150), enqueued by ONE library call
     (`scorp_gs2d_train_view`).  Returns "render", "allmap", "radii", "visibility_filter", "viewspace_points",
     "loss" (= photometric + normal + distortion, a 0-d device tensor), "l1", "ssim", "normal_loss", "dist_loss",
-    "overflow"; parameter gradients are accumulated into the surfel model's leaves."""
+    "overflow"; parameter gradients are accumulated into the surfel model's leaves.  `optimizer` / `stats`: the optimizer
+    step and the view's densification statistics inside the view, as for `train_view` (ScorpGs2dTrainView.adam)."""
     from .renderer2d import _camera_rays
     L = _C.lib()
     xyz = pc.get_xyz
@@ -187,8 +188,18 @@ def train_view2d(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.
     scratch = new((scratch_bytes,), torch.uint8)
     need = [p.requires_grad for p in leaves]
     need[1] = need[2] = need[1] or need[2]
-    g = [torch.empty_like(x) if n else None for x, n in zip(t, need)]
-    g_means2D = new((N, 3)) if xyz.requires_grad else None
+    pack = None
+    if (optimizer is not None and hasattr(optimizer, "fused_view_pack") and f_rest.numel() > 0
+            and all(x.data_ptr() == p.data_ptr() for x, p in zip(t, leaves))):
+        st = None
+        if stats is not None and xyz.requires_grad:
+            st = tuple(s_ if (s_.dtype == torch.float32 and s_.is_contiguous()) else None for s_ in stats)
+            st = None if any(s_ is None for s_ in st) else st
+        pack = optimizer.fused_view_pack(leaves, st)
+        stats = st
+    fused_step = pack is not None
+    g = [torch.empty_like(x) if (n and not fused_step) else None for x, n in zip(t, need)]
+    g_means2D = new((N, 3)) if (xyz.requires_grad and not (fused_step and stats is not None)) else None
     grads = _C.ScorpGs3dGrads()
     grads.means3D, grads.means2D, grads.shs, grads.shs_rest = _ptr(g[0]), _ptr(g_means2D), _ptr(g[1]), _ptr(g[2])
     grads.opacities, grads.scales, grads.rotations = _ptr(g[3]), _ptr(g[4]), _ptr(g[5])
@@ -206,11 +217,14 @@ def train_view2d(viewpoint_camera, pc, pipe, bg_color, gt_image, lambda_dssim=0.
     v.grad_color, v.grad_allmap, v.grads = grad_color.data_ptr(), grad_allmap.data_ptr(), ctypes.addressof(grads)
     v.backward_scratch, v.backward_scratch_bytes = scratch.data_ptr(), scratch_bytes
     v.backward_flags = flags
+    if fused_step:
+        v.adam = ctypes.addressof(pack[0])
     _C.check(L.scorp_gs2d_train_view(ctypes.byref(v), _stream()), "scorp_gs2d_train_view")
     header = PairPolicy.pend(state, N, H, W)
-    for p, gp in zip(leaves, g):
-        if p.requires_grad:
-            _accumulate(p, gp.view_as(p))
-    return {"render": color, "allmap": allmap, "viewspace_points": _ViewspaceGrad(g_means2D), "visibility_filter": radii > 0,
+    if not fused_step:
+        for p, gp in zip(leaves, g):
+            if p.requires_grad:
+                _accumulate(p, gp.view_as(p))
+    return {"optimizer_stepped": fused_step, "stats_accumulated": fused_step and stats is not None, "render": color, "allmap": allmap, "viewspace_points": _ViewspaceGrad(g_means2D), "visibility_filter": radii > 0,
             "radii": radii, "loss": loss5[0] + loss5[3] + loss5[4], "l1": loss5[1], "ssim": loss5[2],
             "normal_loss": loss5[3], "dist_loss": loss5[4], "overflow": header.view(torch.int32)[1:2]}

@@ -255,6 +255,57 @@ def test_optimizer_step_inside_the_view_equals_fused_adam_on_the_written_gradien
         assert torch.equal(a, b), nm
 
 
+@pytest.mark.parametrize("deg,n", [(3, 1500), (1, 700)])
+def test_optimizer_step_inside_the_2dgs_view_equals_the_separate_step(deg, n, dev):
+    """The 2DGS twin (scorp_gs2d_train_view with ScorpFusedAdam; scaling [N,2], the statistic over the whole means2D-gradient
+    row): parameters, moments and statistics after three iterations with the regularisers on are the same bits as
+    train_view2d + accumulate_view_stats + FusedAdam.step() under the deterministic backward."""
+    from scorp_amd import rasterizer3d as R
+    from scorp_amd.gaussian_model import OptimizationParams2D
+    from scorp_amd.rasterizer3d import PairPolicy
+    from scorp_amd.renderer2d import GaussianModel2D
+    from scorp_amd.synthetic import make_gaussians, ring_cameras
+    from scorp_amd.train import PipelineParams
+    from scorp_amd.train_view import train_view2d
+    raw = make_gaussians(n, deg, 33, log_scale_mean=math.log(0.05), scale_dims=2)
+    cams = ring_cameras(3, 144, 96, 5, radius=3.2, device=dev)
+    gts = [torch.rand(3, 96, 144, device=dev, generator=torch.Generator(device=dev).manual_seed(k)) for k in range(3)]
+    bg, pipe = torch.zeros(3, device=dev), PipelineParams()
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    res = []
+    PairPolicy.reset()
+    try:
+        with R.backward_precision("deterministic"):
+            for in_view in (False, True):
+                m = GaussianModel2D.from_raw(raw, deg, device=dev)
+                m.active_sh_degree = deg
+                m.training_setup(OptimizationParams2D())
+                for it in range(3):
+                    m.update_learning_rate(it + 1)
+                    if in_view:
+                        pkg = train_view2d(cams[it], m, pipe, bg, gts[it], 0.2, 0.05, 100.0, optimizer=m.optimizer,
+                                           stats=(m.max_radii2D, m.xyz_gradient_accum, m.denom))
+                        assert pkg["optimizer_stepped"] and pkg["stats_accumulated"]
+                    else:
+                        pkg = train_view2d(cams[it], m, pipe, bg, gts[it], 0.2, 0.05, 100.0)
+                        m.accumulate_view_stats(pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
+                        m.optimizer.step()
+                        m.optimizer.zero_grad(set_to_none=True)
+                PairPolicy.drain()
+                st = [m.optimizer.state[getattr(m, nm)] for nm in names]
+                res.append(([getattr(m, nm).detach().clone() for nm in names], [s_["exp_avg"].clone() for s_ in st],
+                            [s_["exp_avg_sq"].clone() for s_ in st], [m.max_radii2D.clone(), m.xyz_gradient_accum.clone(), m.denom.clone()]))
+    finally:
+        PairPolicy.reset()
+    (pa, ma, va, sa), (pb, mb, vb, sb) = res
+    assert float(sa[2].sum()) > 0
+    for group, xa, xb in (("parameter", pa, pb), ("exp_avg", ma, mb), ("exp_avg_sq", va, vb)):
+        for nm, a, b in zip(names, xa, xb):
+            assert torch.equal(a, b), f"{group} {nm}: {float((a - b).abs().max()):.3e}"
+    for nm, a, b in zip(("max_radii2D", "xyz_gradient_accum", "denom"), sa, sb):
+        assert torch.equal(a, b), nm
+
+
 def test_step_inside_the_view_is_skipped_and_counted_when_the_view_overflows(dev):
     """The fused step honours the view's own overflow word: an overflowed view moves no parameter, no moment and no statistic,
     and the optimizer's device counter says one step was skipped (FusedAdam.take_skipped -> rollback_steps)."""
