@@ -78,26 +78,37 @@ adam_kernel(AdamPack pk, float omb1, float beta2, float omb2, float eps, float b
   const size_t base = (size_t)(blockIdx.x - pk.first_block[ti]) * kAdamPerBlock;
   const float step_size = T.lr / bc1;
   const bool vec = (((uintptr_t)T.param | (uintptr_t)T.grad | (uintptr_t)T.exp_avg | (uintptr_t)T.exp_avg_sq) & 15) == 0;
+  // Four 16-byte quads per thread, all of their loads asked for before the first is computed on (left in a loop the
+  // compiler may not move a round's loads above the previous round's stores), and NONTEMPORAL: moments and gradients are
+  // touched once per step, the parameters' next reader is a whole view later (pergaussian.hpp, adam_ld4 / adam_st4).
+  size_t e[4];
+  bool quad[4], any[4];
+  float4 p[4], m[4], v[4], g[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const size_t e = base + ((size_t)r * 256 + threadIdx.x) * 4;
-    if (e >= T.numel) break;
-    if (vec && e + 4 <= T.numel) {
-      float4 p = *reinterpret_cast<float4 *>(T.param + e), m = *reinterpret_cast<float4 *>(T.exp_avg + e),
-             v = *reinterpret_cast<float4 *>(T.exp_avg_sq + e);
-      const float4 g = *reinterpret_cast<const float4 *>(T.grad + e);
-      adam_one(p.x, g.x, m.x, v.x, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
-      adam_one(p.y, g.y, m.y, v.y, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
-      adam_one(p.z, g.z, m.z, v.z, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
-      adam_one(p.w, g.w, m.w, v.w, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
-      *reinterpret_cast<float4 *>(T.param + e) = p;
-      *reinterpret_cast<float4 *>(T.exp_avg + e) = m;
-      *reinterpret_cast<float4 *>(T.exp_avg_sq + e) = v;
-    } else {
-      for (size_t k = e; k < min(e + 4, (size_t)T.numel); k++) {
-        float p = T.param[k], m = T.exp_avg[k], v = T.exp_avg_sq[k];
-        adam_one(p, T.grad[k], m, v, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
-        T.param[k] = p; T.exp_avg[k] = m; T.exp_avg_sq[k] = v;
+    e[r] = base + ((size_t)r * 256 + threadIdx.x) * 4;
+    any[r] = e[r] < T.numel;
+    quad[r] = vec && e[r] + 4 <= T.numel;
+    if (quad[r]) {
+      p[r] = adam_ld4(reinterpret_cast<const float4 *>(T.param + e[r])); m[r] = adam_ld4(reinterpret_cast<const float4 *>(T.exp_avg + e[r]));
+      v[r] = adam_ld4(reinterpret_cast<const float4 *>(T.exp_avg_sq + e[r])); g[r] = adam_ld4(reinterpret_cast<const float4 *>(T.grad + e[r]));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (quad[r]) {
+      adam_one(p[r].x, g[r].x, m[r].x, v[r].x, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+      adam_one(p[r].y, g[r].y, m[r].y, v[r].y, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+      adam_one(p[r].z, g[r].z, m[r].z, v[r].z, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+      adam_one(p[r].w, g[r].w, m[r].w, v[r].w, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+      adam_st4(reinterpret_cast<float4 *>(T.param + e[r]), p[r]);
+      adam_st4(reinterpret_cast<float4 *>(T.exp_avg + e[r]), m[r]);
+      adam_st4(reinterpret_cast<float4 *>(T.exp_avg_sq + e[r]), v[r]);
+    } else if (any[r]) {
+      for (size_t k = e[r]; k < min(e[r] + 4, (size_t)T.numel); k++) {
+        float p1 = T.param[k], m1 = T.exp_avg[k], v1 = T.exp_avg_sq[k];
+        adam_one(p1, T.grad[k], m1, v1, omb1, beta2, omb2, step_size, inv_sqrt_bc2, eps);
+        T.param[k] = p1; T.exp_avg[k] = m1; T.exp_avg_sq[k] = v1;
       }
     }
   }

@@ -389,6 +389,44 @@ __device__ __forceinline__ void adam_one(float &p, float g, float &m, float &v, 
   const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
   p = p - step_size * (m / denom);
 }
+// The optimizer's streams are NONTEMPORAL: the two moments are touched once per iteration and by nobody else, the parameters'
+// next reader (the next view's preprocess) comes ~1 ms and > 2 GB of traffic later.  Same box, S3 training iteration:
+// 985 - 988 it/s with plain loads and stores, 1 070 with nontemporal ones on the SH streams alone (profiles/r06_fused_adam_step.txt).
+#ifndef SCORP_ADAM_NT
+#define SCORP_ADAM_NT 1   // nontemporal loads / stores on the optimizer's streams (0: plain, for A/B builds)
+#endif
+__device__ __forceinline__ float4 adam_ld4(const float4 *p) {
+#if SCORP_ADAM_NT
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void adam_st4(float4 *p, const float4 x) {
+#if SCORP_ADAM_NT
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 t; t.x = x.x; t.y = x.y; t.z = x.z; t.w = x.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
+#else
+  *p = x;
+#endif
+}
+__device__ __forceinline__ float adam_ld1(const float *p) {
+#if SCORP_ADAM_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void adam_st1(float *p, float x) {
+#if SCORP_ADAM_NT
+  __builtin_nontemporal_store(x, p);
+#else
+  *p = x;
+#endif
+}
 #endif
 
 // ---- binning shared by the 3DGS and 2DGS paths (gs3d_forward.hip) ----

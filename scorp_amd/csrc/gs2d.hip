@@ -90,7 +90,7 @@ __device__ __forceinline__ void preprocess2d_body(const Pg2Args &a, float *s_sh,
   if constexpr (LIN) {
     RawParams r;
     raw_issue_params<2>(r, a.means3D + 3 * (size_t)i, a.rotations + 4 * (size_t)i, a.scales + 2 * (size_t)i, a.opacities + i);
-    stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    stage_sh_linear_async<SCORP_NT_SH ? 2 : 0>(s_sh, a.shs, a.shs_rest, i0);   // (nontemporal: see preprocess_body, gs3d_pergaussian.hip)
     raw_take_params(r, pre);
   }
   float vm[16], pm[16];
@@ -999,7 +999,9 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
     const float s_in0 = a.scales[2 * (size_t)i], s_in1 = a.scales[2 * (size_t)i + 1];
     pre[0] = a.means3D[3 * (size_t)i]; pre[1] = a.means3D[3 * (size_t)i + 1]; pre[2] = a.means3D[3 * (size_t)i + 2];
     pre[10] = a.opacities[i];
-    stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    // (nontemporal unless the optimizer step in the epilogue reads the rows again: see preprocess_backward_body, gs3d_pergaussian.hip)
+    if (SCORP_NT_SH && !(SPLIT && ad.on != 0)) stage_sh_linear_async<2>(s_sh, a.shs, a.shs_rest, i0);
+    else stage_sh_linear_async<0>(s_sh, a.shs, a.shs_rest, i0);
     pre[3] = q_in.x; pre[4] = q_in.y; pre[5] = q_in.z; pre[6] = q_in.w; pre[7] = s_in0; pre[8] = s_in1;
     acc_lo[0] = a0.x; acc_lo[1] = a0.y; acc_lo[2] = a0.z; acc_lo[3] = a0.w; acc_lo[4] = a1.x; acc_lo[5] = a1.y; acc_lo[6] = a1.z;
     acc_lo[7] = a1.w; acc_lo[8] = a2.x; acc_lo[9] = a2.y; acc_lo[10] = a2.z;
@@ -1156,6 +1158,13 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
     }
   }
   if (a.shs && lin) { stage_sh_wait(); __syncthreads(); }
+  AdamGeomMoments am;   // asked for here, used in the epilogue: the SH phase in between hides the latency
+  if (adam_on && active && !a.transmat) {
+    adam_moments_load<3>(ad, 0, 3 * (size_t)i, am.m, am.v);
+    adam_moments_load<1>(ad, 3, (size_t)i, am.m + 3, am.v + 3);
+    adam_moments_load<2>(ad, 4, 2 * (size_t)i, am.m + 4, am.v + 4);
+    adam_moments_load<4>(ad, 5, 4 * (size_t)i, am.m + 7, am.v + 7);
+  }
   if (visible && a.shs) {
     float gdir[3] = {0, 0, 0};
     sh_row_backward<DEG>(row, shx, shy, shz, gr3, want_sh_grad, gdir);
@@ -1189,10 +1198,10 @@ __device__ __forceinline__ void preprocess2d_backward_body(const Pg2Args &a, flo
 #pragma unroll
           for (int q = 0; q < 11; q++) pin[q] = pre[q];
         }
-        adam_leaf<3>(ad, 0, const_cast<float *>(a.means3D), 3 * (size_t)i, gm, LIN ? pin : nullptr);
-        adam_leaf<1>(ad, 3, const_cast<float *>(a.opacities), (size_t)i, &g_op, LIN ? pin + 10 : nullptr);
-        adam_leaf<2>(ad, 4, const_cast<float *>(a.scales), 2 * (size_t)i, gs, LIN ? pin + 7 : nullptr);
-        adam_leaf<4>(ad, 5, const_cast<float *>(a.rotations), 4 * (size_t)i, gq, LIN ? pin + 3 : nullptr);
+        adam_leaf_pre<3>(ad, 0, const_cast<float *>(a.means3D), 3 * (size_t)i, gm, LIN ? pin : nullptr, am.m, am.v);
+        adam_leaf_pre<1>(ad, 3, const_cast<float *>(a.opacities), (size_t)i, &g_op, LIN ? pin + 10 : nullptr, am.m + 3, am.v + 3);
+        adam_leaf_pre<2>(ad, 4, const_cast<float *>(a.scales), 2 * (size_t)i, gs, LIN ? pin + 7 : nullptr, am.m + 4, am.v + 4);
+        adam_leaf_pre<4>(ad, 5, const_cast<float *>(a.rotations), 4 * (size_t)i, gq, LIN ? pin + 3 : nullptr, am.m + 7, am.v + 7);
         if (ad.accum && visible) {
 #pragma clang fp contract(off)
           const float gx = gm2[0], gy = gm2[1];

@@ -196,7 +196,10 @@ __device__ __forceinline__ void preprocess_body(const PgArgs &a, float *s_sh, Sp
     RawParams r;
     float p[11];
     raw_issue_params(r, a.means3D + 3 * (size_t)i, a.rotations + 4 * (size_t)i, a.scales + 3 * (size_t)i, a.opacities + i);
-    stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    // One view per launch: nobody reads these rows again before the backward, > 1 GB of traffic later - nontemporal (same box,
+    // S3: 63 - 66 -> 57 us).  A stacked launch (a.views > 1) re-reads them once per view, from L2: default policy there.
+    if (SCORP_NT_SH && a.views <= 1) stage_sh_linear_async<2>(s_sh, a.shs, a.shs_rest, i0);
+    else stage_sh_linear_async<0>(s_sh, a.shs, a.shs_rest, i0);
     raw_take_params(r, p);
     px_ = p[0]; py_ = p[1]; pz_ = p[2];
     q_raw = make_float4(p[3], p[4], p[5], p[6]);
@@ -290,7 +293,10 @@ __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float 
     static_assert(kAccStride >= 10, "accumulator row: 10 floats used here");
     const float *ap = acc + (size_t)i * kAccStride;
     raw_issue_params(ra, ap, ap + 3, ap + 7, reinterpret_cast<const float *>(&bin[i].radius));
-    stage_sh_linear_async(s_sh, a.shs, a.shs_rest, i0);
+    // nontemporal as in the forward (94 -> 90.5 us) - unless the optimizer step runs in the epilogue: the block then reads its SH
+    // parameters a second time, from L2
+    if (SCORP_NT_SH && !(SPLIT && ad.on != 0)) stage_sh_linear_async<2>(s_sh, a.shs, a.shs_rest, i0);
+    else stage_sh_linear_async<0>(s_sh, a.shs, a.shs_rest, i0);
     raw_take_params(r, pre);
     raw_take_params(ra, pre_acc);   // (its vmcnt(12) is already satisfied)
     rad_bits = __float_as_int(pre_acc[10]);
@@ -502,6 +508,14 @@ __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float 
     }
   }
   if (a.shs && lin) { stage_sh_wait(); __syncthreads(); }
+  AdamGeomMoments am;   // asked for here, used in the epilogue: the SH phase in between hides the latency
+  const bool adam_pre = SPLIT && adam_on && active;
+  if (adam_pre) {
+    adam_moments_load<3>(ad, 0, 3 * (size_t)i, am.m, am.v);
+    adam_moments_load<1>(ad, 3, (size_t)i, am.m + 3, am.v + 3);
+    adam_moments_load<3>(ad, 4, 3 * (size_t)i, am.m + 4, am.v + 4);
+    adam_moments_load<4>(ad, 5, 4 * (size_t)i, am.m + 7, am.v + 7);
+  }
   if (visible && a.shs) {
     float gdir[3] = {0, 0, 0};
     sh_row_backward<DEG>(row, shx, shy, shz, gr3, want_sh_grad, gdir);
@@ -538,10 +552,10 @@ __device__ __forceinline__ void preprocess_backward_body(const PgArgs &a, float 
 #pragma unroll
           for (int q = 0; q < 11; q++) pin[q] = pre[q];
         }
-        adam_leaf<3>(ad, 0, const_cast<float *>(a.means3D), 3 * (size_t)i, gm, LIN ? pin : nullptr);
-        adam_leaf<1>(ad, 3, const_cast<float *>(a.opacities), (size_t)i, &g_op, LIN ? pin + 10 : nullptr);
-        adam_leaf<3>(ad, 4, const_cast<float *>(a.scales), 3 * (size_t)i, gs, LIN ? pin + 7 : nullptr);
-        adam_leaf<4>(ad, 5, const_cast<float *>(a.rotations), 4 * (size_t)i, gq, LIN ? pin + 3 : nullptr);
+        adam_leaf_pre<3>(ad, 0, const_cast<float *>(a.means3D), 3 * (size_t)i, gm, LIN ? pin : nullptr, am.m, am.v);
+        adam_leaf_pre<1>(ad, 3, const_cast<float *>(a.opacities), (size_t)i, &g_op, LIN ? pin + 10 : nullptr, am.m + 3, am.v + 3);
+        adam_leaf_pre<3>(ad, 4, const_cast<float *>(a.scales), 3 * (size_t)i, gs, LIN ? pin + 7 : nullptr, am.m + 4, am.v + 4);
+        adam_leaf_pre<4>(ad, 5, const_cast<float *>(a.rotations), 4 * (size_t)i, gq, LIN ? pin + 3 : nullptr, am.m + 7, am.v + 7);
         if (ad.accum && visible) {
 #pragma clang fp contract(off)
           const float gx = a_[0], gy = a_[1];

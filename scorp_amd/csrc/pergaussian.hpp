@@ -135,6 +135,11 @@ __device__ __forceinline__ void sh_row_zero(ShRow r) {
 // issued as direct global -> LDS loads (global_load_lds_dwordx4: each lane's 16 bytes land at
 // M0 base + lane * 16, no VGPR round trip).  Fire-and-forget: the caller does its other work, then
 // stage_sh_wait() + a workgroup barrier before anyone reads the rows.  48 wave-chunks of 1 KiB, 12 per wave.
+#ifndef SCORP_NT_SH
+#define SCORP_NT_SH 1   // nontemporal SH staging where the rows have no second reader nearby (0: A/B builds)
+#endif
+// AUX: the loads' cache-policy bits (0: default; 2: nontemporal - rows that nobody reads again before > 1 GB of other traffic)
+template <int AUX = 0>
 __device__ __forceinline__ void stage_sh_linear_async(float *__restrict__ lds, const float *__restrict__ dc,
                                                       const float *__restrict__ rest, size_t i0) {
   typedef const __attribute__((address_space(1))) void *GPtr;
@@ -145,8 +150,8 @@ __device__ __forceinline__ void stage_sh_linear_async(float *__restrict__ lds, c
 #pragma unroll
   for (int q = 0; q < 12; q++) {
     const int c = wave + 4 * q;   // wave-uniform chunk id: 0..2 dc, 3..47 rest
-    if (c < 3) __builtin_amdgcn_global_load_lds((GPtr)(d4 + c * 64 + lane), (LPtr)(l4 + c * 64), 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((GPtr)(r4 + (c - 3) * 64 + lane), (LPtr)(lr4 + (c - 3) * 64), 16, 0, 0);
+    if (c < 3) __builtin_amdgcn_global_load_lds((GPtr)(d4 + c * 64 + lane), (LPtr)(l4 + c * 64), 16, 0, AUX);
+    else __builtin_amdgcn_global_load_lds((GPtr)(r4 + (c - 3) * 64 + lane), (LPtr)(lr4 + (c - 3) * 64), 16, 0, AUX);
   }
 }
 __device__ __forceinline__ void stage_sh_wait() { __builtin_amdgcn_s_waitcnt(0); }
@@ -193,6 +198,7 @@ __device__ __forceinline__ void unstage_sh_linear(const float *__restrict__ lds,
                                                   float *__restrict__ g_rest, size_t i0) {
   float4 *d4 = reinterpret_cast<float4 *>(g_dc + i0 * 3), *r4 = reinterpret_cast<float4 *>(g_rest + i0 * 45);
   const float4 *l4 = reinterpret_cast<const float4 *>(lds), *lr4 = reinterpret_cast<const float4 *>(lds + kShLinearRest);
+  // (plain stores: nontemporal ones measured 95.7 against 94 us for the kernel)
   for (int e = threadIdx.x; e < 256 * 3 / 4; e += 256) d4[e] = l4[e];
   for (int e = threadIdx.x; e < 256 * 45 / 4; e += 256) r4[e] = lr4[e];
 }
@@ -288,11 +294,34 @@ __device__ __forceinline__ void adam_leaf(const AdamEpi &ad, int k, float *__res
   float *pp = param + at, *pm_ = ad.m[k] + at, *pv = ad.v[k] + at;
   float pvals[n], m[n], v[n];
 #pragma unroll
-  for (int q = 0; q < n; q++) { pvals[q] = p_in ? p_in[q] : pp[q]; m[q] = pm_[q]; v[q] = pv[q]; }
+  for (int q = 0; q < n; q++) { pvals[q] = p_in ? p_in[q] : pp[q]; m[q] = adam_ld1(pm_ + q); v[q] = adam_ld1(pv + q); }
 #pragma unroll
   for (int q = 0; q < n; q++) adam_one(pvals[q], gr[q], m[q], v[q], ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
 #pragma unroll
-  for (int q = 0; q < n; q++) { pp[q] = pvals[q]; pm_[q] = m[q]; pv[q] = v[q]; }
+  for (int q = 0; q < n; q++) { adam_st1(pp + q, pvals[q]); adam_st1(pm_ + q, m[q]); adam_st1(pv + q, v[q]); }
+}
+// The same with the two moments asked for EARLY (before the SH phase of the kernel, which hides their latency; left to
+// adam_leaf the four leaves are four dependent rounds of load - compute - store behind one another, because the compiler
+// may not move a leaf's loads above the previous leaf's stores).  Slots: means 0-2, opacity 3, scales 4-6, rotation 7-10.
+struct AdamGeomMoments { float m[11], v[11]; };
+template <int n>
+__device__ __forceinline__ void adam_moments_load(const AdamEpi &ad, int k, size_t at, float *m, float *v) {
+  if (!ad.m[k]) return;
+#pragma unroll
+  for (int q = 0; q < n; q++) { m[q] = adam_ld1(ad.m[k] + at + q); v[q] = adam_ld1(ad.v[k] + at + q); }
+}
+template <int n>
+__device__ __forceinline__ void adam_leaf_pre(const AdamEpi &ad, int k, float *__restrict__ param, size_t at, const float *gr,
+                                              const float *p_in, float *m, float *v) {
+  if (!ad.m[k]) return;
+  float *pp = param + at, *pm_ = ad.m[k] + at, *pv = ad.v[k] + at;
+  float pvals[n];
+#pragma unroll
+  for (int q = 0; q < n; q++) pvals[q] = p_in ? p_in[q] : pp[q];
+#pragma unroll
+  for (int q = 0; q < n; q++) adam_one(pvals[q], gr[q], m[q], v[q], ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
+#pragma unroll
+  for (int q = 0; q < n; q++) { adam_st1(pp + q, pvals[q]); adam_st1(pm_ + q, m[q]); adam_st1(pv + q, v[q]); }
 }
 __device__ __forceinline__ void adam_one4(const AdamEpi &ad, int k, float4 &p, const float4 g, float4 &m, float4 &v) {
   adam_one(p.x, g.x, m.x, v.x, ad.omb1, ad.beta2, ad.omb2, ad.step_size[k], ad.inv_sqrt_bc2, ad.eps);
@@ -303,25 +332,44 @@ __device__ __forceinline__ void adam_one4(const AdamEpi &ad, int k, float4 &p, c
 // The SH leaves of a block, gradient rows in LDS.  Linear layout (a full block of the training layout): two 16-byte streams
 // per array; the parameters are read again from global memory - the block streamed those 46 KB into LDS microseconds ago
 // (L2) and has since overwritten them there with their gradients.
+// The streams are software-pipelined by hand: a thread holds FOUR (p, m, v) triples, the two it is computing on and the two
+// it has asked for next.  Left as a plain loop the compiler keeps one triple per thread - load, ~180 instructions of IEEE
+// sqrt and division, store, and only then the next load: with twelve waves per CU that is ~27 KB in flight per CU, 5.3 TB/s
+// for the kernel; see profiles/r06_fused_adam_step.txt for what the deeper pipeline buys.
+template <int N4>   // float4 elements of the block's slice of one leaf
+__device__ __forceinline__ void adam_stream4(const AdamEpi &ad, int k, const float4 *__restrict__ g4, float4 *__restrict__ P,
+                                             float4 *__restrict__ M, float4 *__restrict__ V) {
+  static_assert(N4 >= 256, "every thread has a first element");
+  int e = threadIdx.x;
+  float4 p0 = adam_ld4(P + e), m0 = adam_ld4(M + e), v0 = adam_ld4(V + e), p1, m1, v1;
+  if (e + 256 < N4) { p1 = adam_ld4(P + e + 256); m1 = adam_ld4(M + e + 256); v1 = adam_ld4(V + e + 256); }
+  for (; e < N4; e += 512) {
+    float4 p2, m2, v2, p3, m3, v3;
+    if (e + 512 < N4) { p2 = adam_ld4(P + e + 512); m2 = adam_ld4(M + e + 512); v2 = adam_ld4(V + e + 512); }
+    if (e + 768 < N4) { p3 = adam_ld4(P + e + 768); m3 = adam_ld4(M + e + 768); v3 = adam_ld4(V + e + 768); }
+    adam_one4(ad, k, p0, g4[e], m0, v0);
+    adam_st4(P + e, p0); adam_st4(M + e, m0); adam_st4(V + e, v0);
+    if (e + 256 < N4) {
+      adam_one4(ad, k, p1, g4[e + 256], m1, v1);
+      adam_st4(P + e + 256, p1); adam_st4(M + e + 256, m1); adam_st4(V + e + 256, v1);
+    }
+    p0 = p2; m0 = m2; v0 = v2; p1 = p3; m1 = m3; v1 = v3;
+  }
+}
 __device__ __forceinline__ void adam_sh_linear(const AdamEpi &ad, const float *__restrict__ lds, float *__restrict__ dc,
                                                float *__restrict__ rest, size_t i0) {
   const float4 *l4 = reinterpret_cast<const float4 *>(lds), *lr4 = reinterpret_cast<const float4 *>(lds + kShLinearRest);
   if (ad.m[1]) {
     float4 *P = reinterpret_cast<float4 *>(dc + i0 * 3), *M = reinterpret_cast<float4 *>(ad.m[1] + i0 * 3), *V = reinterpret_cast<float4 *>(ad.v[1] + i0 * 3);
     for (int e = threadIdx.x; e < 256 * 3 / 4; e += 256) {
-      float4 p = P[e], m = M[e], v = V[e];
+      float4 p = adam_ld4(P + e), m = adam_ld4(M + e), v = adam_ld4(V + e);
       adam_one4(ad, 1, p, l4[e], m, v);
-      P[e] = p; M[e] = m; V[e] = v;
+      adam_st4(P + e, p); adam_st4(M + e, m); adam_st4(V + e, v);
     }
   }
-  if (ad.m[2]) {
-    float4 *P = reinterpret_cast<float4 *>(rest + i0 * 45), *M = reinterpret_cast<float4 *>(ad.m[2] + i0 * 45), *V = reinterpret_cast<float4 *>(ad.v[2] + i0 * 45);
-    for (int e = threadIdx.x; e < 256 * 45 / 4; e += 256) {
-      float4 p = P[e], m = M[e], v = V[e];
-      adam_one4(ad, 2, p, lr4[e], m, v);
-      P[e] = p; M[e] = m; V[e] = v;
-    }
-  }
+  if (ad.m[2])
+    adam_stream4<256 * 45 / 4>(ad, 2, lr4, reinterpret_cast<float4 *>(rest + i0 * 45), reinterpret_cast<float4 *>(ad.m[2] + i0 * 45),
+                               reinterpret_cast<float4 *>(ad.v[2] + i0 * 45));
 }
 // ... and the padded layout (the last, partial block; any K): element by element
 __device__ __forceinline__ void adam_sh_rows(const AdamEpi &ad, const float *__restrict__ lds, float *__restrict__ dc,
