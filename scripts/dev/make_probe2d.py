@@ -7,7 +7,8 @@ hit loop switchable off by -D flags, to see what each section adds to the launch
 
 Flags: PROBE_NO_ATOMIC (the read-out lanes keep their value, no atomic), PROBE_NO_READOUT (no result-tile write / read-out /
 atomic), PROBE_NO_MFMA (no A-operand reads, no MFMAs), PROBE_NO_FLUSH (the pair is dropped), PROBE_NO_WMAX (the per-hit scale is a
-constant: no wave maximum), PROBE_NO_VALUES (no splits, no matrix writes), PROBE_EVAL_ONLY (every hit ends after its ballot).
+constant: no wave maximum), PROBE_HALF_WRITES / PROBE_DOUBLE_WRITES (four / sixteen of the eight matrix-row writes per hit,
+same arithmetic), PROBE_NO_SPLIT (raw bits written: the sixteen split instructions gone, same LDS traffic), PROBE_EVAL_ONLY (every hit ends after its ballot).
 """
 import os
 import sys
@@ -40,12 +41,24 @@ rep("  auto flush_pair = [&]() {\n", "  auto flush_pair = [&]() {\n#ifdef PROBE_
 rep("        const uint32_t eb = wave_max_u32(__float_as_uint(fmaxf(fmaxf(fabsf(t), fabsf(dL_dz)), w))) >> 23;",
     "#ifdef PROBE_NO_WMAX\n        const uint32_t eb = 120u;\n#else\n"
     "        const uint32_t eb = wave_max_u32(__float_as_uint(fmaxf(fmaxf(fabsf(t), fabsf(dL_dz)), w))) >> 23;\n#endif")
-# the values
-rep("        rowp[0] = term(dp0); rowp[k2XStride] = term(dp1);",
-    "#ifdef PROBE_NO_VALUES\n        asm volatile(\"\" ::\"v\"(dp0), \"v\"(dp1), \"v\"(dp2), \"v\"(zr), \"v\"(z2), \"v\"(t2), \"v\"(t), \"v\"(w));\n#else\n"
-    "        rowp[0] = term(dp0); rowp[k2XStride] = term(dp1);")
-rep("        rowp[6 * k2XStride] = term(t); rowp[7 * k2XStride] = term(w * kWCarry);",
-    "        rowp[6 * k2XStride] = term(t); rowp[7 * k2XStride] = term(w * kWCarry);\n#endif")
+# only half of the matrix rows written (all eight values still computed), no fp16 split (raw bits written), every row written twice
+rep("        rowp[0] = term(dp0); rowp[k2XStride] = term(dp1);\n        rowp[2 * k2XStride] = term(dp2); rowp[3 * k2XStride] = term(zr);\n"
+    "        rowp[4 * k2XStride] = term(z2); rowp[5 * k2XStride] = term(t2);\n        rowp[6 * k2XStride] = term(t); rowp[7 * k2XStride] = term(w * kWCarry);",
+    "#if defined(PROBE_HALF_WRITES)\n"
+    "        rowp[0] = term(dp0); rowp[k2XStride] = term(dp1); rowp[2 * k2XStride] = term(dp2); rowp[3 * k2XStride] = term(zr);\n"
+    "        { uint32_t a_ = term(z2), b_ = term(t2), c_ = term(t), d_ = term(w * kWCarry); asm volatile(\"\" ::\"v\"(a_), \"v\"(b_), \"v\"(c_), \"v\"(d_)); }\n"
+    "#elif defined(PROBE_DOUBLE_WRITES)\n"
+    "        rowp[0] = term(dp0); rowp[k2XStride] = term(dp1); rowp[2 * k2XStride] = term(dp2); rowp[3 * k2XStride] = term(zr);\n"
+    "        rowp[4 * k2XStride] = term(z2); rowp[5 * k2XStride] = term(t2); rowp[6 * k2XStride] = term(t); rowp[7 * k2XStride] = term(w * kWCarry);\n"
+    "        { volatile uint32_t *r2 = rowp; r2[0] = term(dp0); r2[k2XStride] = term(dp1); r2[2 * k2XStride] = term(dp2); r2[3 * k2XStride] = term(zr);\n"
+    "          r2[4 * k2XStride] = term(z2); r2[5 * k2XStride] = term(t2); r2[6 * k2XStride] = term(t); r2[7 * k2XStride] = term(w * kWCarry); }\n"
+    "#else\n"
+    "        rowp[0] = term(dp0); rowp[k2XStride] = term(dp1);\n        rowp[2 * k2XStride] = term(dp2); rowp[3 * k2XStride] = term(zr);\n"
+    "        rowp[4 * k2XStride] = term(z2); rowp[5 * k2XStride] = term(t2);\n        rowp[6 * k2XStride] = term(t); rowp[7 * k2XStride] = term(w * kWCarry);\n"
+    "#endif")
+rep("        auto term = [](float x) { return kExact ? __float_as_uint(x) : split_one(x); };",
+    "#ifdef PROBE_NO_SPLIT\n        auto term = [](float x) { return __float_as_uint(x); };\n#else\n"
+    "        auto term = [](float x) { return kExact ? __float_as_uint(x) : split_one(x); };\n#endif")
 # eval only
 rep("      if (live == 0) continue;\n      // The per-pixel recurrence runs under `valid`",
     "      if (live == 0) continue;\n#ifdef PROBE_EVAL_ONLY\n      asm volatile(\"\" ::\"v\"(h.s0), \"v\"(h.s1), \"v\"(h.depth), \"v\"(h.Go), \"v\"(h.rdepth));\n      continue;\n#endif\n"
