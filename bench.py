@@ -99,7 +99,7 @@ def cpu_baseline(raw, cam, deg, W, H):
     # (scorp_amd/loss.py restates gs3dgs/utils/loss_utils.py:17-73), forward + backward on the oracle's image - at
     # min(cores, 32) threads and at every core (a depthwise 11x11 conv2d over 3 x 1200 x 1600 does not scale to 256
     # threads: oversubscribed it is several times slower); the baseline takes the faster of the two
-    from scorp_amd.loss import l1_loss, ssim
+    from scorp_amd.loss import l1_loss, ssim_torch as ssim
     gt = (torch.tensor(o.color) + 0.05).clamp(0, 1)
     loss_t = {}
     for nt in sorted({min(cores, 32), cores}):
@@ -722,31 +722,47 @@ def main():
     dt_exact, dt_split = (None, dt_twin) if exact_is_headline else (dt_twin, None)
     R._tls.backward_flags = 0     # the extras and the secondary records below run the library's defaults
     # extra (not part of `value`): what an UNMODIFIED SCORP script gets (north_star: "train_3dgs.py ... run unchanged") - the
-    # reference's own call pattern per view (train_3dgs.py:94-152): GaussianModel properties (torch activations + cat),
-    # render() with the exact pair count (one 8-byte device-to-host read per view), the torch formulation of l1_loss / ssim
-    # (scorp_amd/loss.py restates gs3dgs/utils/loss_utils.py:17-73: five depthwise 11x11 conv2d), loss.backward() through
-    # torch autograd.  Same rasterizer kernels (the library's default backward), everything around them as the reference has it.
+    # reference's own call pattern per view (train_3dgs.py:94-152): render(cam, gaussians, pipe, bg) with the reference's
+    # PipelineParams (arguments/__init__.py: convert_SHs_python, compute_cov3D_python, debug - nothing of this package's), the
+    # exact pair count (one 8-byte device-to-host read per view), l1_loss / ssim by the reference's names
+    # (scorp_amd/loss.py restates gs3dgs/utils/loss_utils.py:17-73), loss.backward() through torch autograd, the library's
+    # default rasterizer backward.  What the package does by itself for such a caller: render() hands the stock
+    # GaussianModel's raw leaves to the kernels (no torch activations / cat), `ssim` answers from the HIP loss kernels.
+    # `torch_activations_and_ssim`: the same step with both switched off (pipe.fused_activations = False, ssim_torch) -
+    # torch sigmoid / exp / normalize / cat and five depthwise 11x11 conv2d per view: round 6's first definition of the figure.
     dropin = None
     if world == 1 and not surfels and side_streams is None and not args.no_secondary:
         try:
-            from scorp_amd.loss import l1_loss as ref_l1, ssim as ref_ssim
-            pipe_ref = Pipe()
-            pipe_ref.fused_activations = False
+            from scorp_amd.loss import l1_loss as ref_l1, ssim as ref_ssim, ssim_torch
+
+            class RefPipe:          # the reference's PipelineParams
+                convert_SHs_python = False
+                compute_cov3D_python = False
+                debug = False
+
+            class TorchPipe(RefPipe):
+                fused_activations = False
             PairPolicy.mode = "exact"
 
-            def step_dropin(i):
+            def step_dropin(i, pipe_=RefPipe, ssim_fn=ref_ssim):
                 cam, gt = my_cams[i % len(my_cams)], gts[i % len(my_cams)]
-                out = render3d(cam, model, pipe_ref, bg)
+                out = render3d(cam, model, pipe_, bg)
                 img = out["render"]
-                loss_ = (1.0 - 0.2) * ref_l1(img, gt) + 0.2 * (1.0 - ref_ssim(img, gt))
+                loss_ = (1.0 - 0.2) * ref_l1(img, gt) + 0.2 * (1.0 - ssim_fn(img, gt))
                 loss_.backward()
                 for p in params:
                     p.grad = None
             n_d = max(8, min(args.steps, 24))
             dt_d, _ = _event_region(lambda: [step_dropin(i) for i in range(4)], lambda: [step_dropin(4 + i) for i in range(n_d)])
+            dt_t, _ = _event_region(lambda: [step_dropin(i, TorchPipe, ssim_torch) for i in range(2)],
+                                    lambda: [step_dropin(2 + i, TorchPipe, ssim_torch) for i in range(8)])
             dropin = {"value": round(n_d / dt_d, 1), "ms_per_step": round(dt_d / n_d * 1e3, 3), "steps": n_d,
-                      "step": "reference call pattern: torch activations + cat, render() with exact pair count (8-byte D2H per view), "
-                              "torch l1_loss + ssim (5 depthwise conv2d), autograd backward; library-default rasterizer backward"}
+                      "step": "reference call pattern: render(cam, gaussians, pipe, bg) with the reference's PipelineParams and exact pair "
+                              "count (8-byte D2H per view), l1_loss + ssim by the reference's names, autograd backward; library-default "
+                              "rasterizer backward (render() takes the stock model's raw leaves, ssim runs on the HIP loss kernels)",
+                      "torch_activations_and_ssim": {"value": round(8 / dt_t, 1), "ms_per_step": round(dt_t / 8 * 1e3, 3),
+                                                     "step": "the same with torch sigmoid / exp / normalize / cat and ssim as five "
+                                                             "depthwise conv2d (MIOpen)"}}
         except Exception as e:   # noqa: BLE001   (an extra: never costs the headline)
             dropin = {"error": f"{type(e).__name__}: {e}"[:200]}
         finally:

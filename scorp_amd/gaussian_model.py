@@ -212,6 +212,17 @@ class GaussianModel:
         L = build_scaling_rotation(scaling_modifier * self.get_scaling, self._rotation)
         return strip_symmetric(L @ L.transpose(1, 2))
 
+    def stock_activations(self):
+        """True while the activation functions and the property getters are the stock ones, i.e. while the kernels' own
+        sigmoid / exp / normalize / dc-rest concat compute what get_opacity / get_scaling / get_rotation / get_features
+        would: render() then takes the raw leaves by itself (a `pipe` without a `fused_activations` attribute - the
+        reference's PipelineParams has none)."""
+        cls = type(self)
+        return (self.scaling_activation is torch.exp and self.opacity_activation is torch.sigmoid
+                and self.rotation_activation is torch.nn.functional.normalize
+                and all(getattr(cls, n, None) is getattr(GaussianModel, n)
+                        for n in ("get_xyz", "get_scaling", "get_rotation", "get_opacity", "get_features", "raw_leaves")))
+
     def raw_leaves(self):
         """(_features_dc, _features_rest, _opacity, _scaling, _rotation) for the fused-activation render path."""
         return self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation

@@ -2,9 +2,13 @@
 gs3dgs/utils/image_utils.py:18-20: `l1_loss`, `ssim` (11x11 Gaussian window, sigma 1.5, zero padding 5,
 C1=0.01^2, C2=0.03^2, mean over all elements) and `psnr`.
 
-`ssim` here is the torch formulation (five depthwise convolutions, as in the reference) with the window cached
-per device instead of rebuilt on the CPU and uploaded on every call (loss_utils.py:45-49).  The fused HIP
-version lives behind scorp_amd.fused_loss (same numbers, one pass).
+`ssim_torch` is the torch formulation (five depthwise convolutions, as in the reference) with the window cached per
+device instead of rebuilt on the CPU and uploaded on every call (loss_utils.py:45-49).  `ssim` - the reference's name,
+what an unmodified training script calls - answers from the HIP loss kernels (scorp_amd.fused_loss, lambda = 1) when its
+arguments are what train_3dgs.py:106-107 passes (a C x H x W float32 GPU image against a ground truth that needs no
+gradient, the default 11-wide window, the scalar mean) and from `ssim_torch` otherwise: MIOpen's depthwise convolutions
+take 9.4 ms per 1600x1200 view, forward + backward (85 % of the reference's call pattern around this library's
+rasterizer), the HIP kernels 0.1 ms.
 """
 from math import exp
 
@@ -40,7 +44,22 @@ def _window(window_size, channel, like):
     return _WINDOWS[key]
 
 
+def _hip_ssim_applies(img1, img2, window_size, size_average):
+    return (torch.is_tensor(img1) and torch.is_tensor(img2) and img1.is_cuda and img2.is_cuda and img1.dim() == 3
+            and img1.shape == img2.shape and img1.dtype == torch.float32 and img2.dtype == torch.float32
+            and window_size == 11 and size_average and not img2.requires_grad)
+
+
 def ssim(img1, img2, window_size=11, size_average=True):
+    """gs3dgs/utils/loss_utils.py:51-73 by name and value; see the module docstring for which arguments the HIP kernels
+    serve.  (The kernels return (1 - lambda) L1 + lambda (1 - SSIM); lambda = 1 leaves 1 - SSIM.)"""
+    if _hip_ssim_applies(img1, img2, window_size, size_average):
+        from .fused_loss import fused_l1_ssim_loss
+        return 1.0 - fused_l1_ssim_loss(img1, img2, 1.0)
+    return ssim_torch(img1, img2, window_size, size_average)
+
+
+def ssim_torch(img1, img2, window_size=11, size_average=True):
     channel = img1.size(-3)
     window = _window(window_size, channel, img1)
     pad = window_size // 2

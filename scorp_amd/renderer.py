@@ -15,6 +15,15 @@ from .sh import eval_sh
 _ZEROS = {}
 
 
+
+def _fused_activations(pipe, pc):
+    """`pipe.fused_activations` if the caller set it; otherwise yes for this package's GaussianModel with its stock
+    activations (gaussian_model.GaussianModel.stock_activations) - same numbers, no torch activations / cat per view."""
+    flag = getattr(pipe, "fused_activations", None)
+    if flag is None:
+        return hasattr(pc, "raw_leaves") and getattr(pc, "stock_activations", lambda: False)()
+    return bool(flag) and hasattr(pc, "raw_leaves")
+
 def _grad_sink(xyz, requires_grad=True):
     """A fresh leaf of zeros shaped like xyz (the screen-space gradient sink) over a cached, never-written storage."""
     key = (xyz.shape[0], xyz.dtype, xyz.device)
@@ -48,7 +57,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
     # Fast path of the build's own harnesses: hand the model's raw leaves to the kernels (activations + SH concat fused
     # in). Same numbers as the branch below; taken only when no python-side colour / covariance branch is requested.
-    if (override_color is None and getattr(pipe, "fused_activations", False) and hasattr(pc, "raw_leaves")
+    if (override_color is None and _fused_activations(pipe, pc)
             and not getattr(pipe, "compute_cov3D_python", False) and not getattr(pipe, "convert_SHs_python", False)):
         f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw = pc.raw_leaves()
         rendered_image, radii, rendered_depth, rendered_alpha = rasterize_gaussians_raw(

@@ -17,6 +17,15 @@ from .rasterizer3d import GaussianRasterizationSettings
 from .sh import RGB2SH, eval_sh
 
 
+
+def _fused_activations(pipe, pc):
+    """`pipe.fused_activations` if the caller set it; otherwise yes for this package's GaussianModel with its stock
+    activations (gaussian_model.GaussianModel.stock_activations) - same numbers, no torch activations / cat per view."""
+    flag = getattr(pipe, "fused_activations", None)
+    if flag is None:
+        return hasattr(pc, "raw_leaves") and getattr(pc, "stock_activations", lambda: False)()
+    return bool(flag) and hasattr(pc, "raw_leaves")
+
 def _camera_rays(view, dev):
     """Per-pixel ray directions / origin of gs2dgs/utils/point_utils.py:9-22.  They depend only on the camera and its
     current resolution, so they are built once per (camera, resolution) and cached on the camera object — the
@@ -89,7 +98,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
 
-    fused = (override_color is None and getattr(pipe, "fused_activations", False) and hasattr(pc, "raw_leaves")
+    fused = (override_color is None and _fused_activations(pipe, pc)
              and not getattr(pipe, "compute_cov3D_python", False))
     if fused:
         f_dc, f_rest, opacity_raw, scaling_raw, rotation_raw = pc.raw_leaves()

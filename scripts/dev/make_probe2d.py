@@ -8,7 +8,8 @@ hit loop switchable off by -D flags, to see what each section adds to the launch
 Flags: PROBE_NO_ATOMIC (the read-out lanes keep their value, no atomic), PROBE_NO_READOUT (no result-tile write / read-out /
 atomic), PROBE_NO_MFMA (no A-operand reads, no MFMAs), PROBE_NO_FLUSH (the pair is dropped), PROBE_NO_WMAX (the per-hit scale is a
 constant: no wave maximum), PROBE_HALF_WRITES / PROBE_DOUBLE_WRITES (four / sixteen of the eight matrix-row writes per hit,
-same arithmetic), PROBE_NO_SPLIT (raw bits written: the sixteen split instructions gone, same LDS traffic), PROBE_EVAL_ONLY (every hit ends after its ballot).
+same arithmetic), PROBE_NO_SPLIT (raw bits written: the sixteen split instructions gone, same LDS traffic), PROBE_EXTRA_VALU / PROBE_EXTRA_SALU (eight dependent v_add_f32 / s_add_u32 more per live hit),
+PROBE_EVAL_ONLY (every hit ends after its ballot).
 """
 import os
 import sys
@@ -59,6 +60,13 @@ rep("        rowp[0] = term(dp0); rowp[k2XStride] = term(dp1);\n        rowp[2 *
 rep("        auto term = [](float x) { return kExact ? __float_as_uint(x) : split_one(x); };",
     "#ifdef PROBE_NO_SPLIT\n        auto term = [](float x) { return __float_as_uint(x); };\n#else\n"
     "        auto term = [](float x) { return kExact ? __float_as_uint(x) : split_one(x); };\n#endif")
+# eight extra independent vector (or scalar) instructions per live hit
+rep("      float inv_sg = 1.0f;\n      if constexpr (!kExact) {   // the hit's power-of-two scale",
+    "#ifdef PROBE_EXTRA_VALU\n      { float z_ = qxb; asm volatile(\"v_add_f32 %0, %0, %0\\n\\tv_add_f32 %0, %0, %0\\n\\tv_add_f32 %0, %0, %0\\n\\tv_add_f32 %0, %0, %0\\n\\t\"\n"
+    "                                 \"v_add_f32 %0, %0, %0\\n\\tv_add_f32 %0, %0, %0\\n\\tv_add_f32 %0, %0, %0\\n\\tv_add_f32 %0, %0, %0\" : \"+v\"(z_)); }\n#endif\n"
+    "#ifdef PROBE_EXTRA_SALU\n      { int z_ = s_; asm volatile(\"s_add_u32 %0, %0, 1\\n\\ts_add_u32 %0, %0, 1\\n\\ts_add_u32 %0, %0, 1\\n\\ts_add_u32 %0, %0, 1\\n\\t\"\n"
+    "                               \"s_add_u32 %0, %0, 1\\n\\ts_add_u32 %0, %0, 1\\n\\ts_add_u32 %0, %0, 1\\n\\ts_add_u32 %0, %0, 1\" : \"+s\"(z_) : : \"scc\"); }\n#endif\n"
+    "      float inv_sg = 1.0f;\n      if constexpr (!kExact) {   // the hit's power-of-two scale")
 # eval only
 rep("      if (live == 0) continue;\n      // The per-pixel recurrence runs under `valid`",
     "      if (live == 0) continue;\n#ifdef PROBE_EVAL_ONLY\n      asm volatile(\"\" ::\"v\"(h.s0), \"v\"(h.s1), \"v\"(h.depth), \"v\"(h.Go), \"v\"(h.rdepth));\n      continue;\n#endif\n"

@@ -4,7 +4,7 @@ sys.path.insert(0, '/root/repo')
 import itertools
 import numpy as np, torch
 from scorp_amd.fused_loss import fused_l1_ssim_loss
-from scorp_amd.loss import l1_loss, ssim
+from scorp_amd.loss import l1_loss, ssim_torch as ssim
 dev = torch.device('cuda:0')
 hs = [1, 2, 5, 10, 11, 12, 33, 34, 35, 63, 64, 65, 67, 68, 69, 100, 102, 103, 137, 1200]
 ws = [1, 3, 9, 11, 31, 32, 33, 54, 63, 64, 65, 74, 127, 128, 129, 200, 1600]

@@ -27,7 +27,7 @@ def test_fused_loss_matches_reference_golden(golden, dev):
                                              ((3, 1200, 1600), False, 0.2), ((3, 5, 7), True, 0.8)])
 def test_fused_loss_matches_torch_formulation(shape, masked, lam, dev):
     from scorp_amd.fused_loss import fused_l1_ssim_loss
-    from scorp_amd.loss import l1_loss, ssim
+    from scorp_amd.loss import l1_loss, ssim_torch as ssim
     g = torch.Generator(device=dev).manual_seed(shape[1])
     x = torch.rand(shape, device=dev, generator=g)
     y = (x + 0.1 * torch.randn(shape, device=dev, generator=g)).clamp(0, 1)
@@ -53,7 +53,7 @@ def test_masked_loss_over_mostly_empty_mask_takes_the_same_values(shape, box, de
     kernels answer those from constants.  Against the torch formulation, and BIT FOR BIT against the same kernels run the
     long way round (no mask, inputs multiplied by it beforehand): the loss value, and the gradient = unmasked gradient x mask."""
     from scorp_amd.fused_loss import fused_l1_ssim_loss
-    from scorp_amd.loss import l1_loss, ssim
+    from scorp_amd.loss import l1_loss, ssim_torch as ssim
     lam = 0.2
     g = torch.Generator(device=dev).manual_seed(shape[2])
     x = torch.rand(shape, device=dev, generator=g)
@@ -73,3 +73,22 @@ def test_masked_loss_over_mostly_empty_mask_takes_the_same_values(shape, box, de
     ref.backward()
     assert abs(l_masked.item() - ref.item()) < 5e-6
     assert (x1.grad - x2.grad).abs().max().item() <= 2e-3 * max(x2.grad.abs().max().item(), 1e-12)
+
+
+def test_ssim_by_the_reference_name_is_served_by_the_hip_kernels(dev):
+    """`scorp_amd.loss.ssim(image, gt)` as train_3dgs.py:107 calls it: value and gradient of the torch formulation, from the HIP
+    loss kernels; other argument forms (a window size, per-image means, a batch dimension, CPU tensors) take the torch form."""
+    from scorp_amd.loss import l1_loss, ssim, ssim_torch
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand((3, 120, 200), device=dev, generator=g)
+    y = (x + 0.1 * torch.randn((3, 120, 200), device=dev, generator=g)).clamp(0, 1)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    a = 0.8 * l1_loss(x1, y) + 0.2 * (1.0 - ssim(x1, y))
+    b = 0.8 * l1_loss(x2, y) + 0.2 * (1.0 - ssim_torch(x2, y))
+    assert type(ssim(x1, y).grad_fn).__name__ != type(ssim_torch(x2, y).grad_fn).__name__   # (not the same graph)
+    a.backward(); b.backward()
+    assert abs(a.item() - b.item()) < 5e-6
+    assert (x1.grad - x2.grad).abs().max().item() < 2e-3 * x2.grad.abs().max().item()
+    assert abs(ssim(x, y, 7).item() - ssim_torch(x, y, 7).item()) == 0.0                       # torch form
+    assert torch.equal(ssim(x[None], y[None], 11, False), ssim_torch(x[None], y[None], 11, False))
+    assert abs(ssim(x.cpu(), y.cpu()).item() - ssim_torch(x.cpu(), y.cpu()).item()) == 0.0
