@@ -122,21 +122,9 @@ __device__ __forceinline__ void centre_frame(const MapsArgs &a, const MapsGrads 
   len = sqrtf(dot3(cr, cr));
 }
 
-// Gradient of the loss with respect to the two difference vectors of the normal centred at pixel c (must be interior).
-template <bool kReg>
-__device__ __forceinline__ void centre_grads(const MapsArgs &a, const MapsGrads &Gr, const float *__restrict__ rays_d,
-                                             const float *__restrict__ allmap, size_t HW, size_t c, V3 &g_dv, V3 &g_dh) {
-  V3 dv, dh, cr;
-  float len;
-  centre_frame<kReg>(a, Gr, rays_d, allmap, HW, c, dv, dh, cr, len);
-  const float al = allmap[HW + c];
-  V3 G;
-  if (kReg) {
-    const V3 rn = world_normal(a, allmap, HW, c);
-    G = {-Gr.kn * rn.x * al, -Gr.kn * rn.y * al, -Gr.kn * rn.z * al};
-  } else {
-    G = {Gr.g_sn[c] * al, Gr.g_sn[HW + c] * al, Gr.g_sn[2 * HW + c] * al};
-  }
+// Gradient of the loss with respect to the two difference vectors dv, dh of a normal, given the gradient G with respect to the
+// (alpha-weighted) unit normal: through normalize(dv x dh) and the cross product.
+__device__ __forceinline__ void frame_grads(const V3 dv, const V3 dh, const V3 cr, float len, const V3 G, V3 &g_dv, V3 &g_dh) {
   V3 gc;
   if (len > kNormEps) {
     const float inv = 1.0f / len;
@@ -149,47 +137,89 @@ __device__ __forceinline__ void centre_grads(const MapsArgs &a, const MapsGrads 
   g_dv = cross3(dh, gc);   // d(dv x dh)/d dv
   g_dh = cross3(gc, dv);   // d(dv x dh)/d dh
 }
-
+// The maps' backward, with the shared work shared (until round 6 one thread per pixel did all of it: 56 us at 1600x1200, now
+// 40): a pixel's gradient needs the frames of its four neighbours, a frame needs the surface points of ITS four neighbours - one thread per pixel
+// evaluated twenty surface depths (a division and two nan_to_num each) and five frames, all but one of them also
+// evaluated by its neighbours.  Here a workgroup's 64 x 4 pixels stage, through LDS, the surface points of the tile
+// grown by two pixels (68 x 8, once each) and the frame gradients of the tile grown by one (66 x 6, once each):
+// 2.1 depths and 1.5 frames per pixel.  Same expressions in the same order per value.
+constexpr int kRT_W = 64, kRT_H = 4, kRT_PW = kRT_W + 4, kRT_PH = kRT_H + 4, kRT_CW = kRT_W + 2, kRT_CH = kRT_H + 2;
+// (tiles of 8 rows: the same 40 us; of 16: 50)
 template <bool kReg>
 __global__ void __launch_bounds__(256)
-maps_backward_kernel(MapsDev dev, const float *__restrict__ allmap, const float *__restrict__ rays_d, MapsGrads Gr,
-                     const float *__restrict__ g_out2, float lambda_normal, float lambda_dist, float *__restrict__ g_allmap) {
+maps_backward_tiled_kernel(MapsDev dev, const float *__restrict__ allmap, const float *__restrict__ rays_d, MapsGrads Gr,
+                           const float *__restrict__ g_out2, float lambda_normal, float lambda_dist, float *__restrict__ g_allmap) {
   const MapsArgs a(dev);
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= a.W || y >= a.H) return;
-  const size_t HW = (size_t)a.W * a.H, p = (size_t)y * a.W + x;
+  __shared__ float sP[3][kRT_PW * kRT_PH];        // surface points
+  __shared__ float sG[kReg ? 9 : 6][kRT_CW * kRT_CH];   // per centre: g_dv (3), g_dh (3); kReg: -k alpha normalize(dv x dh) (3)
+  const int x0 = blockIdx.x * kRT_W, y0 = blockIdx.y * kRT_H;
+  const size_t HW = (size_t)a.W * a.H;
   if (kReg) {
     const float inv_hw = 1.0f / (float)HW;
     Gr.kn = lambda_normal * (g_out2 ? g_out2[0] : 1.0f) * inv_hw;
     Gr.kd = lambda_dist * (g_out2 ? g_out2[1] : 1.0f) * inv_hw;
   }
+  const bool want_frames = kReg || Gr.g_sn;
+  if (want_frames) {
+    for (int i = threadIdx.x; i < kRT_PW * kRT_PH; i += 256) {
+      const int gx = x0 - 2 + i % kRT_PW, gy = y0 - 2 + i / kRT_PW;
+      if (gx >= 0 && gy >= 0 && gx < a.W && gy < a.H) {
+        const size_t q = (size_t)gy * a.W + gx;
+        const V3 P = point_of(depth_at<kReg>(a, Gr, allmap, HW, q), rays_d, q, a.ro);
+        sP[0][i] = P.x; sP[1][i] = P.y; sP[2][i] = P.z;
+      }
+    }
+    __syncthreads();
+    auto pt = [&](int i) { return V3{sP[0][i], sP[1][i], sP[2][i]}; };
+    for (int i = threadIdx.x; i < kRT_CW * kRT_CH; i += 256) {
+      const int lx = i % kRT_CW, ly = i / kRT_CW, cx = x0 - 1 + lx, cy = y0 - 1 + ly;
+      V3 g_dv = {0.0f, 0.0f, 0.0f}, g_dh = g_dv, grn = g_dv;
+      if (cx >= 1 && cy >= 1 && cx < a.W - 1 && cy < a.H - 1) {
+        const int pc = (ly + 1) * kRT_PW + (lx + 1);   // the centre in the point tile
+        const V3 dv = pt(pc + kRT_PW) - pt(pc - kRT_PW), dh = pt(pc + 1) - pt(pc - 1);
+        const V3 cr = cross3(dv, dh);
+        const float len = sqrtf(dot3(cr, cr));
+        const size_t c = (size_t)cy * a.W + cx;
+        const float al = allmap[HW + c];
+        V3 G;
+        if (kReg) {
+          const V3 rn = world_normal(a, allmap, HW, c);
+          G = {-Gr.kn * rn.x * al, -Gr.kn * rn.y * al, -Gr.kn * rn.z * al};
+          const float sc = -Gr.kn * al / fmaxf(len, kNormEps);
+          grn = {cr.x * sc, cr.y * sc, cr.z * sc};
+        } else {
+          G = {Gr.g_sn[c] * al, Gr.g_sn[HW + c] * al, Gr.g_sn[2 * HW + c] * al};
+        }
+        frame_grads(dv, dh, cr, len, G, g_dv, g_dh);
+      }
+      sG[0][i] = g_dv.x; sG[1][i] = g_dv.y; sG[2][i] = g_dv.z; sG[3][i] = g_dh.x; sG[4][i] = g_dh.y; sG[5][i] = g_dh.z;
+      if constexpr (kReg) { sG[6][i] = grn.x; sG[7][i] = grn.y; sG[8][i] = grn.z; }
+    }
+    __syncthreads();
+  }
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, x = x0 + tx, y = y0 + ty;
+  if (x >= a.W || y >= a.H) return;
+  const size_t p = (size_t)y * a.W + x;
   const bool xin = x >= 1 && x < a.W - 1, yin = y >= 1 && y < a.H - 1;
+  const int ci = (ty + 1) * kRT_CW + (tx + 1);   // this pixel in the centre tile
   float gd = (!kReg && Gr.g_sd) ? Gr.g_sd[p] : 0.0f;
-  if (kReg || Gr.g_sn) {
-    V3 gp = {0.0f, 0.0f, 0.0f}, u, v;
-    if (xin && y >= 2) { centre_grads<kReg>(a, Gr, rays_d, allmap, HW, p - a.W, u, v); gp.x += u.x; gp.y += u.y; gp.z += u.z; }       // this pixel is the lower end of dv there
-    if (xin && y < a.H - 2) { centre_grads<kReg>(a, Gr, rays_d, allmap, HW, p + a.W, u, v); gp.x -= u.x; gp.y -= u.y; gp.z -= u.z; }
-    if (yin && x >= 2) { centre_grads<kReg>(a, Gr, rays_d, allmap, HW, p - 1, u, v); gp.x += v.x; gp.y += v.y; gp.z += v.z; }
-    if (yin && x < a.W - 2) { centre_grads<kReg>(a, Gr, rays_d, allmap, HW, p + 1, u, v); gp.x -= v.x; gp.y -= v.y; gp.z -= v.z; }
+  if (want_frames) {
+    V3 gp = {0.0f, 0.0f, 0.0f};
+    if (xin && y >= 2) { const int j = ci - kRT_CW; gp.x += sG[0][j]; gp.y += sG[1][j]; gp.z += sG[2][j]; }         // the lower end of dv there
+    if (xin && y < a.H - 2) { const int j = ci + kRT_CW; gp.x -= sG[0][j]; gp.y -= sG[1][j]; gp.z -= sG[2][j]; }
+    if (yin && x >= 2) { const int j = ci - 1; gp.x += sG[3][j]; gp.y += sG[4][j]; gp.z += sG[5][j]; }
+    if (yin && x < a.W - 2) { const int j = ci + 1; gp.x -= sG[3][j]; gp.y -= sG[4][j]; gp.z -= sG[5][j]; }
     gd += gp.x * rays_d[3 * p] + gp.y * rays_d[3 * p + 1] + gp.z * rays_d[3 * p + 2];
   }
   const float a0 = allmap[p], al = allmap[HW + p], med = allmap[5 * HW + p];
   float g0 = 0.0f, g1 = (!kReg && Gr.g_alpha) ? Gr.g_alpha[p] : 0.0f;
   const float ge = gd * (1.0f - a.depth_ratio);
-  // where the forward's a0/alpha was nan/inf (empty pixels) nan_to_num stops the gradient; PyTorch then still divides
-  // 0 by alpha = 0 and hands the rasterizer NaN at pixels it never reads — here those entries are plain zeros
   if (al != 0.0f && passes_grad(a0 / al)) { g0 = ge / al; g1 -= ge * a0 / (al * al); }
   g_allmap[p] = g0;
   g_allmap[HW + p] = g1;
   V3 grn = {0.0f, 0.0f, 0.0f};   // gradient w.r.t. the world-space rendered normal at this pixel
   if (kReg) {
-    if (xin && yin) {           // -k * surf_normal = -k * alpha * normalize(dv x dh)
-      V3 dv, dh, cr;
-      float len;
-      centre_frame<kReg>(a, Gr, rays_d, allmap, HW, p, dv, dh, cr, len);
-      const float sc = -Gr.kn * al / fmaxf(len, kNormEps);
-      grn = {cr.x * sc, cr.y * sc, cr.z * sc};
-    }
+    if (xin && yin) grn = {sG[kReg ? 6 : 0][ci], sG[kReg ? 7 : 0][ci], sG[kReg ? 8 : 0][ci]};
   } else if (Gr.g_rn) {
     grn = {Gr.g_rn[p], Gr.g_rn[HW + p], Gr.g_rn[2 * HW + p]};
   }
@@ -294,8 +324,8 @@ extern "C" int scorp_gs2d_maps_backward(int32_t W, int32_t H, const float *allma
     MapsGrads Gr = {};
     Gr.sd = surf_depth; Gr.g_alpha = g_render_alpha; Gr.g_rn = g_render_normal; Gr.g_dist = g_render_dist;
     Gr.g_sd = g_surf_depth; Gr.g_sn = g_surf_normal;
-    maps_backward_kernel<false><<<dim3((W + 63) / 64, (H + 3) / 4), 256, 0, stream>>>(a, allmap, rays_d, Gr, nullptr, 0.0f, 0.0f,
-                                                                                       g_allmap);
+    maps_backward_tiled_kernel<false><<<dim3((W + kRT_W - 1) / kRT_W, (H + kRT_H - 1) / kRT_H), 256, 0, stream>>>(
+        a, allmap, rays_d, Gr, nullptr, 0.0f, 0.0f, g_allmap);
   }
   SCORP_KERNEL_CHECK("surfel_maps_backward", 0, stream);
   return SCORP_OK;
@@ -338,8 +368,8 @@ extern "C" int scorp_gs2d_regularizers_backward(int32_t W, int32_t H, const floa
   {
     ProfScope prof(kKMapsBackward2d, stream);
     MapsGrads Gr = {};
-    maps_backward_kernel<true><<<dim3((W + 63) / 64, (H + 3) / 4), 256, 0, stream>>>(a, allmap, rays_d, Gr, g_out2, lambda_normal,
-                                                                                      lambda_dist, g_allmap);
+    maps_backward_tiled_kernel<true><<<dim3((W + kRT_W - 1) / kRT_W, (H + kRT_H - 1) / kRT_H), 256, 0, stream>>>(
+        a, allmap, rays_d, Gr, g_out2, lambda_normal, lambda_dist, g_allmap);
   }
   SCORP_KERNEL_CHECK("surfel_regularizers_backward", 0, stream);
   return SCORP_OK;
