@@ -451,13 +451,15 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
         }
       }
       float al[k2FGroup], dz[k2FGroup], mm[k2FGroup];
+      bool okv[k2FGroup];   // (wave masks in scalar registers: the straight-line group keeps them there)
 #pragma unroll
       for (int i = 0; i < k2FGroup; i++) {
         Eval2 h;
         const bool ok = eval_surfel(g0[i], g1[i], g2[i], g3[i], qxb, qyb, pxf, pyf, h) & (kFull || i < nslots);
+        okv[i] = ok;
         al[i] = ok ? h.alpha : 0.0f;
         dz[i] = ok ? h.depth : 1.0f;
-        mm[i] = fn * (1.0f - kNearZ * (ok ? h.rdepth : 1.0f));
+        mm[i] = __builtin_fmaf(-fn * kNearZ, ok ? h.rdepth : 1.0f, fn);   // the backward's m_d, to the bit
       }
 #pragma unroll
       for (int i = 0; i < k2FGroup; i++) {
@@ -473,7 +475,7 @@ blend2d_forward_wave_kernel(const uint32_t *__restrict__ tile_start, const uint3
           const float A = 1.0f - T, mz = mm[i];
           dist += (mz * mz * A + M2 - 2.0f * mz * M1) * w;
           Dp += dz[i] * w; M1 += mz * w; M2 += mz * mz * w;
-          const bool contributes = ae > 0.0f;
+          const bool contributes = okv[i] & ok;   // = (ae > 0): a hit that passed eval_surfel has alpha >= 1 / 255 (two scalar masks)
           const bool is_med = contributes & (T > 0.5f);
           med = is_med ? dz[i] : med;
           if constexpr (kForBackward) med_c = is_med ? pos[i] : med_c;
