@@ -231,7 +231,20 @@ __device__ __forceinline__ void preprocess_body(const PgArgs &a, float *s_sh, Sp
   const bool vis = active && g.vis;
   float rgb[3] = {0.0f, 0.0f, 0.0f};
   int clamp_bits = 0;
-  if (a.shs) {
+  if (DEG == 0 && a.shs) {
+    // Degree 0 (the objects of the pose sweep and of the post-refinement, 45 stacked views per launch): the colour is three
+    // floats of the Gaussian's own row - read directly.  Through the LDS rows this instantiation carried the 50 KB array of the
+    // degree-3 one (three workgroups per CU for a kernel that is a chain of loads) and two workgroup barriers.
+    if (vis) {
+      const float *d = a.shs + (SPLIT ? (size_t)3 : (size_t)3 * a.K) * i;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        rgb[q] = SH_C0 * d[q] + 0.5f;
+        if (rgb[q] < 0.0f) clamp_bits |= 1 << q;
+        rgb[q] = fmaxf(rgb[q], 0.0f);
+      }
+    }
+  } else if (a.shs) {
     if (lin) stage_sh_wait();
     if (__syncthreads_or(vis ? 1 : 0)) {  // a block with nothing visible never touches its SH rows
       if (!lin) {
@@ -262,7 +275,7 @@ template <int DEG, bool SPLIT>
 __global__ void __launch_bounds__(256)
 preprocess_kernel(PgArgs a, SplatRec *__restrict__ rec, BinRec *__restrict__ bin, uint64_t *__restrict__ tile_mask,
                   int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
-  __shared__ __attribute__((aligned(16))) float s_sh[256 * kShStride];   // direct global->LDS loads land 16-byte words
+  __shared__ __attribute__((aligned(16))) float s_sh[DEG == 0 ? 4 : 256 * kShStride];   // direct global->LDS loads land 16-byte words
   if constexpr (SPLIT && DEG == 3) {
     if (a.shs != nullptr && a.K == 16 && !a.cov3D_precomp && a.N - (int)blockIdx.x * 256 >= 256) {
       preprocess_body<DEG, SPLIT, true>(a, s_sh, rec, bin, tile_mask, radii, tile_count);
