@@ -495,9 +495,22 @@ class GaussianModel:
     _stats_norm_components = 2     # add_densification_stats below norms grad[:, :2] (gs3dgs/scene/gaussian_model.py:603-605)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        """Accumulates |dL/d(ndc xy)| of the visible splats — this is what pins the scale of the means2D gradient."""
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        """Accumulates |dL/d(ndc xy)| of the visible splats — this is what pins the scale of the means2D gradient.
+        (gaussian_model.py:603-605.  With a boolean mask the update is written over ALL rows - the same row norms, zero added
+        where the mask is off - so that no `nonzero` compaction and no host synchronisation runs; the reference's two
+        boolean-mask indexings cost ~0.2 ms per iteration at 1 M Gaussians.)"""
+        self._masked_stats_add(viewspace_point_tensor.grad[:, :2], update_filter)
+
+    def _masked_stats_add(self, grad_cols, update_filter):
+        if torch.is_tensor(update_filter) and update_filter.dtype == torch.bool and update_filter.dim() == 1 \
+                and update_filter.shape[0] == self.xyz_gradient_accum.shape[0]:
+            norm = torch.norm(grad_cols, dim=-1, keepdim=True)
+            f = update_filter.unsqueeze(-1)
+            self.xyz_gradient_accum += torch.where(f, norm, torch.zeros_like(norm))
+            self.denom += f.to(self.denom.dtype)
+        else:       # index tensors and anything else: the reference's statements
+            self.xyz_gradient_accum[update_filter] += torch.norm(grad_cols[update_filter], dim=-1, keepdim=True)
+            self.denom[update_filter] += 1
 
     def accumulate_view_stats(self, viewspace_point_tensor, update_filter, radii, skip_flag=None):
         """One view's share of the densification statistics, train_3dgs.py:180-181 in one step:

@@ -178,8 +178,7 @@ class GaussianModel2D(GaussianModel):
     _stats_norm_components = 3     # the norm below runs over the WHOLE row (gs2dgs/scene/gaussian_model.py:494-495)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        self._masked_stats_add(viewspace_point_tensor.grad, update_filter)   # (the whole row; see GaussianModel._masked_stats_add)
 
     # ---- the "tuning mask" of gs2dgs/scene/gaussian_model.py:60,210-222,498-508: the surfels present when
     # prepare_gs_tuning_mask() was called (the first `num_mask` rows: later ones are appended by densification) are held
