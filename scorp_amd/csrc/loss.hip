@@ -64,7 +64,7 @@ __device__ __forceinline__ LossTile loss_tile(int gx, int gy, int C) {
 // ---------------------------------------------------------------------------------------------------------
 // Forward: ONE WAVE per strip of 64 columns x kStripRows rows of one channel, no workgroup barriers.  The wave
 // walks its strip top to bottom one image row at a time: the row (64 + 10 halo columns) is loaded two rows ahead,
-// x, y, x^2 + y^2, xy go through a per-wave LDS row buffer from which every lane reads its 11 taps (horizontal
+// (x, y, x^2 + y^2, xy) go through a per-wave LDS row buffer from which every lane reads its 11 taps (horizontal
 // pass), and the vertical pass lives in registers: the last 11 rows' horizontal sums form a ring that is indexed
 // statically because the row loop is unrolled by 11.  (The first form, 32x32 tiles per workgroup with the two passes
 // separated by barriers as in the backward below, spent most of a workgroup's life waiting and needed 36 KB of LDS:
@@ -97,11 +97,13 @@ static inline int strip_waves(int C, int H, int W) { return C * ((W + 63) / 64) 
 __global__ void __launch_bounds__(256)
 ssim_l1_forward_strip_kernel(const float *__restrict__ img, const float *__restrict__ gt, const float *__restrict__ mask,
                              int C, int H, int W, Window win, float *__restrict__ dmaps, float *__restrict__ partials) {
-  __shared__ float s_row[4][4][kRowBuf];   // [wave][x, y, x^2 + y^2, xy][column]
+  // [wave][column] of (x, y, x^2 + y^2, xy): a tap is ONE 16-byte LDS read.  (Four arrays [map][column], two ds_read2_b32 per
+  // tap, until late in round 6: same box 44.6 -> 40.2 us - the horizontal pass was paying the LDS pipe per instruction.)
+  __shared__ __attribute__((aligned(16))) float4 s_row4[4][kRowBuf];
   const StripJob job = strip_job(C, H, W);
   if (!job.valid) return;
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float(*buf)[kRowBuf] = s_row[wv];
+  float4 *buf4 = s_row4[wv];
   const int ch = job.ch, cx0 = job.cx0, ry0 = job.ry0;
   const size_t HW = (size_t)H * W, CHW = (size_t)C * HW;
   const float *xp = img + ch * HW, *yp = gt + ch * HW;
@@ -194,11 +196,11 @@ ssim_l1_forward_strip_kernel(const float *__restrict__ img, const float *__restr
       {
         const float m = (rin && cin_a) ? cur.ma : 0.0f;
         const float xv = cur.xa * m, yv = cur.ya * m;
-        buf[0][lane] = xv; buf[1][lane] = yv; buf[2][lane] = xv * xv + yv * yv; buf[3][lane] = xv * yv;
+        buf4[lane] = make_float4(xv, yv, xv * xv + yv * yv, xv * yv);
         if (lane < 2 * kLH) {
           const float m2 = (rin && cin_b) ? cur.mb : 0.0f;
           const float x2 = cur.xb * m2, y2 = cur.yb * m2;
-          buf[0][64 + lane] = x2; buf[1][64 + lane] = y2; buf[2][64 + lane] = x2 * x2 + y2 * y2; buf[3][64 + lane] = x2 * y2;
+          buf4[64 + lane] = make_float4(x2, y2, x2 * x2 + y2 * y2, x2 * y2);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -207,9 +209,10 @@ ssim_l1_forward_strip_kernel(const float *__restrict__ img, const float *__restr
 #pragma unroll
       for (int k = 0; k < 11; k++) {
         const float w = win.w[k];
-        h0 += w * buf[0][lane + k]; h1 += w * buf[1][lane + k]; h2 += w * buf[2][lane + k]; h3 += w * buf[3][lane + k];
+        const float4 b = buf4[lane + k];
+        h0 += w * b.x; h1 += w * b.y; h2 += w * b.z; h3 += w * b.w;
+        if (k == kLH) { cx[u] = b.x; cy[u] = b.y; }
       }
-      cx[u] = buf[0][lane + kLH]; cy[u] = buf[1][lane + kLH];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();                      // the next row's writes come after these reads
       hist[0][u] = h0; hist[1][u] = h1; hist[2][u] = h2; hist[3][u] = h3;
