@@ -74,3 +74,63 @@ def test_bench_self_launcher_builds_the_torchrun_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
     assert cmd[-7].endswith("bench.py")
     assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_add_densification_stats_without_mask_compaction_equals_the_reference_statements():
+    """gaussian_model.py:603-605 (3DGS: norm over x, y) and gs2dgs/scene/gaussian_model.py:494-495 (2DGS: the whole row): with a
+    boolean mask the update runs over all rows - same bits as the two boolean-mask indexings - and an index tensor takes the
+    reference's statements as they stand."""
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.renderer2d import GaussianModel2D
+    from scorp_amd.synthetic import make_gaussians
+    torch.manual_seed(3)
+    for cls, dims in ((GaussianModel, 3), (GaussianModel2D, 2)):
+        raw = make_gaussians(500, 1, 1, scale_dims=dims)
+        m = cls.from_raw(raw, 1, device="cpu")
+        a0, d0 = torch.rand(500, 1), torch.rand(500, 1).round()
+        vp = torch.zeros(500, 3, requires_grad=True)
+        vp.grad = torch.randn(500, 3)
+        f = torch.rand(500) > 0.4
+        cols = vp.grad[f, :2] if dims == 3 else vp.grad[f]
+        ra, rd = a0.clone(), d0.clone()
+        ra[f] += torch.norm(cols, dim=-1, keepdim=True)
+        rd[f] += 1
+        for filt in (f, torch.nonzero(f).squeeze(-1)):
+            m.xyz_gradient_accum, m.denom = a0.clone(), d0.clone()
+            m.add_densification_stats(vp, filt)
+            assert torch.equal(m.xyz_gradient_accum, ra) and torch.equal(m.denom, rd)
+
+
+def test_render_takes_raw_leaves_by_itself_only_for_a_stock_model():
+    """renderer._fused_activations: no `fused_activations` attribute on the pipe (the reference's PipelineParams) -> the raw-leaf
+    path iff the model's activation functions and getters are this package's own; an explicit flag decides otherwise."""
+    from scorp_amd.gaussian_model import GaussianModel
+    from scorp_amd.renderer import _fused_activations
+    from scorp_amd.renderer2d import GaussianModel2D, _fused_activations as fused2d
+    from scorp_amd.synthetic import make_gaussians
+
+    class RefPipe:
+        convert_SHs_python = False
+        compute_cov3D_python = False
+        debug = False
+
+    class Off(RefPipe):
+        fused_activations = False
+
+    class On(RefPipe):
+        fused_activations = True
+
+    class Doubled(GaussianModel):
+        @property
+        def get_scaling(self):
+            return 2.0 * super().get_scaling
+
+    m = GaussianModel.from_raw(make_gaussians(10, 1, 1), 1, device="cpu")
+    m2 = GaussianModel2D.from_raw(make_gaussians(10, 1, 1, scale_dims=2), 1, device="cpu")
+    sub = Doubled.from_raw(make_gaussians(10, 1, 1), 1, device="cpu")
+    assert _fused_activations(RefPipe, m) and fused2d(RefPipe, m2)
+    assert not _fused_activations(RefPipe, sub)              # an overridden getter: the torch activations are what it means
+    assert not _fused_activations(Off, m) and _fused_activations(On, sub)
+    m.opacity_activation = lambda x: torch.sigmoid(x) * 0.5
+    assert not _fused_activations(RefPipe, m)
+    assert not _fused_activations(RefPipe, object())         # (somebody else's model class)
