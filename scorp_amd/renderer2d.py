@@ -14,17 +14,10 @@ import torch.nn as nn
 from .gaussian_model import GaussianModel, build_rotation, inverse_sigmoid
 from .rasterizer2d import GaussianRasterizer, rasterize_surfels_raw, surfel_maps, surfel_regularizer_losses
 from .rasterizer3d import GaussianRasterizationSettings
+from .renderer import _fused_activations
 from .sh import RGB2SH, eval_sh
 
 
-
-def _fused_activations(pipe, pc):
-    """`pipe.fused_activations` if the caller set it; otherwise yes for this package's GaussianModel with its stock
-    activations (gaussian_model.GaussianModel.stock_activations) - same numbers, no torch activations / cat per view."""
-    flag = getattr(pipe, "fused_activations", None)
-    if flag is None:
-        return hasattr(pc, "raw_leaves") and getattr(pc, "stock_activations", lambda: False)()
-    return bool(flag) and hasattr(pc, "raw_leaves")
 
 def _camera_rays(view, dev):
     """Per-pixel ray directions / origin of gs2dgs/utils/point_utils.py:9-22.  They depend only on the camera and its
