@@ -92,3 +92,28 @@ def test_ssim_by_the_reference_name_is_served_by_the_hip_kernels(dev):
     assert abs(ssim(x, y, 7).item() - ssim_torch(x, y, 7).item()) == 0.0                       # torch form
     assert torch.equal(ssim(x[None], y[None], 11, False), ssim_torch(x[None], y[None], 11, False))
     assert abs(ssim(x.cpu(), y.cpu()).item() - ssim_torch(x.cpu(), y.cpu()).item()) == 0.0
+
+
+def test_host_patched_reference_ssim_runs_on_the_hip_kernels(dev):
+    """scorp_amd.hostpatch.patch_ssim (SCORP_AMD_ACCELERATE=1): a module-level torch `ssim` - here a clone of the torch formulation
+    in a module of its own, standing in for gs3dgs/utils/loss_utils.py - keeps its function object and answers GPU calls of the
+    training shape from the HIP loss kernels: same value and gradient as its original code (kept as `ssim_torch`)."""
+    import inspect
+    import types
+    import scorp_amd.loss as L
+    from scorp_amd.hostpatch import patch_ssim
+    mod = types.ModuleType("standin.loss_utils")
+    exec(compile(inspect.getsource(L), "standin_loss_utils.py", "exec"), mod.__dict__)
+    mod.ssim = types.FunctionType(mod.ssim_torch.__code__, mod.__dict__, "ssim", mod.ssim_torch.__defaults__)
+    early = mod.ssim
+    assert patch_ssim(mod) and mod.ssim is early and not patch_ssim(mod)
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.rand((3, 150, 170), device=dev, generator=g)
+    y = (x + 0.1 * torch.randn((3, 150, 170), device=dev, generator=g)).clamp(0, 1)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    a, b = early(x1, y), mod.ssim_torch(x2, y)
+    assert any("FusedL1SSIM" in type(f[0]).__name__ for f in a.grad_fn.next_functions if f[0] is not None)   # (1 - fused loss)
+    a.backward(); b.backward()
+    assert abs(a.item() - b.item()) < 5e-6
+    assert (x1.grad - x2.grad).abs().max().item() < 2e-3 * x2.grad.abs().max().item()
+    assert torch.equal(early(x, y, 7), mod.ssim_torch(x, y, 7))            # other arguments: the original code

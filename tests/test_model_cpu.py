@@ -134,3 +134,48 @@ def test_render_takes_raw_leaves_by_itself_only_for_a_stock_model():
     m.opacity_activation = lambda x: torch.sigmoid(x) * 0.5
     assert not _fused_activations(RefPipe, m)
     assert not _fused_activations(RefPipe, object())         # (somebody else's model class)
+
+
+def test_host_patch_keeps_the_function_object_and_falls_back_to_the_original(monkeypatch):
+    """scorp_amd.hostpatch.patch_ssim on a stand-in for gs3dgs/utils/loss_utils.py: names bound BEFORE the patch see the new body,
+    CPU tensors (and anything the HIP kernels do not serve) take the original code bit for bit, a second patch is a no-op, and
+    nothing happens without SCORP_AMD_ACCELERATE=1."""
+    import sys
+    import types
+    from scorp_amd import hostpatch
+    from scorp_amd.loss import ssim_torch
+    src = '''
+import torch
+import torch.nn.functional as F
+from math import exp
+def gaussian(window_size, sigma):
+    gauss = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    return gauss / gauss.sum()
+def create_window(window_size, channel):
+    w = gaussian(window_size, 1.5).unsqueeze(1)
+    return w.mm(w.t()).float().unsqueeze(0).unsqueeze(0).expand(channel, 1, window_size, window_size).contiguous()
+def ssim(img1, img2, window_size=11, size_average=True):
+    channel = img1.size(-3)
+    window = create_window(window_size, channel).type_as(img1)
+    mu1 = F.conv2d(img1, window, padding=window_size // 2, groups=channel)
+    mu2 = F.conv2d(img2, window, padding=window_size // 2, groups=channel)
+    s1 = F.conv2d(img1 * img1, window, padding=window_size // 2, groups=channel) - mu1 * mu1
+    s2 = F.conv2d(img2 * img2, window, padding=window_size // 2, groups=channel) - mu2 * mu2
+    s12 = F.conv2d(img1 * img2, window, padding=window_size // 2, groups=channel) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))
+    return m.mean() if size_average else m.mean(1).mean(1).mean(1)
+'''
+    mod = types.ModuleType("gs3dgs.utils.loss_utils")
+    exec(compile(src, "loss_utils_standin.py", "exec"), mod.__dict__)
+    early = mod.ssim                                   # what `from gs3dgs.utils.loss_utils import ssim` bound earlier
+    x, y = torch.rand(3, 40, 50), torch.rand(3, 40, 50)
+    before = early(x, y)
+    monkeypatch.setitem(sys.modules, "gs3dgs.utils.loss_utils", mod)
+    monkeypatch.delenv("SCORP_AMD_ACCELERATE", raising=False)
+    assert hostpatch.accelerate_reference() == [] and not getattr(mod.ssim, "_scorp_patched", False)
+    monkeypatch.setenv("SCORP_AMD_ACCELERATE", "1")
+    assert hostpatch.accelerate_reference() == ["gs3dgs.utils.loss_utils"]
+    assert mod.ssim is early and early._scorp_patched and hostpatch.accelerate_reference() == []
+    assert torch.equal(early(x, y), before) and torch.equal(mod.ssim_torch(x, y), before)      # CPU: the original code
+    assert torch.equal(early(x[None], y[None], 7, False), mod.ssim_torch(x[None], y[None], 7, False))
+    assert abs(float(before) - float(ssim_torch(x, y))) < 1e-6
